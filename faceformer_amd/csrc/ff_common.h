@@ -1,0 +1,68 @@
+// Shared helpers of libfaceformer_hip (gfx950 only; wavefront = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "faceformer_hip.h"
+
+#define FF_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error reporting -------------------------------------------------------------------------
+void ff_set_error(const char* fmt, ...);
+
+#define FF_CHECK_ARG(cond, ...)           \
+  do {                                    \
+    if (!(cond)) {                        \
+      ff_set_error(__VA_ARGS__);          \
+      return FF_ERR_ARG;                  \
+    }                                     \
+  } while (0)
+
+#define FF_CHECK_HIP(expr)                                                             \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      ff_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return FF_ERR_LAUNCH;                                                            \
+    }                                                                                  \
+  } while (0)
+
+#define FF_CHECK_LAUNCH() FF_CHECK_HIP(hipGetLastError())
+
+#define FF_RETURN_IF(expr)       \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != FF_OK) return _s;  \
+  } while (0)
+
+static inline bool ff_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int ff_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t ff_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device helpers --------------------------------------------------------------------------
+__device__ __forceinline__ float ff_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, FF_WAVE);
+  return v;
+}
+__device__ __forceinline__ float ff_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, FF_WAVE));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear block id: blocks are dispatched round-robin over the 8
+// XCDs (block b -> XCD b % 8); give every XCD a contiguous range of logical ids so that
+// neighbouring tiles (which share operand panels) hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int ff_xcd_remap(int bid, int nblocks) {
+  const int NX = 8;
+  int xcd = bid % NX, idx = bid / NX;
+  int q = nblocks / NX, r = nblocks % NX;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

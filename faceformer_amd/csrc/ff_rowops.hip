@@ -1,0 +1,203 @@
+// Row-wise kernels of the decode path: LayerNorm(+pos), memory+pos, feedback gather, embedding
+// assembly.  All are HBM/L2-bandwidth bound: one wavefront per row, 16-byte loads/stores,
+// butterfly reductions through __shfl_xor (no LDS).
+#include <stdarg.h>
+
+#include "ff_common.h"
+
+// ---- library-level helpers ---------------------------------------------------------------------
+static thread_local char g_ff_error[512] = "";
+
+void ff_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_ff_error, sizeof(g_ff_error), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int ff_version(void) { return 100; }
+extern "C" const char* ff_last_error(void) { return g_ff_error; }
+extern "C" int ff_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+// ---- LayerNorm (+pos) --------------------------------------------------------------------------
+// NV = float4 chunks per lane (E <= 256*NV).  Two-pass statistics in registers (mean, then the
+// centred second moment) -- the same formula torch's CPU kernel evaluates, biased variance.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
+    float* __restrict__ ypos, int ldypos, const float* __restrict__ pos, int ldpos, int pos_div,
+    int pos_mod, int rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = E >> 2;
+  const float* xr = x + (size_t)row * ldx;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    int vi = lane + c * 64;
+    if (vi < nvec) {
+      v[c] = *reinterpret_cast<const f32x4*>(xr + vi * 4);
+      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    } else {
+      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float inv_e = 1.0f / (float)E;
+  const float mean = ff_wave_sum(s) * inv_e;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    int vi = lane + c * 64;
+    if (vi < nvec) {
+      f32x4 d = v[c] - mean;
+      ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+  }
+  const float var = ff_wave_sum(ss) * inv_e;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float* pr = nullptr;
+  if (ypos != nullptr) pr = pos + (size_t)((row / pos_div) % pos_mod) * ldpos;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    int vi = lane + c * 64;
+    if (vi < nvec) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + vi * 4);
+      f32x4 b = *reinterpret_cast<const f32x4*>(beta + vi * 4);
+      f32x4 o = (v[c] - mean) * rstd * g + b;
+      if (y != nullptr) *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + vi * 4) = o;
+      if (ypos != nullptr) {
+        f32x4 p = *reinterpret_cast<const f32x4*>(pr + vi * 4);
+        *reinterpret_cast<f32x4*>(ypos + (size_t)row * ldypos + vi * 4) = o + p;
+      }
+    }
+  }
+}
+
+extern "C" int ff_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
+                            float eps, float* y, int ldy, float* ypos, int ldypos,
+                            const float* pos, int ldpos, int pos_div, int pos_mod, int rows, int E,
+                            ff_stream_t stream) {
+  if (rows == 0) return FF_OK;
+  FF_CHECK_ARG(rows > 0 && E > 0 && (E & 3) == 0 && E <= 2048, "ff_layernorm: bad rows=%d E=%d", rows, E);
+  FF_CHECK_ARG(x && gamma && beta && (y || ypos), "ff_layernorm: null pointer");
+  FF_CHECK_ARG((ldx & 3) == 0 && ff_aligned16(x) && ff_aligned16(gamma) && ff_aligned16(beta),
+               "ff_layernorm: x/gamma/beta must be 16-byte aligned, ld %% 4 == 0");
+  FF_CHECK_ARG(!y || ((ldy & 3) == 0 && ff_aligned16(y)), "ff_layernorm: y misaligned");
+  if (ypos) {
+    FF_CHECK_ARG(pos && pos_div > 0 && pos_mod > 0 && (ldpos & 3) == 0 && (ldypos & 3) == 0 &&
+                     ff_aligned16(pos) && ff_aligned16(ypos),
+                 "ff_layernorm: bad pos arguments");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(256), grid(ff_cdiv(rows, 4));
+  const int nv = ff_cdiv(E / 4, 64);
+#define FF_LN_LAUNCH(NV)                                                                         \
+  hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, x, ldx, gamma, beta, eps, y, ldy, \
+                     ypos, ldypos, pos, ldpos, pos_div, pos_mod, rows, E)
+  if (nv <= 1) FF_LN_LAUNCH(1);
+  else if (nv <= 2) FF_LN_LAUNCH(2);
+  else if (nv <= 4) FF_LN_LAUNCH(4);
+  else FF_LN_LAUNCH(8);
+#undef FF_LN_LAUNCH
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+// ---- out = x + pos[(row / div) % mod] ----------------------------------------------------------
+__global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ x, int ldx,
+                                                      const float* __restrict__ pos, int ldpos,
+                                                      int pos_div, int pos_mod,
+                                                      float* __restrict__ out, int ldout, int rows,
+                                                      int nvec) {
+  const size_t total = (size_t)rows * nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int row = (int)(i / nvec), vi = (int)(i % nvec);
+    f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + vi * 4);
+    f32x4 p = *reinterpret_cast<const f32x4*>(pos + (size_t)((row / pos_div) % pos_mod) * ldpos + vi * 4);
+    *reinterpret_cast<f32x4*>(out + (size_t)row * ldout + vi * 4) = a + p;
+  }
+}
+
+extern "C" int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div,
+                          int pos_mod, float* out, int ldout, int rows, int E, ff_stream_t stream) {
+  if (rows == 0) return FF_OK;
+  FF_CHECK_ARG(rows > 0 && E > 0 && (E & 3) == 0 && pos_div > 0 && pos_mod > 0, "ff_add_pos: bad sizes");
+  FF_CHECK_ARG(x && pos && out && ((ldx | ldpos | ldout) & 3) == 0 && ff_aligned16(x) &&
+                   ff_aligned16(pos) && ff_aligned16(out), "ff_add_pos: bad pointers");
+  size_t total = (size_t)rows * (E / 4);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, pos,
+                     ldpos, pos_div, pos_mod, out, ldout, rows, E / 4);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+// ---- out[b,:] = memory[b / spg, tok[b], :] -----------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ memory, int S,
+                                                          int E, const int* __restrict__ tok, int B,
+                                                          int spg, float* __restrict__ out,
+                                                          int ldout) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int t = tok[b];
+  t = t < 0 ? 0 : (t >= S ? S - 1 : t);  // the reference would raise from torch.gather; clamp here
+  const float* src = memory + ((size_t)(b / spg) * S + t) * E;
+  float* dst = out + (size_t)b * ldout;
+  for (int vi = lane; vi < (E >> 2); vi += 64)
+    *reinterpret_cast<f32x4*>(dst + vi * 4) = *reinterpret_cast<const f32x4*>(src + vi * 4);
+}
+
+extern "C" int ff_gather_rows(const float* memory, int S, int E, const int* tok, int B,
+                              int seqs_per_group, float* out, int ldout, ff_stream_t stream) {
+  if (B == 0) return FF_OK;
+  FF_CHECK_ARG(B > 0 && S > 0 && E > 0 && (E & 3) == 0 && seqs_per_group > 0 && (ldout & 3) == 0,
+               "ff_gather_rows: bad sizes");
+  FF_CHECK_ARG(memory && tok && out && ff_aligned16(memory) && ff_aligned16(out), "ff_gather_rows: bad pointers");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ff_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream,
+                     memory, S, E, tok, B, seqs_per_group, out, ldout);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+// ---- embedding assembly: token rows ++ edge rows ------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_embedding_kernel(
+    const float* __restrict__ tok_embed, int num_token, const float* __restrict__ edge, int ld_edge,
+    int N, int L, int E, float* __restrict__ out) {
+  const int S = L + num_token;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N * S) return;
+  const int n = row / S, s = row % S;
+  const float* src = (s < num_token) ? tok_embed + (size_t)s * E
+                                     : edge + ((size_t)n * L + (s - num_token)) * ld_edge;
+  float* dst = out + (size_t)row * E;
+  for (int vi = lane; vi < (E >> 2); vi += 64)
+    *reinterpret_cast<f32x4*>(dst + vi * 4) = *reinterpret_cast<const f32x4*>(src + vi * 4);
+}
+
+extern "C" int ff_assemble_embedding(const float* tok_embed, int num_token, const float* edge_embed,
+                                     int ld_edge, int N, int L, int E, float* out,
+                                     ff_stream_t stream) {
+  FF_CHECK_ARG(N > 0 && L >= 0 && num_token >= 0 && E > 0 && (E & 3) == 0 && (ld_edge & 3) == 0,
+               "ff_assemble_embedding: bad sizes");
+  FF_CHECK_ARG(tok_embed && out && (L == 0 || edge_embed) && ff_aligned16(tok_embed) &&
+                   ff_aligned16(out) && ff_aligned16(edge_embed), "ff_assemble_embedding: bad pointers");
+  int rows = N * (L + num_token);
+  hipLaunchKernelGGL(assemble_embedding_kernel, dim3(ff_cdiv(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, tok_embed, num_token, edge_embed, ld_edge, N, L, E, out);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}

@@ -1,0 +1,234 @@
+/*
+ * faceformer_hip.h -- C ABI of libfaceformer_hip.so (gfx950 / MI355X).
+ *
+ * The reference (manycore-research/faceformer) is pure Python on torch and has NO FFI: the
+ * boundary of its decode path is the Python module surface `model_class(**cfg.model)(batch)`
+ * (reference faceformer/trainer.py:20,27-28).  This header is the native layer underneath the
+ * drop-in Python modules of `faceformer_amd`: every entry point replaces a group of torch operator
+ * call sites of the reference (cited per function), takes plain device pointers / sizes and a
+ * hipStream_t, returns 0 on success (negative ff_status otherwise), never allocates device memory
+ * and never synchronises the device -- except ff_decode(), which owns the greedy loop and may wait
+ * on its own stream every `sync_every` steps to evaluate the reference's stop rule.
+ *
+ * All tensors are fp32 row-major unless stated; "ld*" are leading dimensions in ELEMENTS.
+ * Pointers must be 16-byte aligned and every ld / K / E a multiple of 4 (float4 access).
+ */
+#ifndef FACEFORMER_HIP_H
+#define FACEFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ff_stream_t; /* hipStream_t */
+
+enum ff_status {
+  FF_OK = 0,
+  FF_ERR_ARG = -1,       /* bad size / alignment / unsupported shape */
+  FF_ERR_LAUNCH = -2,    /* hip launch or runtime error (see ff_last_error) */
+  FF_ERR_WORKSPACE = -3, /* workspace too small */
+  FF_ERR_NO_DEVICE = -4
+};
+
+#define FF_HEAD_DIM 64   /* attention head width supported by the kernels (reference: 512 / 8) */
+#define FF_MAX_LAYERS 16
+
+/* Library version (major*10000 + minor*100 + patch). */
+int ff_version(void);
+/* Thread-local text of the last error returned by this library ("" if none). */
+const char* ff_last_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int ff_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * G2  LayerNorm (+ positional add).  Replaces nn.LayerNorm followed by `with_pos_embed`
+ * (reference faceformer/transformer.py:168-169, 242-243, 247-249, 253; torch LayerNorm: eps inside
+ * the sqrt, biased variance, affine).
+ *   y[r,:]    = LN(x[r,:]) * gamma + beta                      (skipped if y    == NULL)
+ *   ypos[r,:] = y[r,:] + pos[((r / pos_div) % pos_mod), :]     (skipped if ypos == NULL)
+ * One wavefront per row, float4 loads, shuffle reductions.  E % 4 == 0, E <= 2048.
+ * ------------------------------------------------------------------------------------------- */
+int ff_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                 float* y, int ldy, float* ypos, int ldypos,
+                 const float* pos, int ldpos, int pos_div, int pos_mod,
+                 int rows, int E, ff_stream_t stream);
+
+/* out[r,:] = x[r,:] + pos[((r / pos_div) % pos_mod), :]   (`memory + pos`, transformer.py:249) */
+int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div, int pos_mod,
+               float* out, int ldout, int rows, int E, ff_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * G3  Dense projection on the f32 matrix cores (v_mfma_f32_32x32x2_f32).  Replaces F.linear /
+ * addmm call sites (in-proj q,k,v, out-proj, linear1+relu, linear2, project, embedding MLP;
+ * reference transformer.py:170-175, 244-255, embedding.py:30-36, model_para.py:225):
+ *   C[m,n] = act( sum_k Asel[m,k] * W[n,k] + bias[n] ) + residual[m,n]
+ * W is the nn.Linear weight layout [N,K]; Asel = A for n < n_split and A2 for n >= n_split
+ * (lets one launch produce q,k from `LN(x)+pos` and v from `LN(x)`); pass A2 = NULL to disable.
+ * bias / residual may be NULL.  residual may alias C.  act: 0 = identity, 1 = ReLU.
+ * tile: 0 = automatic, 1 = 64x64, 2 = 128x64, 3 = 128x128 block tiles (for tuning / tests).
+ * ------------------------------------------------------------------------------------------- */
+int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split,
+                const float* W, int ldw, const float* bias,
+                const float* residual, int ldr, float* C, int ldc,
+                int M, int N, int K, int act, int tile, ff_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * G4/G5/G6  Multi-head attention core: softmax(q k^T * scale + mask) v for `num_groups` groups
+ * that each share one key/value set, `num_heads` heads of FF_HEAD_DIM columns.  Replaces the
+ * q*scale / baddbmm / softmax / bmm chain of torch's multi_head_attention_forward at the call
+ * sites transformer.py:170-171 (encoder self), 244-245 (decoder self), 248-251 (decoder cross).
+ * Flash-style: key tiles staged in LDS, scores on the f32 MFMA, online softmax in registers.
+ *
+ * Row addressing (lets one kernel serve position-major decoder tensors without copies):
+ *   query/output row of (group g, query i) = g*q_group_stride + (i / q_inner)*q_outer_stride
+ *                                            + (i % q_inner)
+ *   key/value   row of (group g, key j)    = g*k_group_stride + j*k_stride
+ * Head h reads columns [h*64, h*64+64) of q/k/v and writes the same columns of o.
+ * Masking: key j of group g is ignored when j >= kv_len[g] (kv_len NULL: nk), when
+ * key_mask[g*mask_stride + j] != 0 (key_mask NULL: none) or, if causal != 0, when j > i.
+ * A query whose keys are all masked yields NaN in torch; here it yields 0 (never happens on the
+ * path: the four special-token keys are never masked, reference model.py:61-64).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ff_attn_desc {
+  const float* q; const float* k; const float* v; float* o;
+  int ldq, ldk, ldv, ldo;
+  int num_groups, num_heads;
+  int nq;                 /* queries per group */
+  int q_group_stride, q_inner, q_outer_stride;
+  int nk;                 /* max keys per group */
+  int k_group_stride, k_stride;
+  const int* kv_len;      /* [num_groups] or NULL */
+  const unsigned char* key_mask; int mask_stride; /* [num_groups, mask_stride] or NULL; 1 = masked */
+  int causal;
+  float scale;            /* 1/sqrt(64) = 0.125 on the path */
+} ff_attn_desc;
+
+int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * G7/G8/G9  Pointer head: logits of every sequence against the edge embeddings of its wireframe,
+ * padding mask, argmax, and the feedback gather of the chosen embedding row.  Replaces
+ * select_next (reference model_para.py:173-179, model.py:161-167), the per-step torch.gather
+ * (model_para.py:217-219) and the stop-rule reductions (model_para.py:232, model.py:207).
+ *   logit[b,s] = < memory[w(b), s, :], p[b, :] >,  w(b) = b / seqs_per_group
+ *   masked (mask[w,s] != 0, s >= kv_len[w], or extra_mask[b,s] != 0) -> -FLT_MAX (finfo.min, not -inf)
+ *   next_tok[b] = argmax_s (lowest index on ties)
+ * One wavefront per sequence; p in registers, embedding rows streamed with coalesced float4
+ * loads, 64-lane butterfly reduction per logit.  Optional outputs (NULL to skip):
+ *   best/second [B]   top-2 logits (parity margins),  logits [B, ldlogits] masked logits,
+ *   next_rows [B, ldnext] = memory[w(b), next_tok[b], :]  (next decoder input row),
+ *   count_lt / count_eq: *count_lt += #{b: next_tok[b] >= lt_bound}, *count_eq += #{b: next_tok[b] == eq_value}
+ *   (device counters for the stop rules; caller zeroes them).
+ * ------------------------------------------------------------------------------------------- */
+int ff_pointer_argmax(const float* p, int ldp, const float* memory, int S, int E,
+                      const unsigned char* mask, const int* kv_len,
+                      const unsigned char* extra_mask, int ldextra,
+                      int B, int seqs_per_group,
+                      int* next_tok, float* best, float* second, float* logits, int ldlogits,
+                      float* next_rows, int ldnext,
+                      int* count_ge, int ge_bound, int* count_eq, int eq_value,
+                      ff_stream_t stream);
+
+/* out[b,:] = memory[(b / seqs_per_group), tok[b], :]   (first decoder input: anchors / SOS;
+ * reference model_para.py:217-219 at step 0). */
+int ff_gather_rows(const float* memory, int S, int E, const int* tok, int B, int seqs_per_group,
+                   float* out, int ldout, ff_stream_t stream);
+
+/* value_embed[n, 0:num_token, :] = tok_embed ; value_embed[n, num_token + l, :] = edge_embed[n*L + l, :]
+ * (the torch.cat of reference embedding.py:36). */
+int ff_assemble_embedding(const float* tok_embed, int num_token, const float* edge_embed, int ld_edge,
+                          int N, int L, int E, float* out, ff_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-path engine.  Weights are the tensors of the reference state_dict,
+ * fp32, on the device, passed by pointer -- no repacking.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ff_mha_weights {
+  const float* in_proj_w;  /* [3E, E]  rows: Wq | Wk | Wv */
+  const float* in_proj_b;  /* [3E] */
+  const float* out_w;      /* [E, E] */
+  const float* out_b;      /* [E] */
+} ff_mha_weights;
+
+typedef struct ff_layer_weights {
+  ff_mha_weights self_attn;
+  ff_mha_weights cross_attn;           /* decoder layers only */
+  const float *lin1_w, *lin1_b;        /* [FF, E], [FF] */
+  const float *lin2_w, *lin2_b;        /* [E, FF], [E] */
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b; /* [E]; norm3: decoder */
+} ff_layer_weights;
+
+typedef struct ff_model {
+  int E, H, FF, num_enc_layers, num_dec_layers;
+  int in_dim;              /* num_points_per_line * point_dim (100) */
+  int num_token;           /* 4 special tokens */
+  int pos_len, qpos_len;   /* rows of the two learned position tables */
+  float ln_eps;
+  const float* tok_embed;              /* val_enc.embedding_token.weight [num_token, E] */
+  const float *emb_w1, *emb_b1;        /* val_enc.embedding_value.0  [E, in_dim], [E] */
+  const float *emb_w2, *emb_b2;        /* val_enc.embedding_value.2  [E, E], [E] */
+  const float* pos_table;              /* pos_enc.pos_embed.weight [pos_len, E] */
+  const float* qpos_table;             /* query_pos_enc.pos_embed.weight [qpos_len, E] */
+  ff_layer_weights enc[FF_MAX_LAYERS];
+  const float *enc_norm_w, *enc_norm_b;
+  ff_layer_weights dec[FF_MAX_LAYERS];
+  const float *dec_norm_w, *dec_norm_b;
+  const float *proj_w, *proj_b;        /* project [E, E], [E] */
+} ff_model;
+
+/* Encoder (a1-a4 of SURVEY.md 8a): embedding MLP + token rows, 6 pre-norm layers, final LayerNorm.
+ *   input  [N, L, in_dim]     edge polylines (flattened points)
+ *   mask   [N, S] uint8       S = L + num_token, 1 = padding key (after process_masks)
+ *   kv_len [N]    int32       1 + index of the last unmasked key of each wireframe
+ *   memory [N, S, E]          output
+ * Replaces val_enc + encoder (reference model_para.py:194,210; transformer.py:70-83). */
+size_t ff_encode_workspace_bytes(const ff_model* m, int N, int L);
+int ff_encode(const ff_model* m, const float* input, const unsigned char* mask, const int* kv_len,
+              int N, int L, float* memory, void* workspace, size_t workspace_bytes,
+              ff_stream_t stream);
+
+enum ff_variant { FF_PARALLEL = 0, FF_SEQ2SEQ = 1 };
+enum ff_decode_flags {
+  FF_REUSE_LAYER0_QKV = 1,   /* layer-0 self-attention q,k,v computed once per filled position */
+  FF_LAST_LAYER_LAST_ROW = 2,/* last decoder layer evaluated for the newest position only */
+  FF_RETURN_POINTER = 4      /* also produce project(decoder(...)) for ALL prefix rows of the last step */
+};
+
+typedef struct ff_decode_params {
+  int variant;          /* ff_variant */
+  int N;                /* wireframes */
+  int L;                /* padded edges per wireframe; S = L + num_token */
+  int F;                /* sequences per wireframe: max(num_input) (parallel) or 1 (seq2seq) */
+  int T;                /* max_face_length / label_seq_length; at most T-1 decode steps */
+  int chunk_wireframes; /* wireframes per micro-batch (<=0: all) */
+  int sync_every;       /* evaluate the stop rule on the host every k steps (<=0: only at the end) */
+  int flags;            /* ff_decode_flags */
+  int tok_sos, tok_eos; /* seq2seq start / stop tokens */
+} ff_decode_params;
+
+/* Greedy pointer decode (a5-a12 of SURVEY.md 8a).
+ *   memory, mask, kv_len : as produced by / given to ff_encode
+ *   num_input [N] int32   : real edge count per wireframe (parallel anchors, model_para.py:201-207)
+ *   extra_mask            : optional [B, S] uint8 additional pointer mask (co-edge style), or NULL
+ *   predict [N*F, T] int64: output tokens incl. the start token, zero padded after the stop step
+ *   steps_done            : host int, number of decode steps the reference semantics executed
+ *   pointer_out           : optional [steps_done, N*F, E] (FF_RETURN_POINTER), position-major
+ *   trace_logits          : optional [T-1, N*F, S] masked logits of every step (tests), or NULL
+ *   trace_best/second     : optional [T-1, N*F] top-2 logits, or NULL
+ * Stop rules reproduced exactly: parallel = first step whose tokens are all < num_token
+ * (model_para.py:232); seq2seq = cumulative EOS count == N (model.py:207-210). */
+size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p);
+int ff_decode(const ff_model* m, const ff_decode_params* p,
+              const float* memory, const unsigned char* mask, const int* kv_len,
+              const int* num_input, const unsigned char* extra_mask,
+              int64_t* predict, int* steps_done, float* pointer_out,
+              float* trace_logits, float* trace_best, float* trace_second,
+              void* workspace, size_t workspace_bytes, ff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACEFORMER_HIP_H */

@@ -1,0 +1,54 @@
+"""ORACLE TOOLING: the list of golden-vector cases (shared by `oracle/make_golden.py`, which writes
+them from the imported reference, and by the tests, which regenerate inputs/weights from the same
+recipes).  Every case is fully described by seeds + sizes; no tensor data lives here.
+
+model: E=num_model, H=num_head (head dim is always 64 here, like the reference's 512/8),
+       FF=num_feedforward, enc/dec = layer counts, L=num_lines, seq_len = max_face_length (parallel)
+       or label_seq_length (seq2seq).
+"""
+
+SMALL = dict(E=128, H=2, FF=256, enc=2, dec=2)
+FULL = dict(E=512, H=8, FF=1024, enc=6, dec=6)
+
+
+def _m(base, L, seq_len):
+    d = dict(base)
+    d.update(L=L, seq_len=seq_len)
+    return d
+
+
+CASES = [
+    # --- SurfaceFormer_Parallel -------------------------------------------------------------------
+    dict(name="par_small_default", kind="parallel", model=_m(SMALL, 24, 9), recipe="default",
+         wseed=0, n_edges=[20, 13], seeds=[1, 2]),
+    dict(name="par_small_gain4", kind="parallel", model=_m(SMALL, 24, 9), recipe="gain4",
+         wseed=0, n_edges=[20, 13], seeds=[1, 2]),
+    # ragged batch incl. a 1-edge wireframe and a full one; exercises padding anchors (token 3)
+    dict(name="par_small_ragged", kind="parallel", model=_m(SMALL, 40, 7), recipe="gain4",
+         wseed=3, n_edges=[40, 1, 17, 33], seeds=[5, 6, 7, 8]),
+    # all sequences hit a special token in one step -> early break + zero padding branch
+    dict(name="par_small_earlybreak", kind="parallel", model=_m(SMALL, 16, 10), recipe="gain4",
+         wseed=10, n_edges=[12, 9], seeds=[3, 4]),
+    dict(name="par_small_break1", kind="parallel", model=_m(SMALL, 16, 10), recipe="bias05",
+         wseed=0, n_edges=[12, 9], seeds=[3, 4]),
+    # full-size model (weights regenerated from the seed), short wireframe
+    dict(name="par_full_n40_gain4", kind="parallel", model=_m(FULL, 48, 12), recipe="gain4",
+         wseed=0, n_edges=[40], seeds=[11]),
+    dict(name="par_full_n40_default", kind="parallel", model=_m(FULL, 48, 12), recipe="default",
+         wseed=0, n_edges=[40], seeds=[11]),
+    # BASELINE config B itself: ours.yml sizes with num_lines=256, one 256-edge wireframe, 36 steps
+    dict(name="par_full_B256_default", kind="parallel", model=_m(FULL, 256, 37), recipe="default",
+         wseed=0, n_edges=[256], seeds=[0], keep_logit_rows=[0, 1, 5, 64, 128, 200, 255], slow=True),
+    dict(name="par_full_B256_gain4", kind="parallel", model=_m(FULL, 256, 37), recipe="gain4",
+         wseed=0, n_edges=[256], seeds=[0], keep_logit_rows=[0, 1, 5, 64, 128, 200, 255], slow=True),
+    # --- SurfaceFormer (seq2seq) --------------------------------------------------------------------
+    dict(name="seq_small_default", kind="seq2seq", model=_m(SMALL, 24, 30), recipe="default",
+         wseed=0, n_edges=[20, 13], seeds=[1, 2]),
+    dict(name="seq_small_gain4", kind="seq2seq", model=_m(SMALL, 24, 30), recipe="gain4",
+         wseed=0, n_edges=[20, 13], seeds=[1, 2]),
+    dict(name="seq_small_eos", kind="seq2seq", model=_m(SMALL, 16, 20), recipe="gain4",
+         wseed=6, n_edges=[12], seeds=[3]),
+    # configs/seq2seq.yml sizes (config A): L=110, T=259, one 64-edge wireframe
+    dict(name="seq_full_A64_gain4", kind="seq2seq", model=_m(FULL, 110, 259), recipe="gain4",
+         wseed=0, n_edges=[64], seeds=[3], slow=True),
+]

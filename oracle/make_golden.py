@@ -1,0 +1,167 @@
+"""ORACLE TOOLING (build container only): pin `oracle/refpath.py` against the *imported reference* and
+write the golden vectors under `tests/golden/`.
+
+Run:  python oracle/make_golden.py [--only NAME ...] [--skip-slow]
+
+For every case in `oracle/golden_cases.py` it
+  1. builds the reference model class from /root/reference (imported, never copied), loads the
+     build-owned synthetic weights (`faceformer_amd.synth`), runs `model.eval()(batch)` on CPU while
+     recording the masked logits the reference hands to `torch.argmax`;
+  2. runs `oracle.refpath` on the same weights/inputs and REQUIRES bit-identical `predict`, logits,
+     and (seq2seq) `embedding` / `pointer`;
+  3. stores inputs' recipe (not the tensors: they are regenerated from seeds), `predict`, per-step
+     best logit / top-2 margin for every sequence, the full masked logits of the selected
+     sequences, and the encoder memory (full for small cases, first rows + checksum otherwise).
+
+/root/reference does not exist on the GPU box; nothing at test/bench time imports this script.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REFERENCE = "/root/reference"
+
+
+def _import_reference():
+    """Bind the name `faceformer` to the reference tree for the duration of this script (the repo ships
+    an alias package of the same name, which must not shadow it here)."""
+    pkg = types.ModuleType("faceformer")
+    pkg.__path__ = [os.path.join(REFERENCE, "faceformer")]
+    sys.modules["faceformer"] = pkg
+    import faceformer.models as ref_models  # noqa: E402  (reference code, imported as a library)
+    return ref_models
+
+
+def _clone_batch(batch):
+    return {k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in batch.items()}
+
+
+def top2(logits):
+    """logits [B,S] -> (best value, margin to runner-up, argmax index) per row (first index on ties)."""
+    vals, idx = torch.sort(logits, dim=1, descending=True, stable=True)
+    return vals[:, 0], vals[:, 0] - vals[:, 1], torch.argmax(logits, dim=1)
+
+
+def run_case(case, ref_models):
+    sys.path.insert(0, ROOT)
+    from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec
+    from oracle import refpath
+
+    m = case["model"]
+    kind = case["kind"]
+    seq_len = m["seq_len"]
+    tok = types.SimpleNamespace(PAD=0, SOS=1, SEP=2, EOS=3, DIR0=4, DIR1=5, len=4, face_type_offset=1)
+    common = dict(num_model=m["E"], num_head=m["H"], num_feedforward=m["FF"],
+                  num_encoder_layers=m["enc"], num_decoder_layers=m["dec"], dropout=0.2,
+                  num_lines=m["L"], token=tok)
+    if kind == "parallel":
+        model = ref_models.SurfaceFormer_Parallel(max_face_length=seq_len, **common)
+    else:
+        model = ref_models.SurfaceFormer(label_seq_length=seq_len, **common)
+    model.eval()
+    spec = state_dict_spec(kind, m["L"], seq_len, m["E"], m["FF"], m["enc"], m["dec"])
+    keys = list(model.state_dict().keys())
+    assert [s[0] for s in spec] == keys, "state_dict key order differs from SURVEY Appendix B"
+    sd = make_state_dict(spec, case["recipe"], case["wseed"])
+    model.load_state_dict(sd)
+
+    batch = make_wireframes(case["n_edges"], m["L"], seq_len, kind, seeds=case["seeds"])
+    b_ref, b_orc = _clone_batch(batch), _clone_batch(batch)
+
+    rec = []
+    orig_argmax = torch.argmax
+
+    def spy(x, *a, **k):
+        rec.append(x.detach().clone())
+        return orig_argmax(x, *a, **k)
+
+    t0 = time.time()
+    torch.argmax = spy
+    try:
+        with torch.no_grad():
+            out_ref = model(b_ref)
+    finally:
+        torch.argmax = orig_argmax
+    t_ref = time.time() - t0
+
+    trace = {}
+    t0 = time.time()
+    if kind == "parallel":
+        out_orc = refpath.parallel_forward_eval(sd, b_orc, num_head=m["H"], trace=trace)
+    else:
+        out_orc = refpath.seq2seq_forward_eval(sd, b_orc, num_head=m["H"], trace=trace)
+    t_orc = time.time() - t0
+
+    ref_logits = [r.squeeze(-1) for r in rec]
+    assert torch.equal(out_ref["predict"], out_orc["predict"]), "predict differs from reference"
+    assert len(ref_logits) == len(trace["logits"])
+    for a, b in zip(ref_logits, trace["logits"]):
+        assert torch.equal(a, b), "masked logits differ from reference"
+    if kind == "seq2seq":
+        assert torch.equal(out_ref["embedding"], out_orc["embedding"])
+        assert torch.equal(out_ref["pointer"], out_orc["pointer"])
+
+    steps = len(ref_logits)
+    best = torch.stack([top2(l)[0] for l in ref_logits])       # steps x B
+    margin = torch.stack([top2(l)[1] for l in ref_logits])     # steps x B
+    B = ref_logits[0].shape[0]
+    keep = case.get("keep_logit_rows")
+    rows = list(range(B)) if keep is None else [r for r in keep if r < B]
+    logits_sel = torch.stack([l[rows] for l in ref_logits])    # steps x len(rows) x S
+    memory = trace["memory"]                                  # N x S x E
+    payload = {
+        "case": np.frombuffer(json.dumps(case, sort_keys=True).encode(), dtype=np.uint8),
+        "predict": out_ref["predict"].numpy(),
+        "steps": np.int64(steps),
+        "best": best.numpy(),
+        "margin": margin.numpy(),
+        "logit_rows": np.asarray(rows, dtype=np.int64),
+        "logits": logits_sel.numpy(),
+        "memory_abs_sum": memory.abs().double().sum(dim=(1, 2)).numpy(),
+    }
+    if memory.numel() * 4 <= 256 * 1024:
+        payload["memory"] = memory.numpy()
+    else:
+        payload["memory_head"] = memory[:, :8, :].numpy()
+    if kind == "seq2seq":
+        payload["pointer_last"] = out_ref["pointer"][:, -1, :].numpy()
+    distinct = len(set(map(tuple, out_ref["predict"].reshape(-1, seq_len).tolist())))
+    print("  %-28s steps=%3d B=%4d distinct=%4d min_margin=%.3g max|logit|=%.3g  ref %.1fs oracle %.1fs"
+          % (case["name"], steps, B, distinct, float(margin.min()),
+             float(best.abs().max()), t_ref, t_orc))
+    return payload
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--skip-slow", action="store_true")
+    args = ap.parse_args()
+    if not os.path.isdir(REFERENCE):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ref_models = _import_reference()
+    sys.path.insert(0, ROOT)
+    from oracle.golden_cases import CASES
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for case in CASES:
+        if args.only and case["name"] not in args.only:
+            continue
+        if args.skip_slow and case.get("slow"):
+            continue
+        payload = run_case(case, ref_models)
+        np.savez_compressed(os.path.join(outdir, case["name"] + ".npz"), **payload)
+    print("golden vectors written to", outdir)
+
+
+if __name__ == "__main__":
+    main()
