@@ -1,0 +1,199 @@
+// Multi-head attention core for the decode path (encoder self-, decoder self-, decoder cross-
+// attention) on the f32 matrix cores, flash style.
+//
+// One wavefront owns 32 queries of one (group, head); a block is NW such waves sharing the group's
+// key/value rows, which are staged through LDS in chunks of 64 keys (coalesced 16-byte loads; K rows
+// padded to 68 floats so the per-lane ds_read_b128 of a key row is bank-conflict free).
+//
+// Both products keep the QUERY index on the lane (l & 31) so the running max / sum / rescale of the
+// online softmax never leave the lane:
+//   S^T[key][q] = sum_d K[key][d] * Q[q][d]    A = K (LDS), B = Q (registers, pre-scaled)
+//   O^T[d][q]   = sum_key V[key][d] * P[q][key] A = V (LDS), B = P = exp(S^T - m) (the S accumulator
+//                                               registers themselves: the C-layout key index of
+//                                               register r, (r&3) + 8*(r>>2) + 4*(l>>5), is used as
+//                                               the k index of MFMA step r for A and B alike)
+// so P never moves between lanes or through LDS.  The two lane halves hold disjoint key subsets of
+// a query; they exchange only the tile max (one __shfl_xor 32) and add their partial sums at the end.
+#include <math.h>
+
+#include "ff_common.h"
+
+namespace {
+
+constexpr int KC = 64;     // keys per LDS chunk
+constexpr int K_LD = 68;   // padded K row (floats)
+constexpr int V_LD = 64;
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int q_tiles) {
+  __shared__ __attribute__((aligned(16))) float Ks[KC * K_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[KC * V_LD];
+  __shared__ float Ms[KC];
+
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+
+  // block -> (query tile, group, head); (group, head) varies fastest so that a (group, head) pair
+  // keeps landing on the same XCD (block b -> XCD b % 8) and its K/V stay in that L2.
+  const int gh = d.num_groups * d.num_heads;
+  const int qt = blockIdx.x / gh;
+  const int rem = blockIdx.x % gh;
+  const int g = rem / d.num_heads, h = rem % d.num_heads;
+
+  const int qi = (qt * NW + wave) * 32 + l32;
+  const bool q_valid = qi < d.nq;
+  const int qc = q_valid ? qi : d.nq - 1;
+  const size_t qrow = (size_t)g * d.q_group_stride + (size_t)(qc / d.q_inner) * d.q_outer_stride +
+                      (size_t)(qc % d.q_inner);
+
+  float qreg[32];
+  {
+    const float* qp = d.q + qrow * d.ldq + h * FF_HEAD_DIM + half * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(qp + c * 4);
+      qreg[c * 4 + 0] = t.x * d.scale;
+      qreg[c * 4 + 1] = t.y * d.scale;
+      qreg[c * 4 + 2] = t.z * d.scale;
+      qreg[c * 4 + 3] = t.w * d.scale;
+    }
+  }
+
+  int nk = d.nk;
+  if (d.kv_len) {
+    int kl = d.kv_len[g];
+    nk = kl < nk ? kl : nk;
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+
+  const float* kbase = d.k + (size_t)g * d.k_group_stride * d.ldk + h * FF_HEAD_DIM;
+  const float* vbase = d.v + (size_t)g * d.k_group_stride * d.ldv + h * FF_HEAD_DIM;
+
+  for (int c0 = 0; c0 < nk; c0 += KC) {
+    __syncthreads();
+    // ---- stage K / V chunk + additive mask ----
+#pragma unroll
+    for (int p = 0; p < (KC * 16) / NT; ++p) {
+      const int idx = tid + p * NT;
+      const int row = idx >> 4, c4 = idx & 15;
+      const int key = c0 + row;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (key < nk) {
+        const size_t krow = (size_t)key * d.k_stride;
+        kv = *reinterpret_cast<const f32x4*>(kbase + krow * d.ldk + c4 * 4);
+        vv = *reinterpret_cast<const f32x4*>(vbase + krow * d.ldv + c4 * 4);
+      }
+      *reinterpret_cast<f32x4*>(Ks + row * K_LD + c4 * 4) = kv;
+      *reinterpret_cast<f32x4*>(Vs + row * V_LD + c4 * 4) = vv;
+    }
+    if (tid < KC) {
+      const int key = c0 + tid;
+      bool masked = key >= nk;
+      if (!masked && d.key_mask) masked = d.key_mask[(size_t)g * d.mask_stride + key] != 0;
+      Ms[tid] = masked ? -INFINITY : 0.f;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int kt = 0; kt < KC / 32; ++kt) {
+      if (c0 + kt * 32 >= nk) break;  // block-uniform
+      // ---- S^T tile: 32 keys x 32 queries ----
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      const float* krow_p = Ks + (kt * 32 + l32) * K_LD + half * 32;
+#pragma unroll
+      for (int cg = 0; cg < 8; ++cg) {
+        f32x4 kf = *reinterpret_cast<const f32x4*>(krow_p + cg * 4);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qreg[cg * 4 + 0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qreg[cg * 4 + 1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[cg * 4 + 2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qreg[cg * 4 + 3], s, 0, 0, 0);
+      }
+      // ---- mask, online softmax (query on the lane; keys across registers and the two halves) ----
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int keyl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = s[r] + Ms[keyl];
+        if (d.causal && (c0 + keyl) > qi) v = -INFINITY;
+        s[r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
+      const float m_new = fmaxf(m_run, tmax);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = expf(m_run - m_safe);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(s[r] - m_safe);
+        s[r] = p;
+        psum += p;
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int keyl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float v0 = Vs[keyl * V_LD + l32];
+        const float v1 = Vs[keyl * V_LD + 32 + l32];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, FF_WAVE);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q_valid) {
+    float* op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 a = {o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv, o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv};
+      f32x4 b = {o1[g4 * 4 + 0] * inv, o1[g4 * 4 + 1] * inv, o1[g4 * 4 + 2] * inv, o1[g4 * 4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
+      *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = b;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
+  FF_CHECK_ARG(desc != nullptr, "ff_attention: null descriptor");
+  const ff_attn_desc d = *desc;
+  if (d.num_groups == 0 || d.nq == 0) return FF_OK;
+  FF_CHECK_ARG(d.num_groups > 0 && d.num_heads > 0 && d.nq > 0 && d.nk >= 0, "ff_attention: bad counts");
+  FF_CHECK_ARG(d.q && d.k && d.v && d.o, "ff_attention: null tensor");
+  FF_CHECK_ARG(((d.ldq | d.ldk | d.ldv | d.ldo) & 3) == 0 && ff_aligned16(d.q) && ff_aligned16(d.k) &&
+                   ff_aligned16(d.v) && ff_aligned16(d.o),
+               "ff_attention: tensors must be 16-byte aligned with ld %% 4 == 0");
+  const int width = d.num_heads * FF_HEAD_DIM;
+  FF_CHECK_ARG(d.ldq >= width && d.ldk >= width && d.ldv >= width && d.ldo >= width,
+               "ff_attention: ld smaller than num_heads*64");
+  FF_CHECK_ARG(d.q_inner > 0, "ff_attention: q_inner must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const long gh = (long)d.num_groups * d.num_heads;
+  int nw = d.nq > 64 ? 4 : (d.nq > 32 ? 2 : 1);
+  const int q_tiles = ff_cdiv(d.nq, 32 * nw);
+  const long blocks = gh * q_tiles;
+  FF_CHECK_ARG(blocks < 2147483647L, "ff_attention: grid too large");
+  if (nw == 4)
+    hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, d, q_tiles);
+  else if (nw == 2)
+    hipLaunchKernelGGL(attention_kernel<2>, dim3((unsigned)blocks), dim3(128), 0, st, d, q_tiles);
+  else
+    hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, st, d, q_tiles);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}

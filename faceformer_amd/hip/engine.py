@@ -1,0 +1,158 @@
+"""Host side of the whole-path engine: binds a model's parameters (by reference, no repacking) into
+the C `ff_model` struct and runs ff_encode / ff_decode on torch-owned device memory."""
+import ctypes as C
+
+import torch
+
+from . import lib as _L
+from .ops import _dev, _p, _stream
+
+DEFAULT_FLAGS = _L.FF_REUSE_LAYER0_QKV | _L.FF_LAST_LAYER_LAST_ROW
+
+
+def _kv_len_from_mask(mask_u8):
+    """1 + index of the last unmasked key per row (0 if every key is masked)."""
+    S = mask_u8.size(1)
+    idx = torch.arange(1, S + 1, device=mask_u8.device, dtype=torch.int32)
+    return ((mask_u8 == 0).to(torch.int32) * idx).amax(dim=1).to(torch.int32).contiguous()
+
+
+class PathEngine:
+    """Encoder + greedy pointer decode of one model instance on one ROCm device.
+
+    `tensors` is a mapping name -> fp32 CUDA tensor with the reference state_dict names
+    (SURVEY.md Appendix B).  Tensors are referenced, not copied: in-place weight updates are seen.
+    """
+
+    def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5):
+        self._lib = _L.load()
+        self._keep = {}
+        m = _L.Model()
+        get = self._get
+        self.tensors = tensors
+        E = tensors["project.weight"].shape[0]
+        m.E, m.H = E, num_head
+        m.FF = tensors["decoder.layers.0.linear1.weight"].shape[0]
+        n_enc = 1 + max([int(k.split(".")[2]) for k in tensors if k.startswith("encoder.layers.")] or [-1])
+        n_dec = 1 + max(int(k.split(".")[2]) for k in tensors if k.startswith("decoder.layers."))
+        if n_enc > _L.FF_MAX_LAYERS or n_dec > _L.FF_MAX_LAYERS:
+            raise ValueError("at most %d layers are supported" % _L.FF_MAX_LAYERS)
+        if E != num_head * _L.FF_HEAD_DIM:
+            raise _L.HipExtensionError(
+                "the HIP attention kernels need num_model == num_head * 64 (got %d, %d)" % (E, num_head))
+        m.num_enc_layers, m.num_dec_layers = n_enc, n_dec
+        m.in_dim = tensors["val_enc.embedding_value.0.weight"].shape[1]
+        m.num_token = num_token
+        m.pos_len = tensors["pos_enc.pos_embed.weight"].shape[0]
+        m.qpos_len = tensors["query_pos_enc.pos_embed.weight"].shape[0]
+        m.ln_eps = ln_eps
+        m.tok_embed = get("val_enc.embedding_token.weight")
+        m.emb_w1, m.emb_b1 = get("val_enc.embedding_value.0.weight"), get("val_enc.embedding_value.0.bias")
+        m.emb_w2, m.emb_b2 = get("val_enc.embedding_value.2.weight"), get("val_enc.embedding_value.2.bias")
+        m.pos_table, m.qpos_table = get("pos_enc.pos_embed.weight"), get("query_pos_enc.pos_embed.weight")
+
+        def mha(dst, p):
+            dst.in_proj_w, dst.in_proj_b = get(p + ".in_proj_weight"), get(p + ".in_proj_bias")
+            dst.out_w, dst.out_b = get(p + ".out_proj.weight"), get(p + ".out_proj.bias")
+
+        def layer(dst, p, decoder):
+            mha(dst.self_attn, p + ".self_attn")
+            if decoder:
+                mha(dst.cross_attn, p + ".multihead_attn")
+            dst.lin1_w, dst.lin1_b = get(p + ".linear1.weight"), get(p + ".linear1.bias")
+            dst.lin2_w, dst.lin2_b = get(p + ".linear2.weight"), get(p + ".linear2.bias")
+            dst.norm1_w, dst.norm1_b = get(p + ".norm1.weight"), get(p + ".norm1.bias")
+            dst.norm2_w, dst.norm2_b = get(p + ".norm2.weight"), get(p + ".norm2.bias")
+            if decoder:
+                dst.norm3_w, dst.norm3_b = get(p + ".norm3.weight"), get(p + ".norm3.bias")
+
+        for i in range(n_enc):
+            layer(m.enc[i], "encoder.layers.%d" % i, False)
+        m.enc_norm_w, m.enc_norm_b = get("encoder.norm.weight"), get("encoder.norm.bias")
+        for i in range(n_dec):
+            layer(m.dec[i], "decoder.layers.%d" % i, True)
+        m.dec_norm_w, m.dec_norm_b = get("decoder.norm.weight"), get("decoder.norm.bias")
+        m.proj_w, m.proj_b = get("project.weight"), get("project.bias")
+        self.model = m
+        self.E, self.H, self.num_token = E, num_head, num_token
+        self.device = tensors["project.weight"].device
+        self._ws = None
+
+    def _get(self, name):
+        t = self.tensors[name]
+        _dev(t, name)
+        if not t.is_contiguous():
+            raise ValueError("parameter %s must be contiguous" % name)
+        if t.data_ptr() % 16:
+            raise ValueError("parameter %s is not 16-byte aligned" % name)
+        self._keep[name] = t
+        return t.data_ptr()
+
+    def pointers_current(self):
+        """True while every bound tensor still lives at the address captured in the struct."""
+        return all(self.tensors[k].data_ptr() == v.data_ptr() for k, v in self._keep.items())
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), device=self.device, dtype=torch.uint8)
+        return self._ws
+
+    # ---------------------------------------------------------------------------------------------
+    def encode(self, inp, mask_u8):
+        """inp [N, L, in_dim] fp32, mask_u8 [N, S] uint8 (1 = padding) -> (memory [N,S,E], kv_len)."""
+        _dev(inp, "input"), _dev(mask_u8, "mask", torch.uint8)
+        N, L = inp.shape[0], inp.shape[1]
+        S = L + self.num_token
+        inp = inp.reshape(N, L, -1).contiguous()
+        if inp.shape[2] != self.model.in_dim:
+            raise ValueError("input has %d values per edge, model expects %d" % (inp.shape[2], self.model.in_dim))
+        mask_u8 = mask_u8.contiguous()
+        kv_len = _kv_len_from_mask(mask_u8)
+        memory = torch.empty((N, S, self.E), device=self.device, dtype=torch.float32)
+        nbytes = self._lib.ff_encode_workspace_bytes(C.byref(self.model), N, L)
+        ws = self._workspace(nbytes)
+        _L.check(self._lib.ff_encode(C.byref(self.model), _p(inp), _p(mask_u8), _p(kv_len), N, L,
+                                     _p(memory), _p(ws), ws.numel(), _stream()), "ff_encode")
+        return memory, kv_len
+
+    def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
+               chunk_wireframes=0, sync_every=4, flags=DEFAULT_FLAGS, tok_sos=1, tok_eos=3,
+               trace=False, return_pointer=False):
+        """Greedy decode. Returns dict(predict [N*F, T] int64, steps, [pointer], [trace tensors])."""
+        _dev(memory, "memory")
+        N, S, E = memory.shape
+        L = S - self.num_token
+        prm = _L.DecodeParams()
+        prm.variant, prm.N, prm.L, prm.F, prm.T = variant, N, L, F, T
+        prm.chunk_wireframes, prm.sync_every = chunk_wireframes, sync_every
+        prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0)
+        prm.tok_sos, prm.tok_eos = tok_sos, tok_eos
+        B = N * F
+        dev = self.device
+        predict = torch.empty((B, T), device=dev, dtype=torch.int64)
+        ni = None
+        if num_input is not None:
+            ni = torch.as_tensor([int(x) for x in num_input], dtype=torch.int32).to(dev)
+        pointer = torch.zeros((max(T - 1, 1), B, E), device=dev, dtype=torch.float32) if return_pointer else None
+        tl = tb = ts = None
+        if trace:
+            tl = torch.full((max(T - 1, 1), B, S), float("nan"), device=dev, dtype=torch.float32)
+            tb = torch.full((max(T - 1, 1), B), float("nan"), device=dev, dtype=torch.float32)
+            ts = torch.full((max(T - 1, 1), B), float("nan"), device=dev, dtype=torch.float32)
+        if extra_mask is not None:
+            _dev(extra_mask, "extra_mask", torch.uint8)
+            extra_mask = extra_mask.contiguous()
+        nbytes = self._lib.ff_decode_workspace_bytes(C.byref(self.model), C.byref(prm))
+        ws = self._workspace(nbytes)
+        steps = C.c_int(0)
+        _L.check(self._lib.ff_decode(
+            C.byref(self.model), C.byref(prm), _p(memory), _p(mask_u8), _p(kv_len), _p(ni),
+            _p(extra_mask), _p(predict), C.byref(steps), _p(pointer), _p(tl), _p(tb), _p(ts),
+            _p(ws), ws.numel(), _stream()), "ff_decode")
+        out = {"predict": predict, "steps": steps.value}
+        if return_pointer:
+            out["pointer"] = pointer[: steps.value]
+        if trace:
+            out["logits"], out["best"], out["second"] = tl, tb, ts
+        return out

@@ -1,0 +1,135 @@
+"""ctypes binding of libfaceformer_hip.so -- the C ABI declared in include/faceformer_hip.h.
+
+There is deliberately no fallback: if the shared library is missing or fails to load, `load()` raises
+and every op / model of this package fails loudly (the product path must never run on a substitute).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfaceformer_hip.so")
+
+FF_MAX_LAYERS = 16
+FF_HEAD_DIM = 64
+FF_PARALLEL, FF_SEQ2SEQ = 0, 1
+FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER = 1, 2, 4
+
+fptr = C.c_void_p  # device pointers travel as integers
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", fptr), ("k", fptr), ("v", fptr), ("o", fptr),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
+        ("num_groups", C.c_int), ("num_heads", C.c_int),
+        ("nq", C.c_int),
+        ("q_group_stride", C.c_int), ("q_inner", C.c_int), ("q_outer_stride", C.c_int),
+        ("nk", C.c_int),
+        ("k_group_stride", C.c_int), ("k_stride", C.c_int),
+        ("kv_len", fptr),
+        ("key_mask", fptr), ("mask_stride", C.c_int),
+        ("causal", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
+class MhaWeights(C.Structure):
+    _fields_ = [("in_proj_w", fptr), ("in_proj_b", fptr), ("out_w", fptr), ("out_b", fptr)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [
+        ("self_attn", MhaWeights), ("cross_attn", MhaWeights),
+        ("lin1_w", fptr), ("lin1_b", fptr), ("lin2_w", fptr), ("lin2_b", fptr),
+        ("norm1_w", fptr), ("norm1_b", fptr), ("norm2_w", fptr), ("norm2_b", fptr),
+        ("norm3_w", fptr), ("norm3_b", fptr),
+    ]
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("E", C.c_int), ("H", C.c_int), ("FF", C.c_int),
+        ("num_enc_layers", C.c_int), ("num_dec_layers", C.c_int),
+        ("in_dim", C.c_int), ("num_token", C.c_int),
+        ("pos_len", C.c_int), ("qpos_len", C.c_int),
+        ("ln_eps", C.c_float),
+        ("tok_embed", fptr),
+        ("emb_w1", fptr), ("emb_b1", fptr), ("emb_w2", fptr), ("emb_b2", fptr),
+        ("pos_table", fptr), ("qpos_table", fptr),
+        ("enc", LayerWeights * FF_MAX_LAYERS),
+        ("enc_norm_w", fptr), ("enc_norm_b", fptr),
+        ("dec", LayerWeights * FF_MAX_LAYERS),
+        ("dec_norm_w", fptr), ("dec_norm_b", fptr),
+        ("proj_w", fptr), ("proj_b", fptr),
+    ]
+
+
+class DecodeParams(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int), ("N", C.c_int), ("L", C.c_int), ("F", C.c_int), ("T", C.c_int),
+        ("chunk_wireframes", C.c_int), ("sync_every", C.c_int), ("flags", C.c_int),
+        ("tok_sos", C.c_int), ("tok_eos", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/faceformer_hip.h
+SIGNATURES = {
+    "ff_version": (C.c_int, []),
+    "ff_last_error": (C.c_char_p, []),
+    "ff_device_count": (C.c_int, []),
+    "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
+                               fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,
+                             C.c_int, fptr]),
+    "ff_gemm_f32": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
+    "ff_pointer_argmax": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int,
+                                    C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int,
+                                    fptr, C.c_int, fptr, C.c_int, fptr]),
+    "ff_gather_rows": (C.c_int, [fptr, C.c_int, C.c_int, fptr, C.c_int, C.c_int, fptr, C.c_int, fptr]),
+    "ff_assemble_embedding": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr,
+                                        fptr]),
+    "ff_encode_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int, C.c_int]),
+    "ff_encode": (C.c_int, [C.POINTER(Model), fptr, fptr, fptr, C.c_int, C.c_int, fptr, fptr,
+                            C.c_size_t, fptr]),
+    "ff_decode_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(DecodeParams)]),
+    "ff_decode": (C.c_int, [C.POINTER(Model), C.POINTER(DecodeParams), fptr, fptr, fptr, fptr, fptr,
+                            fptr, C.POINTER(C.c_int), fptr, fptr, fptr, fptr, fptr, C.c_size_t, fptr]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises HipExtensionError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            "HIP extension not built: %s is missing. Run `python -m faceformer_amd.hip.build` "
+            "(needs hipcc); there is no CPU fallback for the decode path." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipExtensionError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipExtensionError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ff_last_error()
+        raise HipExtensionError("%s failed with status %d: %s" % (what, status, (msg or b"").decode()))

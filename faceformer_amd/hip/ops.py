@@ -1,0 +1,166 @@
+"""Torch-tensor front end of the C-ABI kernels (device memory + stream plumbing only).
+
+Every function takes fp32 CUDA(ROCm) tensors, hands raw pointers to libfaceformer_hip.so on the
+current torch stream and returns torch tensors.  CPU tensors are rejected: there is no fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _L
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise _L.HipExtensionError(
+            "%s is on %s: the faceformer_amd decode path only runs on a ROCm device "
+            "(no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _rows(t, name):
+    """2-D row-major view [rows, cols] with unit inner stride; returns (tensor, ld)."""
+    _dev(t, name)
+    if t.dim() != 2:
+        raise ValueError("%s must be 2-D" % name)
+    if t.stride(1) != 1 and t.size(1) != 1:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0)))
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pos=None, pos_div=1, pos_mod=1, want_y=True):
+    """(y, ypos): y = LN(x); ypos = y + pos[(row // pos_div) % pos_mod] (None when pos is None)."""
+    x, ldx = _rows(x, "x")
+    rows, E = x.shape
+    y = torch.empty((rows, E), device=x.device, dtype=torch.float32) if want_y else None
+    ypos = torch.empty((rows, E), device=x.device, dtype=torch.float32) if pos is not None else None
+    if pos is not None:
+        pos, ldpos = _rows(pos, "pos")
+    else:
+        ldpos = 0
+    lib = _L.load()
+    _L.check(lib.ff_layernorm(_p(x), ldx, _p(_dev(gamma, "gamma")), _p(_dev(beta, "beta")), eps,
+                              _p(y), E, _p(ypos), E, _p(pos), ldpos, pos_div, pos_mod, rows, E,
+                              _stream()), "ff_layernorm")
+    return y, ypos
+
+
+def add_pos(x, pos, pos_div=1, pos_mod=1):
+    x, ldx = _rows(x, "x")
+    pos, ldpos = _rows(pos, "pos")
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    _L.check(_L.load().ff_add_pos(_p(x), ldx, _p(pos), ldpos, pos_div, pos_mod, _p(out), x.size(1),
+                                  x.size(0), x.size(1), _stream()), "ff_add_pos")
+    return out
+
+
+def linear(x, weight, bias=None, act=0, residual=None, x2=None, n_split=0, tile=0, out=None):
+    """out = act(xsel @ weight.T + bias) + residual on the f32 matrix cores (F.linear layout)."""
+    x, lda = _rows(x, "x")
+    weight, ldw = _rows(weight, "weight")
+    M, K = x.shape
+    N = weight.size(0)
+    if weight.size(1) != K:
+        raise ValueError("linear: x is [%d,%d] but weight is [%d,%d]" % (M, K, N, weight.size(1)))
+    if x2 is not None:
+        x2, lda2 = _rows(x2, "x2")
+        if x2.shape != x.shape or lda2 != lda:
+            raise ValueError("linear: x2 must match x")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    out, ldc = _rows(out, "out")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "residual")
+    if bias is not None:
+        _dev(bias, "bias")
+    _L.check(_L.load().ff_gemm_f32(_p(x), lda, _p(x2), n_split, _p(weight), ldw, _p(bias),
+                                   _p(residual), ldr, _p(out), ldc, M, N, K, act, tile, _stream()),
+             "ff_gemm_f32")
+    return out
+
+
+def attention(q, k, v, num_groups, num_heads, nq, nk, q_group_stride, q_inner, q_outer_stride,
+              k_group_stride, k_stride, kv_len=None, key_mask=None, causal=False, scale=0.125,
+              out=None):
+    """Raw descriptor-level attention (see ff_attn_desc).  q/k/v/out are 2-D row tensors (views
+    into wider buffers are fine: the leading dimension is taken from stride(0))."""
+    _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
+    if out is None:
+        out = torch.empty((q.size(0), num_heads * _L.FF_HEAD_DIM), device=q.device, dtype=torch.float32)
+    d = _L.AttnDesc()
+    d.q, d.k, d.v, d.o = _p(q), _p(k), _p(v), _p(out)
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.num_groups, d.num_heads, d.nq, d.nk = num_groups, num_heads, nq, nk
+    d.q_group_stride, d.q_inner, d.q_outer_stride = q_group_stride, q_inner, q_outer_stride
+    d.k_group_stride, d.k_stride = k_group_stride, k_stride
+    if kv_len is not None:
+        _dev(kv_len, "kv_len", torch.int32)
+    if key_mask is not None:
+        _dev(key_mask, "key_mask", torch.uint8)
+        d.mask_stride = key_mask.stride(0)
+    d.kv_len, d.key_mask = _p(kv_len), _p(key_mask)
+    d.causal = 1 if causal else 0
+    d.scale = scale
+    _L.check(_L.load().ff_attention(C.byref(d), _stream()), "ff_attention")
+    return out
+
+
+def pointer_argmax(p, memory, mask=None, kv_len=None, extra_mask=None, seqs_per_group=1,
+                   want_logits=False, want_rows=False, counters=None, ge_bound=0, eq_value=0):
+    """select_next: returns dict(next, best, second, [logits], [rows])."""
+    p, ldp = _rows(p, "p")
+    _dev(memory, "memory")
+    if memory.dim() != 3 or not memory.is_contiguous():
+        raise ValueError("memory must be a contiguous [N, S, E] tensor")
+    B, E = p.shape
+    S = memory.size(1)
+    dev = p.device
+    nxt = torch.empty(B, device=dev, dtype=torch.int32)
+    best = torch.empty(B, device=dev, dtype=torch.float32)
+    second = torch.empty(B, device=dev, dtype=torch.float32)
+    logits = torch.empty((B, S), device=dev, dtype=torch.float32) if want_logits else None
+    rows = torch.empty((B, E), device=dev, dtype=torch.float32) if want_rows else None
+    if mask is not None:
+        _dev(mask, "mask", torch.uint8)
+    if kv_len is not None:
+        _dev(kv_len, "kv_len", torch.int32)
+    ldextra = 0
+    if extra_mask is not None:
+        _dev(extra_mask, "extra_mask", torch.uint8)
+        ldextra = extra_mask.stride(0)
+    cge = ceq = None
+    if counters is not None:
+        _dev(counters, "counters", torch.int32)
+        cge, ceq = counters.data_ptr(), counters.data_ptr() + 4
+    _L.check(_L.load().ff_pointer_argmax(
+        _p(p), ldp, _p(memory), S, E, _p(mask), _p(kv_len), _p(extra_mask), ldextra, B,
+        seqs_per_group, _p(nxt), _p(best), _p(second), _p(logits), S, _p(rows), E,
+        cge, ge_bound, ceq, eq_value, _stream()), "ff_pointer_argmax")
+    out = {"next": nxt, "best": best, "second": second}
+    if want_logits:
+        out["logits"] = logits
+    if want_rows:
+        out["rows"] = rows
+    return out
+
+
+def gather_rows(memory, tok, seqs_per_group=1):
+    _dev(memory, "memory"), _dev(tok, "tok", torch.int32)
+    N, S, E = memory.shape
+    out = torch.empty((tok.numel(), E), device=memory.device, dtype=torch.float32)
+    _L.check(_L.load().ff_gather_rows(_p(memory.contiguous()), S, E, _p(tok), tok.numel(),
+                                      seqs_per_group, _p(out), E, _stream()), "ff_gather_rows")
+    return out

@@ -1,0 +1,45 @@
+"""SurfaceFormer: all faces of a wireframe as ONE token sequence (surface of reference
+`faceformer/models/model.py`; greedy eval path 169-219, pointer head 161-167).
+
+Constructor arguments, `state_dict` layout and the `forward(inputs: dict) -> dict` contract match the
+reference; `forward_eval` runs on the native engine (ff_encode + ff_decode, variant FF_SEQ2SEQ):
+start token SOS, at most label_seq_length-1 steps, stop when the cumulative EOS count equals the
+batch size (reference model.py:191,207-210), zero padding afterwards.
+"""
+from ..hip import lib as _L
+from .common import SurfaceFormerBase
+
+
+class SurfaceFormer(SurfaceFormerBase):
+
+    def __init__(self, num_model=512, num_head=8, num_feedforward=2048, num_encoder_layers=6,
+                 num_decoder_layers=6, dropout=0.1, activation="relu", normalize_before=True,
+                 num_points_per_line=50, num_lines=1000, point_dim=2, label_seq_length=2000,
+                 token=None, teacher_forcing_ratio=0, **kwargs):
+        super().__init__()
+        self.num_labels = label_seq_length
+        self._build(num_model, num_head, num_feedforward, num_encoder_layers, num_decoder_layers,
+                    dropout, activation, normalize_before, num_points_per_line, num_lines, point_dim,
+                    label_seq_length, token, teacher_forcing_ratio)
+
+    def get_embeddings(self, input, label):
+        val_embed = self.val_enc(input)
+        return val_embed, self.pos_enc(val_embed), self.query_pos_enc(label)
+
+    def forward_eval(self, inputs):
+        """inputs: input N x L x P x D, input_mask N x L (True = padding), label N x T (shape only).
+        Adds predict N x T (int64), embedding N x S x E, pointer N x t_last x E."""
+        label = inputs["label"]
+        T = self.num_labels
+        if label.size(1) < T - 1:
+            raise ValueError("label has %d positions but label_seq_length-1=%d query positions are "
+                             "needed" % (label.size(1), T - 1))
+        eng, memory, mask, kv_len = self._encode(inputs)
+        out = eng.decode(memory, mask, kv_len, _L.FF_SEQ2SEQ, T=T, F=1,
+                         chunk_wireframes=self.chunk_wireframes, sync_every=1,
+                         flags=self.decode_flags, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
+                         return_pointer=True)
+        inputs["embedding"] = memory
+        inputs["pointer"] = out["pointer"].transpose(0, 1)
+        inputs["predict"] = out["predict"]
+        return inputs

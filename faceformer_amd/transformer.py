@@ -1,0 +1,413 @@
+"""Transformer blocks of the decode path on hand-written HIP kernels (gfx950).
+
+Module surface, constructor signatures, parameter names / shapes and forward keyword arguments follow
+reference `faceformer/transformer.py` (encoder stack 62-83, decoder stack 86-124, encoder layer
+127-184, decoder layer 187-269, helpers 272-284) so `state_dict`s are interchangeable.  The
+arithmetic is NOT torch's: every forward below runs on libfaceformer_hip.so --
+
+    LayerNorm (+pos add)      -> ff_layernorm      (one wavefront per row)
+    q/k/v, out-proj, FFN      -> ff_gemm_f32       (v_mfma_f32_32x32x2_f32, fused bias/ReLU/residual)
+    softmax(qk^T)v            -> ff_attention      (LDS-staged K/V tiles, online softmax, f32 MFMA)
+
+Tensors are sequence-first (len x batch x E) like the reference; a contiguous sequence-first tensor
+IS the position-major row matrix the kernels want (row = position * batch + b), so no transposes
+happen.  Inference only: a module in training mode raises (training is out of scope of this build),
+and CPU tensors raise (there is no fallback path).
+"""
+import copy
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .hip import ops
+from .hip.lib import FF_HEAD_DIM, HipExtensionError
+
+__all__ = ["Transformer", "TransformerEncoder", "TransformerDecoder", "TransformerEncoderLayer",
+           "TransformerDecoderLayer", "MultiheadAttention"]
+
+
+def _eval_only(mod):
+    if mod.training:
+        raise NotImplementedError(
+            "%s: training-mode forward (dropout / teacher forcing) is out of scope of the MI355X "
+            "decode build; call .eval()" % type(mod).__name__)
+
+
+def _rows(x):
+    """[len, batch, E] -> contiguous [len*batch, E] row matrix (a view when already contiguous)."""
+    if x.dim() != 3:
+        raise ValueError("expected a sequence-first [len, batch, E] tensor, got %s" % (tuple(x.shape),))
+    return x.contiguous().view(x.size(0) * x.size(1), x.size(2))
+
+
+def _pos_table(pos, length, batch):
+    """Positional term as (table, pos_div, pos_mod) for the kernels' `(row // div) % mod` lookup.
+    Accepts [len,1,E] (broadcast over batch, what the path uses) or a full [len,batch,E]."""
+    if pos is None:
+        return None, 1, 1
+    if pos.dim() != 3 or pos.size(0) != length:
+        raise ValueError("positional term must be [len, 1|batch, E] with len=%d" % length)
+    if pos.size(1) == 1:
+        return pos.contiguous().view(length, pos.size(2)), batch, length
+    if pos.size(1) == batch:
+        return pos.contiguous().view(length * batch, pos.size(2)), 1, length * batch
+    raise ValueError("positional term batch dim must be 1 or %d" % batch)
+
+
+def _mask_u8(mask, name, shape):
+    if mask is None:
+        return None
+    if mask.dtype not in (torch.bool, torch.uint8):
+        raise NotImplementedError("%s: only boolean padding masks are supported" % name)
+    if tuple(mask.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, shape, tuple(mask.shape)))
+    return mask.to(torch.uint8).contiguous()
+
+
+def _is_causal(mask, n):
+    """True iff `mask` is the square 'subsequent' mask (reference model.py:71-73)."""
+    if mask is None:
+        return False
+    if mask.dtype != torch.bool or tuple(mask.shape) != (n, n):
+        raise NotImplementedError("tgt_mask: only the boolean causal mask is supported")
+    want = torch.triu(torch.ones(n, n, dtype=torch.bool, device=mask.device), diagonal=1)
+    if not torch.equal(mask, want):
+        raise NotImplementedError("tgt_mask: only the boolean causal mask is supported")
+    return True
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter container with torch's nn.MultiheadAttention names/shapes (`in_proj_weight` [3E,E],
+    `in_proj_bias`, `out_proj.{weight,bias}`) whose forward runs on the HIP kernels.
+    forward(query, key, value, key_padding_mask=None, attn_mask=None) -> (output, None)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.in_proj_bias, 0.0)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def _check(self):
+        _eval_only(self)
+        if self.head_dim != FF_HEAD_DIM:
+            raise HipExtensionError("HIP attention kernels support head_dim == 64 only (got %d)" % self.head_dim)
+
+    def project_self(self, yq, y):
+        """q|k from `yq`, v from `y` in one launch -> [rows, 3E]."""
+        E = self.embed_dim
+        return ops.linear(yq, self.in_proj_weight, self.in_proj_bias, x2=y, n_split=2 * E)
+
+    def project_q(self, yq):
+        E = self.embed_dim
+        return ops.linear(yq, self.in_proj_weight[:E], self.in_proj_bias[:E])
+
+    def project_kv(self, kin, vin):
+        """k from `kin`, v from `vin` -> [rows, 2E]."""
+        E = self.embed_dim
+        return ops.linear(kin, self.in_proj_weight[E:], self.in_proj_bias[E:], x2=vin, n_split=E)
+
+    def attend(self, q, k, v, lq, lk, batch, key_padding_mask=None, causal=False):
+        """q: [lq*batch, >=E] rows (position-major), k/v: [lk*batch, ...]; returns [lq*batch, E]."""
+        kv_len = None
+        if key_padding_mask is not None:
+            idx = torch.arange(1, lk + 1, device=q.device, dtype=torch.int32)
+            kv_len = ((key_padding_mask == 0).to(torch.int32) * idx).amax(dim=1).to(torch.int32)
+        return ops.attention(q, k, v, num_groups=batch, num_heads=self.num_heads, nq=lq, nk=lk,
+                             q_group_stride=1, q_inner=1, q_outer_stride=batch,
+                             k_group_stride=1, k_stride=batch, kv_len=kv_len,
+                             key_mask=key_padding_mask, causal=causal,
+                             scale=float(self.head_dim) ** -0.5)
+
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=False, attn_mask=None):
+        self._check()
+        lq, batch, E = query.shape
+        lk = key.size(0)
+        q = self.project_q(_rows(query))
+        kv = self.project_kv(_rows(key), _rows(value))
+        kpm = _mask_u8(key_padding_mask, "key_padding_mask", (batch, lk))
+        causal = _is_causal(attn_mask, lq) if attn_mask is not None else False
+        o = self.attend(q, kv[:, :E], kv[:, E:], lq, lk, batch, kpm, causal)
+        out = ops.linear(o, self.out_proj.weight, self.out_proj.bias)
+        return out.view(lq, batch, E), None
+
+
+def _activation_code(name):
+    if name == "relu":
+        return 1
+    if name in ("gelu", "glu"):
+        raise NotImplementedError("activation %r: the fused GEMM epilogue implements relu (the "
+                                  "reference configs use relu, config.py / model.py:16)" % name)
+    raise RuntimeError("activation should be relu/gelu, not %s." % name)
+
+
+def _get_activation_fn(activation):
+    """Kept for API parity (reference transformer.py:276-284); returns the torch functional."""
+    import torch.nn.functional as F
+    if activation == "relu":
+        return F.relu
+    if activation == "gelu":
+        return F.gelu
+    if activation == "glu":
+        return F.glu
+    raise RuntimeError("activation should be relu/gelu, not %s." % activation)
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Reference transformer.py:127-184."""
+
+    def __init__(self, num_model, num_head, num_feedforward=2048, dropout=0.1, activation="relu",
+                 normalize_before=False):
+        super().__init__()
+        self.self_attn = MultiheadAttention(num_model, num_head, dropout=dropout)
+        self.linear1 = nn.Linear(num_model, num_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(num_feedforward, num_model)
+        self.norm1 = nn.LayerNorm(num_model)
+        self.norm2 = nn.LayerNorm(num_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.activation_name = activation
+        self.activation = _get_activation_fn(activation)
+        self.normalize_before = normalize_before
+
+    def with_pos_embed(self, tensor, pos: Optional[Tensor]):
+        if pos is None:
+            return tensor
+        table, div, mod = _pos_table(pos, tensor.size(0), tensor.size(1))
+        return ops.add_pos(_rows(tensor), table, div, mod).view_as(tensor)
+
+    def _ffn(self, y, residual):
+        h = ops.linear(y, self.linear1.weight, self.linear1.bias, act=_activation_code(self.activation_name))
+        return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=residual)
+
+    def _prep(self, src, src_mask, src_key_padding_mask, pos):
+        self.self_attn._check()
+        if src_mask is not None:
+            raise NotImplementedError("src_mask is not used on the decode path and not supported")
+        S, N, E = src.shape
+        kpm = _mask_u8(src_key_padding_mask, "src_key_padding_mask", (N, S))
+        return S, N, E, kpm, _pos_table(pos, S, N)
+
+    def forward_pre(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
+        S, N, E, kpm, (table, div, mod) = self._prep(src, src_mask, src_key_padding_mask, pos)
+        x = _rows(src)
+        y, yq = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, table, div, mod)
+        qkv = self.self_attn.project_self(yq if yq is not None else y, y)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], S, S, N, kpm)
+        x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
+        y, _ = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self._ffn(y, x).view(S, N, E)
+
+    def forward_post(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
+        S, N, E, kpm, (table, div, mod) = self._prep(src, src_mask, src_key_padding_mask, pos)
+        x = _rows(src)
+        xq = ops.add_pos(x, table, div, mod) if table is not None else x
+        qkv = self.self_attn.project_self(xq, x)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], S, S, N, kpm)
+        x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
+        x, _ = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self._ffn(x, x)
+        x, _ = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return x.view(S, N, E)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
+        _eval_only(self)
+        if self.normalize_before:
+            return self.forward_pre(src, src_mask, src_key_padding_mask, pos)
+        return self.forward_post(src, src_mask, src_key_padding_mask, pos)
+
+
+class TransformerDecoderLayer(nn.Module):
+    """Reference transformer.py:187-269."""
+
+    def __init__(self, num_model, num_head, num_feedforward=2048, dropout=0.1, activation="relu",
+                 normalize_before=False):
+        super().__init__()
+        self.self_attn = MultiheadAttention(num_model, num_head, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(num_model, num_head, dropout=dropout)
+        self.linear1 = nn.Linear(num_model, num_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(num_feedforward, num_model)
+        self.norm1 = nn.LayerNorm(num_model)
+        self.norm2 = nn.LayerNorm(num_model)
+        self.norm3 = nn.LayerNorm(num_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.activation_name = activation
+        self.activation = _get_activation_fn(activation)
+        self.normalize_before = normalize_before
+
+    with_pos_embed = TransformerEncoderLayer.with_pos_embed
+    _ffn = TransformerEncoderLayer._ffn
+
+    def _prep(self, tgt, memory, tgt_mask, memory_mask, tgt_kpm, mem_kpm, pos, query_pos):
+        self.self_attn._check()
+        if memory_mask is not None:
+            raise NotImplementedError("memory_mask is not used on the decode path and not supported")
+        t, B, E = tgt.shape
+        S = memory.size(0)
+        if memory.size(1) != B:
+            raise ValueError("memory batch %d != tgt batch %d" % (memory.size(1), B))
+        return (t, B, E, S, _is_causal(tgt_mask, t) if tgt_mask is not None else False,
+                _mask_u8(tgt_kpm, "tgt_key_padding_mask", (B, t)),
+                _mask_u8(mem_kpm, "memory_key_padding_mask", (B, S)),
+                _pos_table(pos, S, B), _pos_table(query_pos, t, B))
+
+    def _cross_kv(self, memory, ptab):
+        mem = _rows(memory)
+        table, div, mod = ptab
+        kin = ops.add_pos(mem, table, div, mod) if table is not None else mem
+        return self.multihead_attn.project_kv(kin, mem)
+
+    def forward_pre(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                    memory_key_padding_mask=None, pos=None, query_pos=None):
+        t, B, E, S, causal, tkpm, mkpm, ptab, (qtab, qdiv, qmod) = self._prep(
+            tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos, query_pos)
+        x = _rows(tgt)
+        y, yq = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, qtab, qdiv, qmod)
+        qkv = self.self_attn.project_self(yq if yq is not None else y, y)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], t, t, B, tkpm, causal)
+        x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
+        y, yq = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, qtab, qdiv, qmod)
+        q = self.multihead_attn.project_q(yq if yq is not None else y)
+        kv = self._cross_kv(memory, ptab)
+        o = self.multihead_attn.attend(q, kv[:, :E], kv[:, E:], t, S, B, mkpm)
+        x = ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, residual=x)
+        y, _ = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self._ffn(y, x).view(t, B, E)
+
+    def forward_post(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                     memory_key_padding_mask=None, pos=None, query_pos=None):
+        t, B, E, S, causal, tkpm, mkpm, ptab, (qtab, qdiv, qmod) = self._prep(
+            tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos, query_pos)
+        x = _rows(tgt)
+        xq = ops.add_pos(x, qtab, qdiv, qmod) if qtab is not None else x
+        qkv = self.self_attn.project_self(xq, x)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], t, t, B, tkpm, causal)
+        x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
+        x, xq = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, qtab, qdiv, qmod)
+        q = self.multihead_attn.project_q(xq if xq is not None else x)
+        kv = self._cross_kv(memory, ptab)
+        o = self.multihead_attn.attend(q, kv[:, :E], kv[:, E:], t, S, B, mkpm)
+        x = ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, residual=x)
+        x, _ = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = self._ffn(x, x)
+        x, _ = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return x.view(t, B, E)
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None):
+        _eval_only(self)
+        fn = self.forward_pre if self.normalize_before else self.forward_post
+        return fn(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask,
+                  pos, query_pos)
+
+
+def _final_norm(norm, x):
+    L, B, E = x.shape
+    y, _ = ops.layernorm(_rows(x), norm.weight, norm.bias, norm.eps)
+    return y.view(L, B, E)
+
+
+class TransformerEncoder(nn.Module):
+    """Reference transformer.py:62-83."""
+
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, src, mask=None, src_key_padding_mask=None, pos=None):
+        _eval_only(self)
+        output = src
+        for layer in self.layers:
+            output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
+        if self.norm is not None:
+            output = _final_norm(self.norm, output)
+        return output
+
+
+class TransformerDecoder(nn.Module):
+    """Reference transformer.py:86-124."""
+
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None):
+        _eval_only(self)
+        output = tgt
+        intermediate = []
+        for layer in self.layers:
+            output = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                           tgt_key_padding_mask=tgt_key_padding_mask,
+                           memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos)
+            if self.return_intermediate:
+                intermediate.append(_final_norm(self.norm, output))
+        if self.norm is not None:
+            output = _final_norm(self.norm, output)
+            if self.return_intermediate:
+                intermediate[-1] = output
+        if self.return_intermediate:
+            return torch.stack(intermediate)
+        return output
+
+
+class Transformer(nn.Module):
+    """DETR-style wrapper (reference transformer.py:18-59).  The decode path never instantiates it;
+    it is kept so that `faceformer.transformer.Transformer` stays importable and usable."""
+
+    def __init__(self, num_model=512, num_head=8, num_encoder_layers=6, num_decoder_layers=6,
+                 num_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
+                 return_intermediate_dec=False):
+        super().__init__()
+        enc_layer = TransformerEncoderLayer(num_model, num_head, num_feedforward, dropout, activation,
+                                            normalize_before)
+        self.encoder = TransformerEncoder(enc_layer, num_encoder_layers,
+                                          nn.LayerNorm(num_model) if normalize_before else None)
+        dec_layer = TransformerDecoderLayer(num_model, num_head, num_feedforward, dropout, activation,
+                                            normalize_before)
+        self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, nn.LayerNorm(num_model),
+                                          return_intermediate=return_intermediate_dec)
+        self._reset_parameters()
+        self.num_model = num_model
+        self.num_head = num_head
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, mask, query_embed, pos_embed):
+        bs, c, h, w = src.shape
+        src = src.flatten(2).permute(2, 0, 1)
+        pos_embed = pos_embed.flatten(2).permute(2, 0, 1)
+        query_embed = query_embed.unsqueeze(1).repeat(1, bs, 1)
+        mask = mask.flatten(1)
+        tgt = torch.zeros_like(query_embed)
+        memory = self.encoder(src, src_key_padding_mask=mask, pos=pos_embed)
+        hs = self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_embed, query_pos=query_embed)
+        if hs.dim() == 3:
+            hs = hs.unsqueeze(0)
+        return hs.transpose(1, 2), memory.permute(1, 2, 0).view(bs, c, h, w)

@@ -1,0 +1,74 @@
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU oracle case")
+
+
+def has_gpu():
+    return torch.cuda.is_available()
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The built C-ABI library (built on demand: hipcc cross-compiles without a GPU)."""
+    from faceformer_amd.hip import build, lib
+    if not os.path.exists(lib.LIB_PATH):
+        build.build()
+    return lib.load()
+
+
+def token_ns():
+    return types.SimpleNamespace(PAD=0, SOS=1, SEP=2, EOS=3, DIR0=4, DIR1=5, len=4, face_type_offset=1)
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    case = json.loads(bytes(z["case"]).decode())
+    return case, z
+
+
+def golden_names(include_slow=True):
+    from oracle.golden_cases import CASES
+    return [c["name"] for c in CASES if include_slow or not c.get("slow")]
+
+
+def case_weights_and_batch(case):
+    """Regenerate (state_dict, batch) of a golden case from its seeds."""
+    from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec
+    m = case["model"]
+    spec = state_dict_spec(case["kind"], m["L"], m["seq_len"], m["E"], m["FF"], m["enc"], m["dec"])
+    sd = make_state_dict(spec, case["recipe"], case["wseed"])
+    batch = make_wireframes(case["n_edges"], m["L"], m["seq_len"], case["kind"], seeds=case["seeds"])
+    return sd, batch
+
+
+def build_model(case, sd, device):
+    from faceformer_amd.models import SurfaceFormer, SurfaceFormer_Parallel
+    m = case["model"]
+    common = dict(num_model=m["E"], num_head=m["H"], num_feedforward=m["FF"],
+                  num_encoder_layers=m["enc"], num_decoder_layers=m["dec"], dropout=0.2,
+                  num_lines=m["L"], token=token_ns())
+    if case["kind"] == "parallel":
+        model = SurfaceFormer_Parallel(max_face_length=m["seq_len"], **common)
+    else:
+        model = SurfaceFormer(label_seq_length=m["seq_len"], **common)
+    model.load_state_dict(sd)
+    return model.eval().to(device)
+
+
+def batch_to(batch, device):
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}

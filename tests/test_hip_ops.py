@@ -1,0 +1,237 @@
+"""GPU: every C-ABI kernel against a plain PyTorch reference of the same op (computed in fp64 on the
+CPU and compared at fp32 round-off class tolerances)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from faceformer_amd.hip import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def rel_err(got, want):
+    want = want.double()
+    return float((got.double().cpu() - want).abs().max() / (want.abs().max() + 1e-30))
+
+
+# ---- LayerNorm -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,E", [(1, 512), (37, 512), (1000, 512), (130, 128), (5, 64), (9, 1024), (3, 2048)])
+def test_layernorm_pos(ops, rows, E):
+    x = rnd(rows, E, seed=1, scale=3.0) + 0.5
+    g, b = rnd(E, seed=2) + 1.0, rnd(E, seed=3)
+    div, mod = 4, 7
+    pos = rnd(mod, E, seed=4)
+    y, yp = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-5, pos.cuda(), div, mod)
+    ref = F.layer_norm(x.double(), (E,), g.double(), b.double(), 1e-5)
+    idx = (torch.arange(rows) // div) % mod
+    assert rel_err(y, ref) < 2e-6
+    assert rel_err(yp, ref + pos.double()[idx]) < 2e-6
+    y2, none = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-5)
+    assert none is None and torch.equal(y2, y)
+
+
+def test_add_pos_and_gather(ops):
+    x, pos = rnd(50, 512, seed=1), rnd(10, 512, seed=2)
+    out = ops.add_pos(x.cuda(), pos.cuda(), 5, 10)
+    idx = (torch.arange(50) // 5) % 10
+    assert torch.equal(out.cpu(), x + pos[idx])
+    mem = rnd(3, 20, 512, seed=3)
+    tok = torch.tensor([0, 19, 5, 7, 7, 1], dtype=torch.int32)
+    rows = ops.gather_rows(mem.cuda(), tok.cuda(), seqs_per_group=2)
+    want = torch.stack([mem[i // 2, int(t)] for i, t in enumerate(tok)])
+    assert torch.equal(rows.cpu(), want)
+
+
+# ---- GEMM -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
+                                   (520, 512, 100), (4100, 1024, 512), (64, 260, 512), (130, 96, 36)])
+def test_gemm_bias_act_residual(ops, M, N, K, tile):
+    a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    # asymmetric operands: a transposed C-write or swapped operand cannot pass
+    ref0 = a.double() @ w.double().t() + bias.double()
+    out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), tile=tile)
+    assert rel_err(out, ref0) < 3e-6
+    out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=res.cuda(), tile=tile)
+    assert rel_err(out, torch.relu(ref0) + res.double()) < 3e-6
+    out = ops.linear(a.cuda(), w.cuda(), None, tile=tile)
+    assert rel_err(out, a.double() @ w.double().t()) < 3e-6
+
+
+def test_gemm_identity_layout(ops):
+    """A = I against an asymmetric W: catches any row/col swap exactly (values are copied, not summed)."""
+    K = 64
+    eye = torch.eye(K)
+    w = rnd(96, K, seed=9)
+    for tile in (1, 2, 3):
+        out = ops.linear(eye.cuda(), w.cuda(), None, tile=tile)
+        assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_gemm_split_a_and_inplace_residual(ops, tile):
+    M, E = 300, 512
+    yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
+    out = ops.linear(yq.cuda(), w.cuda(), b.cuda(), x2=y.cuda(), n_split=2 * E, tile=tile)
+    ref = torch.cat([yq.double() @ w[: 2 * E].double().t(), y.double() @ w[2 * E:].double().t()], 1) + b.double()
+    assert rel_err(out, ref) < 3e-6
+    # residual aliasing the output (x += o W^T + b), strided views as operands
+    x = rnd(M, E, seed=5).cuda()
+    x0 = x.clone()
+    wo = rnd(E, E, seed=6, scale=0.05)
+    ops.linear(out[:, :E], wo.cuda(), None, residual=x, out=x, tile=tile)
+    ref2 = x0.double().cpu() + ref[:, :E] @ wo.double().t()
+    assert rel_err(x, ref2) < 3e-6
+
+
+# ---- attention --------------------------------------------------------------------------------------
+def ref_attention(q, k, v, mask=None, causal=False):
+    """q [G,H,nq,64] k,v [G,H,nk,64] fp64; mask [G,nk] bool"""
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    if causal:
+        nq, nk = s.shape[-2:]
+        s = s.masked_fill(torch.triu(torch.ones(nq, nk, dtype=torch.bool), 1), float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("G,H,nq,nk", [(2, 2, 33, 33), (1, 8, 260, 260), (3, 2, 5, 100), (4, 1, 1, 1),
+                                       (2, 8, 140, 70), (1, 2, 64, 64), (1, 1, 65, 129)])
+def test_attention_group_major_with_mask(ops, G, H, nq, nk):
+    """Encoder-style layout: rows = g*len + i; padding mask + kv_len."""
+    E = H * 64
+    q, k, v = rnd(G * nq, E, seed=1), rnd(G * nk, E, seed=2), rnd(G * nk, E, seed=3)
+    mask = torch.zeros(G, nk, dtype=torch.bool)
+    kv_len = torch.full((G,), nk, dtype=torch.int32)
+    for g in range(G):
+        cut = max(1, nk - 3 * g - (nk // 4))
+        mask[g, cut:] = True
+        kv_len[g] = cut
+        if cut > 2:
+            mask[g, 1] = True  # a hole inside the valid range
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), G, H, nq, nk, q_group_stride=nq, q_inner=nq,
+                        q_outer_stride=0, k_group_stride=nk, k_stride=1, kv_len=kv_len.cuda(),
+                        key_mask=mask.to(torch.uint8).cuda())
+    qd = q.double().view(G, nq, H, 64).transpose(1, 2)
+    kd = k.double().view(G, nk, H, 64).transpose(1, 2)
+    vd = v.double().view(G, nk, H, 64).transpose(1, 2)
+    ref = ref_attention(qd, kd, vd, mask).transpose(1, 2).reshape(G * nq, E)
+    assert rel_err(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize("t,B,H,causal", [(1, 5, 2, False), (7, 40, 8, False), (36, 24, 8, False),
+                                          (70, 3, 2, False), (9, 4, 2, True), (258, 2, 8, False)])
+def test_attention_position_major_self(ops, t, B, H, causal):
+    """Decoder self-attention layout: rows = j*B + b, packed q|k|v buffer (ld = 3E)."""
+    E = H * 64
+    qkv = rnd(t * B, 3 * E, seed=5)
+    dq = qkv.cuda()
+    out = ops.attention(dq[:, :E], dq[:, E:2 * E], dq[:, 2 * E:], B, H, t, t, q_group_stride=1, q_inner=1,
+                        q_outer_stride=B, k_group_stride=1, k_stride=B, causal=causal)
+    x = qkv.double().view(t, B, 3, H, 64).permute(2, 1, 3, 0, 4)  # [3,B,H,t,64]
+    ref = ref_attention(x[0], x[1], x[2], None, causal)           # [B,H,t,64]
+    ref = ref.permute(2, 0, 1, 3).reshape(t * B, E)
+    assert rel_err(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize("t,F,W,S", [(1, 3, 2, 30), (5, 7, 3, 50), (12, 40, 1, 44), (36, 33, 2, 260)])
+def test_attention_cross_shared_kv(ops, t, F, W, S):
+    """Decoder cross-attention: F sequences of a wireframe share its K/V; queries position-major."""
+    H, E = 8, 512
+    B = W * F
+    q = rnd(t * B, E, seed=1)
+    kv = rnd(W * S, 2 * E, seed=2)
+    mask = torch.zeros(W, S, dtype=torch.bool)
+    kv_len = torch.full((W,), S, dtype=torch.int32)
+    for w in range(W):
+        cut = S - 5 * w - 3
+        mask[w, cut:] = True
+        kv_len[w] = cut
+    dkv = kv.cuda()
+    out = ops.attention(q.cuda(), dkv[:, :E], dkv[:, E:], W, H, F * t, S, q_group_stride=F, q_inner=F,
+                        q_outer_stride=B, k_group_stride=S, k_stride=1, kv_len=kv_len.cuda(),
+                        key_mask=mask.to(torch.uint8).cuda())
+    qd = q.double().view(t, W, F, H, 64).permute(1, 3, 0, 2, 4).reshape(W, H, t * F, 64)
+    kd = kv[:, :E].double().view(W, S, H, 64).transpose(1, 2)
+    vd = kv[:, E:].double().view(W, S, H, 64).transpose(1, 2)
+    ref = ref_attention(qd, kd, vd, mask)                          # [W,H,t*F,64]
+    ref = ref.view(W, H, t, F, 64).permute(2, 0, 3, 1, 4).reshape(t * B, E)
+    assert rel_err(out, ref) < 5e-6
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """Spike one late key so the running max jumps in a later key tile (forces the rescale path)."""
+    H, E, nq, nk = 1, 64, 40, 200
+    q, k, v = rnd(nq, E, seed=1), rnd(nk, E, seed=2), rnd(nk, E, seed=3)
+    k[150] = q[7] * 40.0   # huge score for query 7 at key 150 (third chunk)
+    k[3] = q[20] * 25.0    # and an early spike for another query
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), 1, H, nq, nk, q_group_stride=nq, q_inner=nq,
+                        q_outer_stride=0, k_group_stride=nk, k_stride=1)
+    ref = ref_attention(q.double()[None, None], k.double()[None, None], v.double()[None, None])[0, 0]
+    assert rel_err(out, ref) < 5e-6
+
+
+# ---- pointer head -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,F,S,E", [(1, 256, 260, 512), (3, 7, 44, 512), (2, 5, 70, 128), (1, 1, 5, 64)])
+def test_pointer_argmax(ops, W, F, S, E):
+    B = W * F
+    p, mem = rnd(B, E, seed=1), rnd(W, S, E, seed=2)
+    mask = torch.zeros(W, S, dtype=torch.bool)
+    kv_len = torch.full((W,), S, dtype=torch.int32)
+    for w in range(W):
+        cut = S - 2 * w - 1
+        mask[w, cut:] = True
+        kv_len[w] = cut
+    counters = torch.zeros(2, dtype=torch.int32).cuda()
+    res = ops.pointer_argmax(p.cuda(), mem.cuda(), mask.to(torch.uint8).cuda(), kv_len.cuda(),
+                             seqs_per_group=F, want_logits=True, want_rows=True, counters=counters,
+                             ge_bound=4, eq_value=3)
+    fill = torch.finfo(torch.float32).min
+    logit = torch.einsum("be,bse->bs", p.double(), mem.double()[torch.arange(B) // F])
+    logit = logit.masked_fill(mask[torch.arange(B) // F], fill)
+    got = res["logits"].cpu().double()
+    live = logit > fill
+    assert torch.equal(got[~live], logit[~live])
+    assert float((got[live] - logit[live]).abs().max()) < 1e-4 * float(logit[live].abs().max())
+    # argmax must be exactly torch's on the kernel's own logits (first index on ties)
+    assert torch.equal(res["next"].cpu().long(), torch.argmax(res["logits"].cpu(), dim=1))
+    top2 = torch.sort(res["logits"].cpu(), dim=1, descending=True).values
+    assert torch.equal(res["best"].cpu(), top2[:, 0])
+    if S > 1:
+        assert torch.equal(res["second"].cpu(), top2[:, 1])
+    nxt = res["next"].cpu().long()
+    assert torch.equal(res["rows"].cpu(), mem[torch.arange(B) // F, nxt])
+    assert counters.cpu().tolist() == [int((nxt >= 4).sum()), int((nxt == 3).sum())]
+
+
+def test_pointer_ties_and_all_masked(ops):
+    E, S = 64, 9
+    mem = torch.zeros(1, S, E)
+    mem[0, 2] = 1.0
+    mem[0, 5] = 1.0          # exact tie between keys 2 and 5 -> lowest index wins
+    p = torch.ones(2, E)
+    res = ops.pointer_argmax(p.cuda(), mem.cuda(), seqs_per_group=2)
+    assert res["next"].cpu().tolist() == [2, 2]
+    allmask = torch.ones(1, S, dtype=torch.uint8)
+    res = ops.pointer_argmax(p.cuda(), mem.cuda(), allmask.cuda(), seqs_per_group=2, want_logits=True)
+    assert res["next"].cpu().tolist() == [0, 0]   # torch.argmax of a constant row is 0
+    assert float(res["best"][0]) == torch.finfo(torch.float32).min
+    extra = torch.zeros(2, S, dtype=torch.uint8)
+    extra[1, 2] = 1          # per-sequence extra mask removes key 2 for sequence 1 only
+    res = ops.pointer_argmax(p.cuda(), mem.cuda(), extra_mask=extra.cuda(), seqs_per_group=2)
+    assert res["next"].cpu().tolist() == [2, 5]
