@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Throughput of the greedy pointer-decode path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Metric (BASELINE.json): decoded edges/s = pointer selections per second on 256-edge wireframes.
+One "step" = one pass of the hot path over one batch per GPU: encoder + all greedy decode steps +
+output packing (+ the RCCL all-gather of the predicted loops when N > 1).  Default workload =
+BASELINE config B: configs/ours.yml with model.num_lines=256, ONE synthetic 256-edge wireframe per
+GPU (F=256 anchor sequences x 36 steps = 9216 selections), default-xavier synthetic weights (never
+stops early), fp32.  `--wireframes-per-gpu 128` gives config C's per-GPU batch.
+
+The JSON line also carries
+  roofline     : the dominant kernel (the f32-MFMA GEMM): algorithmic flops (2MNK summed over its
+                 launches of one step) / its summed duration, measured with HIP events on the launch
+                 stream by the library's profiling hooks, against the 157.3 TF/s f32 matrix peak;
+  cpu_baseline : the CPU oracle (op-for-op restatement of the reference, oracle/refpath.py) timed on
+                 the host cores on a bounded sample of the SAME wireframe (first `anchors` anchor
+                 sequences, all 36 steps; sequences are independent so the sample is faithful).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100):
+    """algorithmic flops of one wireframe of the parallel model (F = n sequences)."""
+    S, steps, F = n + 4, T - 1, n
+    st = steps * (steps + 1) // 2
+    st2 = steps * (steps + 1) * (2 * steps + 1) // 6
+    embed = n * 2 * (in_dim * E + E * E)
+    enc = layers * (S * 2 * (4 * E * E + 2 * E * FF) + 4 * S * S * E)
+    cross_kv = layers * S * 2 * (2 * E * E)
+    dec_lin = layers * F * st * 2 * (6 * E * E + 2 * E * FF)
+    dec_self = layers * F * 4 * E * st2
+    dec_cross = layers * F * 4 * S * E * st
+    ptr = F * steps * (2 * E * E + 2 * S * E)
+    return embed + enc + cross_kv + dec_lin + dec_self + dec_cross + ptr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--wireframes-per-gpu", type=int, default=1)
+    ap.add_argument("--edges", type=int, default=256)
+    ap.add_argument("--chunk", type=int, default=0, help="wireframes per micro-batch (0 = all)")
+    ap.add_argument("--cpu-anchors", type=int, default=48, help="anchor sequences in the CPU sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the decode path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from faceformer_amd.config import load_cfg
+    from faceformer_amd.dist import gather_predictions
+    from faceformer_amd.hip import lib as L
+    from faceformer_amd.models import SurfaceFormer_Parallel
+    from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec
+
+    n, W = args.edges, args.wireframes_per_gpu
+    cfg = load_cfg(os.path.join(ROOT, "configs", "ours.yml"), ["model.num_lines", str(n)])
+    T = cfg.model.max_face_length
+    model = SurfaceFormer_Parallel(**cfg.model)
+    spec = state_dict_spec("parallel", n, T, cfg.model.num_model, cfg.model.num_feedforward,
+                           cfg.model.num_encoder_layers, cfg.model.num_decoder_layers)
+    sd = make_state_dict(spec, "default", 0)
+    model.load_state_dict(sd)
+    model = model.eval().to(dev)
+    model.chunk_wireframes = args.chunk
+    seeds = [rank * W + i for i in range(W)]
+    batch_cpu = make_wireframes(n, n, T, "parallel", seeds=seeds)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
+
+    def step():
+        with torch.no_grad():
+            out = model(dict(batch))
+        pred = out["predict"]
+        if world > 1:
+            pred = gather_predictions(pred, dist)
+        return pred
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pred = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # decode steps actually executed (the reference semantics run T-1 with these weights)
+    local = pred[rank * W:(rank + 1) * W] if world > 1 else pred
+    nz = (local[:, :, 1:] != 0).any(dim=1).any(dim=0)
+    steps_done = int(nz.nonzero().max().item()) + 1 if bool(nz.any()) else 0
+    sel_per_step = world * W * n * steps_done
+    value = sel_per_step * args.steps / dt
+
+    result = {
+        "metric": "decoded edges/sec (greedy face-loop decode, pointer selections/s), 256-edge wireframes",
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs/ours.yml model.num_lines=%d: %d synthetic %d-edge wireframe(s) per GPU, "
+                               "F=%d anchor sequences x %d greedy steps, default-xavier synthetic weights"
+                               % (n, W, n, n, steps_done),
+                   "wireframes_per_gpu": W, "edges": n, "max_face_length": T, "decode_steps": steps_done,
+                   "parallelism": "wireframe-sharded x%d, RCCL all-gather of predictions" % world},
+        "wireframes_per_s": world * W * args.steps / dt,
+    }
+    falg = alg_flops_per_wireframe(n, T)
+    result["path_roofline"] = {"alg_tflop_per_wireframe": falg / 1e12,
+                               "achieved_tflops_per_gpu": falg * W * args.steps / dt / 1e12,
+                               "frac_of_f32_mfma_peak": falg * W * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS}
+
+    if rank == 0 and not args.no_roofline:
+        lib = L.load()
+        ncat = 5
+        ms, work, cnt = (ctypes.c_double * ncat)(), (ctypes.c_double * ncat)(), (ctypes.c_longlong * ncat)()
+        torch.cuda.synchronize()
+        lib.ff_profile_begin()
+        with torch.no_grad():
+            model(dict(batch))
+        L.check(lib.ff_profile_end(ms, work, cnt, ncat), "ff_profile_end")
+        names = ["gemm_f32_kernel", "attention_kernel", "layernorm_kernel", "pointer_kernel", "row_ops"]
+        total_ms = sum(ms)
+        ach = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        result["roofline"] = {
+            "kernel": names[0], "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": int(cnt[0]), "avg_launch_us": 1e3 * ms[0] / max(1, cnt[0]),
+            "alg_flop_per_launch": work[0] / max(1, cnt[0]),
+            "share_of_kernel_time": ms[0] / total_ms if total_ms > 0 else None,
+        }
+        result["kernel_time_ms_per_step"] = {names[i]: ms[i] for i in range(ncat)}
+        result["kernel_launches_per_step"] = {names[i]: int(cnt[i]) for i in range(ncat)}
+        if ms[1] > 0:
+            result["attention_tflops"] = work[1] / (ms[1] * 1e-3) / 1e12
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import refpath
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        one = make_wireframes(n, n, T, "parallel", seeds=seeds[:1])
+        k = max(1, min(args.cpu_anchors, n))
+        t0 = time.perf_counter()
+        ref = refpath.parallel_forward_eval(sd, one, num_head=cfg.model.num_head, anchor_limit=k)
+        tc = time.perf_counter() - t0
+        ref_steps = int((ref["predict"][0, :, 1:] != 0).any(dim=0).nonzero().max().item()) + 1
+        same = bool(torch.equal(ref["predict"][0, :k].to(dev), local[0, :k]))
+        result["cpu_baseline"] = {
+            "value": k * ref_steps / tc, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "first %d of %d anchor sequences of the same %d-edge wireframe, all %d steps, "
+                      "oracle/refpath.py (torch %s CPU eager fp32, %d threads): %.1f s"
+                      % (k, n, n, ref_steps, torch.__version__, torch.get_num_threads(), tc),
+            "tokens_identical_to_gpu": same,
+        }
+        result["speedup_vs_cpu"] = value / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

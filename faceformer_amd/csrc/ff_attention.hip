@@ -188,6 +188,7 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   const int q_tiles = ff_cdiv(d.nq, 32 * nw);
   const long blocks = gh * q_tiles;
   FF_CHECK_ARG(blocks < 2147483647L, "ff_attention: grid too large");
+  FFProfScope prof(FF_CAT_ATTN, 4.0 * FF_HEAD_DIM * (double)gh * d.nq * d.nk, st);
   if (nw == 4)
     hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, d, q_tiles);
   else if (nw == 2)

@@ -44,6 +44,24 @@ static inline bool ff_aligned16(const void* p) { return (reinterpret_cast<uintpt
 static inline int ff_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t ff_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- optional per-category event profiling (bench.py's roofline leg) ---------------------------
+// When enabled via ff_profile_begin(), every op launch is bracketed by a hipEvent pair on its own
+// stream; ff_profile_end() synchronises and sums elapsed time / algorithmic work per category.
+enum ff_prof_cat { FF_CAT_GEMM = 0, FF_CAT_ATTN = 1, FF_CAT_LN = 2, FF_CAT_POINTER = 3, FF_CAT_ROWOP = 4, FF_NUM_CAT = 5 };
+bool ff_prof_enabled();
+void ff_prof_open(int cat, double work, hipStream_t st);
+void ff_prof_close(hipStream_t st);
+struct FFProfScope {
+  hipStream_t st;
+  bool on;
+  FFProfScope(int cat, double work, hipStream_t s) : st(s), on(ff_prof_enabled()) {
+    if (on) ff_prof_open(cat, work, st);
+  }
+  ~FFProfScope() {
+    if (on) ff_prof_close(st);
+  }
+};
+
 // ---- device helpers --------------------------------------------------------------------------
 __device__ __forceinline__ float ff_wave_sum(float v) {
 #pragma unroll

@@ -55,10 +55,11 @@ __global__ void init_tokens_kernel(int* tok, int B, int F, const int* num_input,
 // steps_done from the per-step counters, then predict[b, j] (int64) = token or 0 after the stop.
 __global__ void finalize_kernel(const int* __restrict__ tok_all, const int* __restrict__ cnt_ge,
                                 const int* __restrict__ cnt_eq, int variant, int N, int Btot,
-                                int Bchunk, int T, int steps_enqueued, int64_t* __restrict__ predict,
-                                int* __restrict__ steps_done_out) {
+                                int Bchunk, int T, int steps_enqueued, int no_stop,
+                                int64_t* __restrict__ predict, int* __restrict__ steps_done_out) {
   int steps = steps_enqueued;
-  if (variant == FF_PARALLEL) {
+  if (no_stop) {
+  } else if (variant == FF_PARALLEL) {
     for (int s = 0; s < steps_enqueued; ++s)
       if (cnt_ge[s] == 0) { steps = s + 1; break; }
   } else {
@@ -322,7 +323,7 @@ extern "C" size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_p
 extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const float* memory,
                          const unsigned char* mask, const int* kv_len, const int* num_input,
                          const unsigned char* extra_mask, int64_t* predict, int* steps_done,
-                         float* pointer_out, float* trace_logits, float* trace_best,
+                         int* step_counts, float* pointer_out, float* trace_logits, float* trace_best,
                          float* trace_second, void* workspace, size_t workspace_bytes,
                          ff_stream_t stream) {
   FF_RETURN_IF(check_model(m));
@@ -395,7 +396,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
           buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st));
     }
     enq = step + 1;
-    if (p->sync_every > 0 && (enq % p->sync_every) == 0 && enq < max_steps) {
+    if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
       const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
       FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, st));
       FF_CHECK_HIP(hipStreamSynchronize(st));
@@ -410,10 +411,13 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
 
   hipLaunchKernelGGL(finalize_kernel, dim3(ff_cdiv(Btot * T, 256) < 1024 ? ff_cdiv(Btot * T, 256) : 1024),
                      dim3(256), 0, st, buf.tok_all, buf.cnt_ge, buf.cnt_eq, p->variant, N, Btot, Bch, T, enq,
-                     predict, buf.steps_dev);
+                     (p->flags & FF_NO_STOP) ? 1 : 0, predict, buf.steps_dev);
   FF_CHECK_LAUNCH();
   int steps = 0;
   FF_CHECK_HIP(hipMemcpyAsync(&steps, buf.steps_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (step_counts && enq > 0)
+    FF_CHECK_HIP(hipMemcpyAsync(step_counts, (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
+                                sizeof(int) * enq, hipMemcpyDeviceToHost, st));
   FF_CHECK_HIP(hipStreamSynchronize(st));
   if (steps_done) *steps_done = steps;
 

@@ -201,6 +201,7 @@ extern "C" int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split
   }
   if (tile == 3 && !split128) tile = 2;
   hipStream_t st = (hipStream_t)stream;
+  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K, st);
   switch (tile) {
     case 1: return launch_gemm<64, 64, 32, 32>(g, st);
     case 2: return launch_gemm<128, 64, 64, 32>(g, st);

@@ -148,6 +148,7 @@ extern "C" int ff_pointer_argmax(const float* p, int ldp, const float* memory, i
                 next_tok, best, second, logits, ldlogits, next_rows, ldnext,
                 count_ge, ge_bound, count_eq, eq_value};
   hipStream_t st = (hipStream_t)stream;
+  FFProfScope prof(FF_CAT_POINTER, 2.0 * B * (double)S * E, st);
   dim3 grid(ff_cdiv(B, 4)), block(256);
   const int nv = ff_cdiv(E / 4, 64);
   if (nv <= 1) hipLaunchKernelGGL(pointer_kernel<1>, grid, block, 0, st, a);

@@ -26,6 +26,60 @@ extern "C" int ff_device_count(void) {
   return n;
 }
 
+// ---- event profiler ------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { int cat; double work; hipEvent_t a, b; };
+struct Profiler {
+  bool enabled = false;
+  std::vector<hipEvent_t> pool;
+  size_t next = 0;
+  std::vector<ProfRec> recs;
+  hipEvent_t get() {
+    if (next == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[next++];
+  }
+} g_prof;
+}  // namespace
+
+bool ff_prof_enabled() { return g_prof.enabled; }
+void ff_prof_open(int cat, double work, hipStream_t st) {
+  ProfRec r{cat, work, g_prof.get(), g_prof.get()};
+  if (r.a) (void)hipEventRecord(r.a, st);
+  g_prof.recs.push_back(r);
+}
+void ff_prof_close(hipStream_t st) {
+  if (!g_prof.recs.empty() && g_prof.recs.back().b) (void)hipEventRecord(g_prof.recs.back().b, st);
+}
+
+extern "C" int ff_profile_begin(void) {
+  g_prof.recs.clear();
+  g_prof.next = 0;
+  g_prof.enabled = true;
+  return FF_OK;
+}
+
+extern "C" int ff_profile_end(double* ms, double* work, long long* launches, int ncat) {
+  g_prof.enabled = false;
+  FF_CHECK_HIP(hipDeviceSynchronize());
+  for (int c = 0; c < ncat; ++c) { ms[c] = 0; work[c] = 0; launches[c] = 0; }
+  for (const ProfRec& r : g_prof.recs) {
+    if (r.cat < 0 || r.cat >= ncat || !r.a || !r.b) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+    ms[r.cat] += t;
+    work[r.cat] += r.work;
+    launches[r.cat] += 1;
+  }
+  g_prof.recs.clear();
+  g_prof.next = 0;
+  return FF_OK;
+}
+
 // ---- LayerNorm (+pos) --------------------------------------------------------------------------
 // NV = float4 chunks per lane (E <= 256*NV).  Two-pass statistics in registers (mean, then the
 // centred second moment) -- the same formula torch's CPU kernel evaluates, biased variance.
@@ -99,6 +153,7 @@ extern "C" int ff_layernorm(const float* x, int ldx, const float* gamma, const f
                  "ff_layernorm: bad pos arguments");
   }
   hipStream_t st = (hipStream_t)stream;
+  FFProfScope prof(FF_CAT_LN, (double)rows * E * 4.0 * (1 + (y != nullptr) + (ypos != nullptr)), st);
   dim3 block(256), grid(ff_cdiv(rows, 4));
   const int nv = ff_cdiv(E / 4, 64);
 #define FF_LN_LAUNCH(NV)                                                                         \
@@ -138,6 +193,7 @@ extern "C" int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, 
   size_t total = (size_t)rows * (E / 4);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
+  FFProfScope prof(FF_CAT_ROWOP, (double)rows * E * 8.0, (hipStream_t)stream);
   hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, pos,
                      ldpos, pos_div, pos_mod, out, ldout, rows, E / 4);
   FF_CHECK_LAUNCH();
@@ -166,6 +222,7 @@ extern "C" int ff_gather_rows(const float* memory, int S, int E, const int* tok,
   FF_CHECK_ARG(B > 0 && S > 0 && E > 0 && (E & 3) == 0 && seqs_per_group > 0 && (ldout & 3) == 0,
                "ff_gather_rows: bad sizes");
   FF_CHECK_ARG(memory && tok && out && ff_aligned16(memory) && ff_aligned16(out), "ff_gather_rows: bad pointers");
+  FFProfScope prof(FF_CAT_ROWOP, (double)B * E * 8.0, (hipStream_t)stream);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(ff_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream,
                      memory, S, E, tok, B, seqs_per_group, out, ldout);
   FF_CHECK_LAUNCH();
@@ -196,6 +253,7 @@ extern "C" int ff_assemble_embedding(const float* tok_embed, int num_token, cons
   FF_CHECK_ARG(tok_embed && out && (L == 0 || edge_embed) && ff_aligned16(tok_embed) &&
                    ff_aligned16(out) && ff_aligned16(edge_embed), "ff_assemble_embedding: bad pointers");
   int rows = N * (L + num_token);
+  FFProfScope prof(FF_CAT_ROWOP, (double)rows * E * 8.0, (hipStream_t)stream);
   hipLaunchKernelGGL(assemble_embedding_kernel, dim3(ff_cdiv(rows, 4)), dim3(256), 0,
                      (hipStream_t)stream, tok_embed, num_token, edge_embed, ld_edge, N, L, E, out);
   FF_CHECK_LAUNCH();

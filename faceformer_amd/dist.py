@@ -1,0 +1,89 @@
+"""Multi-GPU decode: wireframes are independent, so the batch is sharded by wireframe index (one
+process per GPU) and only RESULTS travel: one `all_gather_into_tensor` of the fixed-shape int32
+token tensor over RCCL/xGMI.  No collective sits on the data path of the kernels.
+
+The reference has no distributed code; what it fixes is the meaning of the raw
+`predict` tensor, which couples the wireframes of a batch in two places: the padded sequence count
+F = max(num_input) over the WHOLE batch (reference model_para.py:187) and the stop rule, evaluated
+over ALL sequences of the batch (model_para.py:232).  `decode_sharded` therefore (a) decodes every
+shard with the global F, (b) runs all T-1 steps locally without applying a stop rule, (c) sums the
+per-step special-token counters over ranks (tiny all_reduce) and applies the GLOBAL rule, and
+(d) gathers.  The result is identical to the single-GPU tensor for any world size.
+"""
+import torch
+
+from .hip import lib as _L
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block partition: [lo, hi) of `n_items` owned by `rank` (blocks of equal size
+    ceil(n/world); trailing ranks may own fewer or none)."""
+    per = (n_items + world - 1) // world
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per), per
+
+
+def gather_predictions(pred, dist_mod, group=None):
+    """all_gather of an integer token tensor [n_local, ...] (same shape on every rank) ->
+    [world * n_local, ...] int64 on every rank.  int32 on the wire (token ids < 2^31)."""
+    world = dist_mod.get_world_size(group)
+    send = pred.to(torch.int32).contiguous()
+    out = torch.empty((world * send.size(0),) + tuple(send.shape[1:]), dtype=torch.int32, device=send.device)
+    dist_mod.all_gather_into_tensor(out, send, group=group)
+    return out.to(torch.int64)
+
+
+def apply_global_stop(predict, counts, num_wireframes, variant):
+    """Zero the tokens after the reference's stop step given GLOBAL per-step counters.
+    predict [..., T]; counts[s] = #{tokens >= num_token} (parallel) or #{EOS} (seq2seq) at step s."""
+    steps = len(counts)
+    stop = steps
+    if variant == _L.FF_PARALLEL:
+        for s, c in enumerate(counts):
+            if c == 0:
+                stop = s + 1
+                break
+    else:
+        cum = 0
+        for s, c in enumerate(counts):
+            cum += c
+            if cum == num_wireframes:
+                stop = s + 1
+                break
+    if stop + 1 < predict.size(-1):
+        predict[..., stop + 1:] = 0
+    return predict, stop
+
+
+def decode_sharded(model, inputs, dist_mod, group=None):
+    """Decode the FULL batch `inputs` (same dict on every rank) across the ranks of `group`.
+    Returns the dict with 'predict' [N, F, T] (parallel) / [N, T] (seq2seq) for the whole batch on
+    every rank, identical to a single-process `model(inputs)['predict']`."""
+    from .models import SurfaceFormer_Parallel
+    rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
+    N = inputs["input"].size(0)
+    lo, hi, per = shard_range(N, rank, world)
+    parallel = isinstance(model, SurfaceFormer_Parallel)
+    variant = _L.FF_PARALLEL if parallel else _L.FF_SEQ2SEQ
+    T = model.max_face_length if parallel else model.num_labels
+    num_input = [int(n) for n in inputs["num_input"]] if parallel else None
+    F = max(num_input) if parallel else 1
+    dev = next(model.parameters()).device
+    local = torch.zeros((per, F, T), dtype=torch.int64, device=dev)
+    counts = torch.zeros(max(T - 1, 1), dtype=torch.int64, device=dev)
+    if hi > lo:
+        sub = {"input": inputs["input"][lo:hi], "input_mask": inputs["input_mask"][lo:hi]}
+        eng, memory, mask, kv_len = model._encode(sub)
+        out = eng.decode(memory, mask, kv_len, variant, T=T, F=F,
+                         num_input=num_input[lo:hi] if parallel else None,
+                         chunk_wireframes=model.chunk_wireframes, sync_every=0, flags=model.decode_flags,
+                         tok_sos=model.token.SOS if not parallel else 1,
+                         tok_eos=model.token.EOS if not parallel else 3, no_stop=True)
+        local[: hi - lo] = out["predict"].view(hi - lo, F, T)
+        c = out["step_counts"]
+        counts[: len(c)] = torch.tensor(c, dtype=torch.int64, device=dev)
+    dist_mod.all_reduce(counts, group=group)
+    full = gather_predictions(local, dist_mod, group)[:N]
+    full, _ = apply_global_stop(full, counts[: T - 1].tolist(), N, variant)
+    inputs["predict"] = full if parallel else full.view(N, T)
+    return inputs

@@ -118,7 +118,7 @@ class PathEngine:
 
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
                chunk_wireframes=0, sync_every=4, flags=DEFAULT_FLAGS, tok_sos=1, tok_eos=3,
-               trace=False, return_pointer=False):
+               trace=False, return_pointer=False, no_stop=False):
         """Greedy decode. Returns dict(predict [N*F, T] int64, steps, [pointer], [trace tensors])."""
         _dev(memory, "memory")
         N, S, E = memory.shape
@@ -126,7 +126,7 @@ class PathEngine:
         prm = _L.DecodeParams()
         prm.variant, prm.N, prm.L, prm.F, prm.T = variant, N, L, F, T
         prm.chunk_wireframes, prm.sync_every = chunk_wireframes, sync_every
-        prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0)
+        prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0) | (_L.FF_NO_STOP if no_stop else 0)
         prm.tok_sos, prm.tok_eos = tok_sos, tok_eos
         B = N * F
         dev = self.device
@@ -146,11 +146,12 @@ class PathEngine:
         nbytes = self._lib.ff_decode_workspace_bytes(C.byref(self.model), C.byref(prm))
         ws = self._workspace(nbytes)
         steps = C.c_int(0)
+        counts = (C.c_int * max(T - 1, 1))()
         _L.check(self._lib.ff_decode(
             C.byref(self.model), C.byref(prm), _p(memory), _p(mask_u8), _p(kv_len), _p(ni),
-            _p(extra_mask), _p(predict), C.byref(steps), _p(pointer), _p(tl), _p(tb), _p(ts),
+            _p(extra_mask), _p(predict), C.byref(steps), counts, _p(pointer), _p(tl), _p(tb), _p(ts),
             _p(ws), ws.numel(), _stream()), "ff_decode")
-        out = {"predict": predict, "steps": steps.value}
+        out = {"predict": predict, "steps": steps.value, "step_counts": list(counts)[: steps.value]}
         if return_pointer:
             out["pointer"] = pointer[: steps.value]
         if trace:

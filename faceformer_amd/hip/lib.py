@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libfaceformer_hip.so")
 FF_MAX_LAYERS = 16
 FF_HEAD_DIM = 64
 FF_PARALLEL, FF_SEQ2SEQ = 0, 1
-FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER = 1, 2, 4
+FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP = 1, 2, 4, 8
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -81,6 +81,8 @@ SIGNATURES = {
     "ff_version": (C.c_int, []),
     "ff_last_error": (C.c_char_p, []),
     "ff_device_count": (C.c_int, []),
+    "ff_profile_begin": (C.c_int, []),
+    "ff_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
                                fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,
@@ -99,7 +101,8 @@ SIGNATURES = {
                             C.c_size_t, fptr]),
     "ff_decode_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(DecodeParams)]),
     "ff_decode": (C.c_int, [C.POINTER(Model), C.POINTER(DecodeParams), fptr, fptr, fptr, fptr, fptr,
-                            fptr, C.POINTER(C.c_int), fptr, fptr, fptr, fptr, fptr, C.c_size_t, fptr]),
+                            fptr, C.POINTER(C.c_int), C.POINTER(C.c_int), fptr, fptr, fptr, fptr, fptr,
+                            C.c_size_t, fptr]),
 }
 
 _lib = None

@@ -43,6 +43,13 @@ const char* ff_last_error(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int ff_device_count(void);
 
+/* Measurement hooks (bench.py roofline leg; not on the product path).  Between begin and end every
+ * op launch of this library is bracketed by a hipEvent pair on its stream; end() synchronises the
+ * device and returns, per category (0 gemm, 1 attention, 2 layernorm, 3 pointer, 4 other row ops),
+ * the summed kernel time [ms], algorithmic work (flops for 0/1/3, bytes for 2/4) and launches. */
+int ff_profile_begin(void);
+int ff_profile_end(double* ms_by_cat, double* work_by_cat, long long* launches_by_cat, int ncat);
+
 /* ---------------------------------------------------------------------------------------------
  * G2  LayerNorm (+ positional add).  Replaces nn.LayerNorm followed by `with_pos_embed`
  * (reference faceformer/transformer.py:168-169, 242-243, 247-249, 253; torch LayerNorm: eps inside
@@ -194,7 +201,9 @@ enum ff_variant { FF_PARALLEL = 0, FF_SEQ2SEQ = 1 };
 enum ff_decode_flags {
   FF_REUSE_LAYER0_QKV = 1,   /* layer-0 self-attention q,k,v computed once per filled position */
   FF_LAST_LAYER_LAST_ROW = 2,/* last decoder layer evaluated for the newest position only */
-  FF_RETURN_POINTER = 4      /* also produce project(decoder(...)) for ALL prefix rows of the last step */
+  FF_RETURN_POINTER = 4,     /* also produce project(decoder(...)) for ALL prefix rows of the last step */
+  FF_NO_STOP = 8             /* run all T-1 steps and do not apply the stop rule (multi-GPU: the caller
+                                all-reduces step_counts and applies the GLOBAL rule) */
 };
 
 typedef struct ff_decode_params {
@@ -215,6 +224,8 @@ typedef struct ff_decode_params {
  *   extra_mask            : optional [B, S] uint8 additional pointer mask (co-edge style), or NULL
  *   predict [N*F, T] int64: output tokens incl. the start token, zero padded after the stop step
  *   steps_done            : host int, number of decode steps the reference semantics executed
+ *   step_counts           : optional host int[T-1]: per executed step, #{tokens >= num_token} (parallel)
+ *                           or #{tokens == EOS} (seq2seq) -- the inputs of the stop rules
  *   pointer_out           : optional [steps_done, N*F, E] (FF_RETURN_POINTER), position-major
  *   trace_logits          : optional [T-1, N*F, S] masked logits of every step (tests), or NULL
  *   trace_best/second     : optional [T-1, N*F] top-2 logits, or NULL
@@ -224,7 +235,7 @@ size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p);
 int ff_decode(const ff_model* m, const ff_decode_params* p,
               const float* memory, const unsigned char* mask, const int* kv_len,
               const int* num_input, const unsigned char* extra_mask,
-              int64_t* predict, int* steps_done, float* pointer_out,
+              int64_t* predict, int* steps_done, int* step_counts, float* pointer_out,
               float* trace_logits, float* trace_best, float* trace_second,
               void* workspace, size_t workspace_bytes, ff_stream_t stream);
 

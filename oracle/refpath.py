@@ -136,19 +136,24 @@ def _dims(sd):
 
 @torch.no_grad()
 def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=None,
-                          anchor_limit=None):
+                          anchor_limit=None, stop_rule=True, num_anchors=None):
     """SurfaceFormer_Parallel.forward_eval (reference model_para.py:181-241).
 
     `trace`: optional dict; receives 'logits' (list of BxS tensors per step) and 'memory'.
     `anchor_limit`: ONLY for the bounded cpu_baseline timing sample -- keep the first
     `anchor_limit` anchor sequences of every wireframe (sequences are independent, so their tokens
     are unchanged); `None` reproduces the reference exactly.
+    `stop_rule=False` / `num_anchors`: ONLY for the multi-process tests -- run all T-1 steps and record
+    the per-step special-token counts in trace['counts'] (a shard cannot evaluate the batch-global
+    stop rule alone), and pad the anchor set to the batch-global F = max(num_input).
     """
     num_model, n_enc, n_dec, num_token = _dims(sd)
     inp, input_mask, label = inputs["input"], inputs["input_mask"], inputs["label"]
     T = max_face_length if max_face_length is not None else sd["query_pos_enc.pos_embed.weight"].shape[0]
     batch_size = inp.size(0)
     max_num_edges = int(max(int(x) for x in inputs["num_input"]))
+    if num_anchors is not None:
+        max_num_edges = int(num_anchors)
 
     padding_mask = torch.zeros((len(input_mask), num_token)).type_as(input_mask)
     input_mask = torch.cat([padding_mask, input_mask], dim=1)
@@ -173,6 +178,7 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
     if trace is not None:
         trace["memory"] = memory.transpose(0, 1).clone()
         trace["logits"] = []
+        trace["counts"] = []
     memory = memory.repeat_interleave(max_num_edges, 1)
     input_mask = input_mask.repeat_interleave(max_num_edges, 0)
 
@@ -186,7 +192,9 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
         if trace is not None:
             trace["logits"].append(logit.clone())
         predicts = torch.cat((predicts, next_token), dim=0)
-        if torch.all(next_token < num_token):
+        if trace is not None:
+            trace["counts"].append(int((next_token >= num_token).sum()))
+        if stop_rule and torch.all(next_token < num_token):
             break
 
     predicts = torch.cat(

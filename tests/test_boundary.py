@@ -1,0 +1,192 @@
+"""CPU: the drop-in boundary -- config-file API, module surface, state_dict layout, C-ABI exports,
+and the no-fallback rule (the product path refuses to run without a ROCm device)."""
+import argparse
+import ctypes
+import glob
+import os
+import pickle
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, token_ns
+
+
+# ---- config-file API (reference faceformer/config.py:54-79) -------------------------------------------
+def test_default_tree_and_yaml_overlay():
+    from faceformer_amd.config import get_cfg, get_parser
+    args = get_parser().parse_args(["--config-file", os.path.join(ROOT, "configs", "ours.yml"),
+                                    "model.num_lines", "256", "trainer.lr", "0.5"])
+    cfg = get_cfg(args)
+    assert cfg.model_class == "SurfaceFormer_Parallel" and cfg.dataset_class == "ABCDataset_Parallel"
+    assert cfg.model.num_lines == 256 and cfg.model.max_face_length == 37
+    assert cfg.model.num_model == 512 and cfg.model.num_head == 8 and cfg.model.num_feedforward == 1024
+    assert cfg.model.token.len == 4 and cfg.model.token.SOS == 1 and cfg.model.token.EOS == 3
+    assert cfg.trainer.lr == 0.5 and cfg.post_process.enclosedness_tol == 2e-4
+    assert cfg.is_frozen()
+    with pytest.raises(AttributeError):
+        cfg.model.num_lines = 1
+    c2 = pickle.loads(pickle.dumps(cfg))
+    assert c2.model.num_lines == 256 and c2.is_frozen()
+    assert dict(**cfg.model)["num_lines"] == 256  # splatted into the model ctor by the harness
+
+
+def test_every_reference_config_loads():
+    from faceformer_amd.config import load_cfg
+    want = {"ours.yml": ("SurfaceFormer_Parallel", 216, 37, None),
+            "ours-perspective.yml": ("SurfaceFormer_Parallel", 202, 38, None),
+            "ours-fixed_viewpoint.yml": ("SurfaceFormer_Parallel", 186, 33, None),
+            "seq2seq.yml": ("SurfaceFormer", 110, None, 259),
+            "seq2seq+coedge.yml": ("SurfaceFormer", 216, None, 259)}
+    files = sorted(glob.glob(os.path.join(ROOT, "configs", "*.yml")))
+    assert {os.path.basename(f) for f in files} == set(want)
+    for f in files:
+        cfg = load_cfg(f)
+        cls, lines, tface, tseq = want[os.path.basename(f)]
+        assert cfg.model_class == cls and cfg.model.num_lines == lines
+        if tface:
+            assert cfg.model.max_face_length == tface
+        if tseq:
+            assert cfg.model.label_seq_length == tseq
+    assert load_cfg(os.path.join(ROOT, "configs", "seq2seq.yml")).post_process.is_coedge is False
+
+
+def test_config_rejects_unknown_keys_and_bad_types():
+    from faceformer_amd.config import load_cfg
+    with pytest.raises(KeyError):
+        load_cfg("", ["model.not_a_key", "1"])
+    with pytest.raises(ValueError):
+        load_cfg("", ["model.num_lines", "abc"])
+    with pytest.raises(ValueError):
+        load_cfg("", ["model.num_lines"])
+    assert load_cfg("", ["trainer.lr", "1"]).trainer.lr == 1.0  # int -> float promotion
+
+
+# ---- module surface / state_dict --------------------------------------------------
+def test_state_dict_layout_matches_appendix_b():
+    from faceformer_amd.config import load_cfg
+    from faceformer_amd.models import SurfaceFormer, SurfaceFormer_Parallel
+    from faceformer_amd.synth import make_state_dict, state_dict_spec
+    cfg = load_cfg(os.path.join(ROOT, "configs", "ours.yml"))
+    m = SurfaceFormer_Parallel(**cfg.model)
+    spec = state_dict_spec("parallel", 216, 37)
+    sd = m.state_dict()
+    assert len(sd) == 195 and list(sd.keys()) == [s[0] for s in spec]
+    for name, shape, _ in spec:
+        assert tuple(sd[name].shape) == tuple(shape), name
+    assert sum(p.numel() for p in m.parameters()) == 32256000
+    m.load_state_dict(make_state_dict(spec, "gain4", 1))       # strict load of synthetic weights
+    cfg2 = load_cfg(os.path.join(ROOT, "configs", "seq2seq+coedge.yml"))
+    m2 = SurfaceFormer(**cfg2.model)
+    assert sum(p.numel() for p in m2.parameters()) == 32369664
+    assert list(m2.state_dict().keys()) == [s[0] for s in state_dict_spec("seq2seq", 216, 259)]
+    # a Lightning checkpoint prefixes every key with "model." (reference trainer.py:20)
+    pref = {"model." + k: v for k, v in m2.state_dict().items()}
+    m2.load_state_dict({k[len("model."):]: v for k, v in pref.items()})
+
+
+def test_import_surface_of_reference_modules():
+    import faceformer_amd.embedding as emb
+    import faceformer_amd.transformer as tr
+    import faceformer_amd.utils as ut
+    for name in ("Transformer", "TransformerEncoder", "TransformerDecoder", "TransformerEncoderLayer",
+                 "TransformerDecoderLayer", "_get_clones", "_get_activation_fn"):
+        assert hasattr(tr, name)
+    for name in ("VanillaEmedding", "CoordinateEmbedding", "PositionalEncoding", "PositionEmbeddingLearned"):
+        assert hasattr(emb, name)
+    assert ut.min_value_of_dtype(torch.float32) == torch.finfo(torch.float32).min
+    assert ut.max_value_of_dtype(torch.int32) == 2 ** 31 - 1
+    assert ut.tiny_value_of_dtype(torch.half) == 1e-4 and ut.flatten_list([[1], [2, 3]]) == [1, 2, 3]
+    with pytest.raises(TypeError):
+        ut.min_value_of_dtype(torch.bool)
+    layer = tr.TransformerDecoderLayer(128, 2, 256, 0.1, "relu", True)
+    assert {n for n, _ in layer.named_parameters()} >= {"self_attn.in_proj_weight", "multihead_attn.out_proj.bias",
+                                                        "linear1.weight", "norm3.bias"}
+    pe = emb.PositionEmbeddingLearned(64, max_len=10)
+    assert tuple(pe(torch.zeros(2, 7, 64)).shape) == (1, 7, 64)
+    with pytest.raises(RuntimeError):
+        tr._get_activation_fn("swish")
+
+
+def test_alias_package_exposes_reference_names():
+    import faceformer
+    from faceformer.models import SurfaceFormer, SurfaceFormer_Parallel  # noqa: F401
+    from faceformer.transformer import TransformerDecoderLayer  # noqa: F401
+    from faceformer.embedding import VanillaEmedding  # noqa: F401
+    from faceformer.config import get_cfg, get_parser  # noqa: F401
+    from faceformer.utils import min_value_of_dtype  # noqa: F401
+    import faceformer_amd.models
+    assert SurfaceFormer is faceformer_amd.models.SurfaceFormer
+    assert faceformer.__name__ == "faceformer"
+
+
+# ---- no CPU fallback ------------------------------------------------------------------------------------
+def test_cpu_forward_fails_loudly():
+    from faceformer_amd.hip.lib import HipExtensionError
+    from faceformer_amd.models import SurfaceFormer_Parallel
+    from faceformer_amd import transformer as tr
+    m = SurfaceFormer_Parallel(num_model=128, num_head=2, num_feedforward=256, num_encoder_layers=1,
+                               num_decoder_layers=1, num_lines=8, max_face_length=5, token=token_ns()).eval()
+    batch = dict(input=torch.zeros(1, 8, 50, 2), input_mask=torch.zeros(1, 8, dtype=torch.bool),
+                 label=torch.zeros(1, 8, 5, dtype=torch.long), num_input=[8])
+    with pytest.raises(HipExtensionError):
+        m(batch)
+    with pytest.raises(NotImplementedError):
+        m.train()(batch)
+    enc = tr.TransformerEncoderLayer(128, 2, 256, 0.0, "relu", True).eval()
+    with pytest.raises(HipExtensionError):
+        enc(torch.zeros(4, 1, 128))
+
+
+def test_product_code_never_imports_the_oracle():
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "faceformer_amd", "**", "*.py"), recursive=True) + \
+            glob.glob(os.path.join(ROOT, "faceformer", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "/root/reference" in src:
+            bad.append(path)
+    assert not bad, bad
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(hip_lib):
+    header = open(os.path.join(ROOT, "include", "faceformer_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ff_[a-z0-9_]+)\s*\(", header))
+    assert {"ff_gemm_f32", "ff_attention", "ff_pointer_argmax", "ff_layernorm", "ff_encode", "ff_decode",
+            "ff_version"} <= declared
+    from faceformer_amd.hip import lib
+    assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert hip_lib.ff_version() >= 100
+    assert hip_lib.ff_last_error() is not None
+    assert hip_lib.ff_device_count() >= 0
+
+
+def test_struct_layouts_match_the_header(hip_lib):
+    """ctypes mirrors vs. the compiler's layout, via a tiny C probe compiled with gcc."""
+    import shutil
+    import subprocess
+    import tempfile
+    from faceformer_amd.hip import lib
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    probe = r'''
+#include <stdio.h>
+#include "faceformer_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(ff_attn_desc), sizeof(ff_mha_weights), sizeof(ff_layer_weights),
+         sizeof(ff_model), sizeof(ff_decode_params), offsetof(ff_model, dec));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "p.c"), os.path.join(d, "p")
+        open(src, "w").write(probe)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    got = [ctypes.sizeof(lib.AttnDesc), ctypes.sizeof(lib.MhaWeights), ctypes.sizeof(lib.LayerWeights),
+           ctypes.sizeof(lib.Model), ctypes.sizeof(lib.DecodeParams), lib.Model.dec.offset]
+    assert [int(x) for x in out] == got

@@ -1,0 +1,94 @@
+"""CPU, world_size 2 over gloo: the multi-GPU result path (shard by wireframe, global stop rule from
+all-reduced counters, all-gather of tokens) must reproduce the single-process tensor.  The device
+engine is replaced by an oracle-backed stand-in (tests only) because no GPU exists here; the GPU
+variant of this test lives in test_parity_golden.py::test_sharded_equals_single."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, case_weights_and_batch, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _OracleEngine:
+    """Stand-in for PathEngine: same decode() contract, tokens from the CPU oracle."""
+
+    def __init__(self, sd, num_head, batch):
+        self.sd, self.H, self.batch = sd, num_head, batch
+
+    def decode(self, memory, mask, kv_len, variant, T, F, num_input, no_stop=False, **kw):
+        from oracle import refpath
+        assert no_stop
+        lo, hi = memory
+        sub = {"input": self.batch["input"][lo:hi], "input_mask": self.batch["input_mask"][lo:hi],
+               "label": self.batch["label"][lo:hi], "num_input": list(num_input)}
+        trace = {}
+        out = refpath.parallel_forward_eval(self.sd, sub, num_head=self.H, trace=trace, stop_rule=False,
+                                            num_anchors=F)
+        return {"predict": out["predict"].reshape(-1, T), "steps": T - 1, "step_counts": trace["counts"]}
+
+
+def _worker(rank, world, port, name, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from faceformer_amd import dist as ffd
+    from faceformer_amd.models import SurfaceFormer_Parallel
+    from conftest import token_ns
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    m = case["model"]
+    model = SurfaceFormer_Parallel(num_model=m["E"], num_head=m["H"], num_feedforward=m["FF"],
+                                   num_encoder_layers=m["enc"], num_decoder_layers=m["dec"],
+                                   num_lines=m["L"], max_face_length=m["seq_len"], token=token_ns()).eval()
+    eng = _OracleEngine(sd, m["H"], batch)
+    lo, hi, _ = ffd.shard_range(batch["input"].size(0), rank, world)
+    model._encode = lambda sub: (eng, (lo, hi), None, None)   # carries the shard range to the stand-in
+    out = ffd.decode_sharded(model, dict(batch), dist)
+    ok = np.array_equal(out["predict"].numpy(), z["predict"])
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak", "par_small_break1"])
+def test_sharded_decode_equals_single_process_gloo(name):
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_range_and_global_stop():
+    from faceformer_amd import dist as ffd
+    from faceformer_amd.hip import lib as L
+    assert [ffd.shard_range(5, r, 2)[:2] for r in range(2)] == [(0, 3), (3, 5)]
+    assert [ffd.shard_range(3, r, 4)[:2] for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert ffd.shard_range(1024, 7, 8) == (896, 1024, 128)
+    pred = torch.arange(1, 13).view(2, 6).clone()
+    out, stop = ffd.apply_global_stop(pred.clone(), [3, 0, 2, 1, 9], 2, L.FF_PARALLEL)
+    assert stop == 2 and out[:, 3:].eq(0).all() and out[:, :3].equal(pred[:, :3])
+    out, stop = ffd.apply_global_stop(pred.clone(), [1, 0, 1, 0, 0], 2, L.FF_SEQ2SEQ)
+    assert stop == 3 and out[:, 4:].eq(0).all()
+    out, stop = ffd.apply_global_stop(pred.clone(), [1, 2, 0, 0, 0], 2, L.FF_SEQ2SEQ)
+    assert stop == 5 and out.equal(pred)   # the count jumped past N: the reference never stops early

@@ -165,3 +165,24 @@ def test_fresh_inputs_against_oracle(hip_lib):
         same = pred[:, s + 1] == gold[:, s + 1]
         assert same[alive & (margin > 2 * tol)].all()
         alive &= same
+
+
+@pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak", "par_small_break1", "seq_small_gain4"])
+def test_sharded_equals_single(hip_lib, name):
+    """decode_sharded on the real engine (world_size 1 over RCCL): no-stop decode + counters +
+    global stop rule + all-gather must reproduce the plain forward."""
+    import torch.distributed as dist
+    from faceformer_amd.dist import decode_sharded
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        created = True
+    try:
+        out = decode_sharded(model, batch_to(batch, "cuda"), dist)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert np.array_equal(out["predict"].cpu().numpy(), z["predict"])
