@@ -24,13 +24,14 @@ constexpr int KC = 64;     // keys per LDS chunk
 constexpr int K_LD = 68;   // padded K row (floats)
 constexpr int V_LD = 64;
 
-template <int NW>
+template <int NW, bool DB>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int q_tiles) {
-  __shared__ __attribute__((aligned(16))) float Ks[KC * K_LD];
-  __shared__ __attribute__((aligned(16))) float Vs[KC * V_LD];
-  __shared__ float Ms[KC];
+  constexpr int NBUF = DB ? 2 : 1;
+  constexpr int CHUNK_FLOATS = KC * K_LD + KC * V_LD + KC;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * CHUNK_FLOATS];
 
   constexpr int NT = 64 * NW;
+  constexpr int NLD = (KC * 16) / NT;  // float4 loads per thread per operand per chunk
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, l32 = lane & 31;
@@ -48,16 +49,19 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
   const size_t qrow = (size_t)g * d.q_group_stride + (size_t)(qc / d.q_inner) * d.q_outer_stride +
                       (size_t)(qc % d.q_inner);
 
+  // scores are kept in the log2 domain: q is pre-multiplied by scale * log2(e) so that the softmax
+  // numerator is a bare v_exp_f32 (2^x); the result is the same softmax.
+  const float qscale = d.scale * 1.4426950408889634f;
   float qreg[32];
   {
     const float* qp = d.q + qrow * d.ldq + h * FF_HEAD_DIM + half * 32;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       f32x4 t = *reinterpret_cast<const f32x4*>(qp + c * 4);
-      qreg[c * 4 + 0] = t.x * d.scale;
-      qreg[c * 4 + 1] = t.y * d.scale;
-      qreg[c * 4 + 2] = t.z * d.scale;
-      qreg[c * 4 + 3] = t.w * d.scale;
+      qreg[c * 4 + 0] = t.x * qscale;
+      qreg[c * 4 + 1] = t.y * qscale;
+      qreg[c * 4 + 2] = t.z * qscale;
+      qreg[c * 4 + 3] = t.w * qscale;
     }
   }
 
@@ -75,31 +79,56 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
   const float* kbase = d.k + (size_t)g * d.k_group_stride * d.ldk + h * FF_HEAD_DIM;
   const float* vbase = d.v + (size_t)g * d.k_group_stride * d.ldv + h * FF_HEAD_DIM;
 
-  for (int c0 = 0; c0 < nk; c0 += KC) {
-    __syncthreads();
-    // ---- stage K / V chunk + additive mask ----
+  // ---- staging: global -> registers -> LDS.  Only the rows of the 32-key tiles that will be
+  //      computed are touched (rows past nk inside such a tile are zero-filled: P is 0 there, but
+  //      0 * garbage must not produce NaN). ----
+  constexpr int NREG = DB ? NLD : 1;  // the single-buffered variant stages in small batches
+  f32x4 kreg[NREG], vreg[NREG];
+  float mreg = 0.f;
+  auto rows_needed = [&](int c0) { int r = nk - c0; r = r > KC ? KC : r; return (r + 31) & ~31; };
+  auto load_chunk = [&](int c0) {
+    const int need = rows_needed(c0);
 #pragma unroll
-    for (int p = 0; p < (KC * 16) / NT; ++p) {
+    for (int p = 0; p < NREG; ++p) {
       const int idx = tid + p * NT;
       const int row = idx >> 4, c4 = idx & 15;
       const int key = c0 + row;
-      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-      if (key < nk) {
+      kreg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      vreg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < need && key < nk) {
         const size_t krow = (size_t)key * d.k_stride;
-        kv = *reinterpret_cast<const f32x4*>(kbase + krow * d.ldk + c4 * 4);
-        vv = *reinterpret_cast<const f32x4*>(vbase + krow * d.ldv + c4 * 4);
+        kreg[p] = *reinterpret_cast<const f32x4*>(kbase + krow * d.ldk + c4 * 4);
+        vreg[p] = *reinterpret_cast<const f32x4*>(vbase + krow * d.ldv + c4 * 4);
       }
-      *reinterpret_cast<f32x4*>(Ks + row * K_LD + c4 * 4) = kv;
-      *reinterpret_cast<f32x4*>(Vs + row * V_LD + c4 * 4) = vv;
     }
     if (tid < KC) {
       const int key = c0 + tid;
       bool masked = key >= nk;
       if (!masked && d.key_mask) masked = d.key_mask[(size_t)g * d.mask_stride + key] != 0;
-      Ms[tid] = masked ? -INFINITY : 0.f;
+      mreg = masked ? -INFINITY : 0.f;
     }
-    __syncthreads();
+  };
+  auto store_chunk = [&](int c0, int buf) {
+    const int need = rows_needed(c0);
+    float* Ks = lds + buf * CHUNK_FLOATS;
+    float* Vs = Ks + KC * K_LD;
+    float* Ms = Vs + KC * V_LD;
+#pragma unroll
+    for (int p = 0; p < NREG; ++p) {
+      const int idx = tid + p * NT;
+      const int row = idx >> 4, c4 = idx & 15;
+      if (row < need) {
+        *reinterpret_cast<f32x4*>(Ks + row * K_LD + c4 * 4) = kreg[p];
+        *reinterpret_cast<f32x4*>(Vs + row * V_LD + c4 * 4) = vreg[p];
+      }
+    }
+    if (tid < KC) Ms[tid] = mreg;
+  };
 
+  auto compute_chunk = [&](int c0, int buf) {
+    const float* Ks = lds + buf * CHUNK_FLOATS;
+    const float* Vs = Ks + KC * K_LD;
+    const float* Ms = Vs + KC * V_LD;
 #pragma unroll
     for (int kt = 0; kt < KC / 32; ++kt) {
       if (c0 + kt * 32 >= nk) break;  // block-uniform
@@ -129,11 +158,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
       const float m_new = fmaxf(m_run, tmax);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = expf(m_run - m_safe);
+      const float alpha = exp2f(m_run - m_safe);
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = expf(s[r] - m_safe);
+        const float p = exp2f(s[r] - m_safe);
         s[r] = p;
         psum += p;
       }
@@ -150,6 +179,57 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
         o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
       }
+    }
+  };
+
+  if (DB) {
+    if (nk > 0) {
+      load_chunk(0);
+      store_chunk(0, 0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < nk; c0 += KC) {
+      const bool more = (c0 + KC) < nk;
+      if (more) load_chunk(c0 + KC);
+      compute_chunk(c0, buf);
+      if (more) store_chunk(c0 + KC, buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    for (int c0 = 0; c0 < nk; c0 += KC) {
+      __syncthreads();
+      {
+        const int need = rows_needed(c0);
+        float* Ks = lds;
+        float* Vs = Ks + KC * K_LD;
+        float* Ms = Vs + KC * V_LD;
+#pragma unroll 4
+        for (int p = 0; p < NLD; ++p) {
+          const int idx = tid + p * NT;
+          const int row = idx >> 4, c4 = idx & 15;
+          const int key = c0 + row;
+          if (row < need) {
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < nk) {
+              const size_t krow = (size_t)key * d.k_stride;
+              kv = *reinterpret_cast<const f32x4*>(kbase + krow * d.ldk + c4 * 4);
+              vv = *reinterpret_cast<const f32x4*>(vbase + krow * d.ldv + c4 * 4);
+            }
+            *reinterpret_cast<f32x4*>(Ks + row * K_LD + c4 * 4) = kv;
+            *reinterpret_cast<f32x4*>(Vs + row * V_LD + c4 * 4) = vv;
+          }
+        }
+        if (tid < KC) {
+          const int key = c0 + tid;
+          bool masked = key >= nk;
+          if (!masked && d.key_mask) masked = d.key_mask[(size_t)g * d.mask_stride + key] != 0;
+          Ms[tid] = masked ? -INFINITY : 0.f;
+        }
+      }
+      __syncthreads();
+      compute_chunk(c0, 0);
     }
   }
 
@@ -190,11 +270,11 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   FF_CHECK_ARG(blocks < 2147483647L, "ff_attention: grid too large");
   FFProfScope prof(FF_CAT_ATTN, 4.0 * FF_HEAD_DIM * (double)gh * d.nq * d.nk, st);
   if (nw == 4)
-    hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, d, q_tiles);
+    hipLaunchKernelGGL((attention_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, st, d, q_tiles);
   else if (nw == 2)
-    hipLaunchKernelGGL(attention_kernel<2>, dim3((unsigned)blocks), dim3(128), 0, st, d, q_tiles);
+    hipLaunchKernelGGL((attention_kernel<2, false>), dim3((unsigned)blocks), dim3(128), 0, st, d, q_tiles);
   else
-    hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, st, d, q_tiles);
+    hipLaunchKernelGGL((attention_kernel<1, false>), dim3((unsigned)blocks), dim3(64), 0, st, d, q_tiles);
   FF_CHECK_LAUNCH();
   return FF_OK;
 }

@@ -108,7 +108,7 @@ struct DecodeBuffers {
   float *mem_pos, *kvc[FF_MAX_LAYERS];
   float *x0_all, *qkv0_all;
   int* tok_all;
-  float *x, *y, *yq, *qkv, *o, *h, *p;
+  float *x, *y, *yq, *qkv, *o, *h, *p, *logits;
   int *cnt_ge, *cnt_eq, *steps_dev;
 };
 
@@ -139,6 +139,7 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, Bump& bp, Dec
   b.o = bp.take<float>(Rmax * E);
   b.h = bp.take<float>(Rmax * FFd);
   b.p = bp.take<float>(Bch * E);
+  b.logits = bp.take<float>(Bch * (size_t)S);
   b.cnt_ge = bp.take<int>(T);
   b.cnt_eq = bp.take<int>(T);
   b.steps_dev = bp.take<int>(4);
@@ -392,7 +393,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
           buf.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
           extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, F, c.tok + (size_t)t * c.Bc,
           trace_best ? trace_best + trow : nullptr, trace_second ? trace_second + trow : nullptr,
-          trace_logits ? trace_logits + trow * S : nullptr, S, c.x0 + (size_t)t * c.Bc * E, E,
+          trace_logits ? trace_logits + trow * S : buf.logits, S, c.x0 + (size_t)t * c.Bc * E, E,
           buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st));
     }
     enq = step + 1;

@@ -27,6 +27,7 @@ struct GemmArgs {
   int M, N, K;
   int n_split, act;
   int tiles_m, tiles_n;
+  long long batch_stride_a, batch_stride_w, batch_stride_c;  // blockIdx.y = batch index (elements)
 };
 
 constexpr int BK = 32;
@@ -48,8 +49,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int lid = ff_xcd_remap(blockIdx.x, nblocks);
   const int m0 = (lid / g.tiles_n) * BM;
   const int n0 = (lid % g.tiles_n) * BN;
-  const float* __restrict__ Asrc = (g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A;
-  const float* __restrict__ W = g.W;
+  const long long bz = blockIdx.y;
+  const float* __restrict__ Asrc =
+      ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + bz * g.batch_stride_a;
+  const float* __restrict__ W = g.W + bz * g.batch_stride_w;
+  float* __restrict__ Cout = g.C + bz * g.batch_stride_c;
 
   // ---- global -> register staging (thread: float4 column c4 of rows r, r+32, ...) -------------
   const int c4 = tid & 7, r = tid >> 3;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           float v = acc[mi][ni][e] + bv;
           if (g.act == 1) v = fmaxf(v, 0.f);
           if (g.res) v += g.res[(size_t)row * g.ldr + col];
-          g.C[(size_t)row * g.ldc + col] = v;
+          Cout[(size_t)row * g.ldc + col] = v;
         }
       }
     }
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_gemm(GemmArgs g, hipStream_t st) {
+int launch_gemm(GemmArgs g, int batch, hipStream_t st) {
   static bool attr_set = false;
   constexpr int bytes = gemm_lds_bytes<BM, BN>();
   if (!attr_set) {
@@ -166,18 +170,20 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   }
   g.tiles_m = ff_cdiv(g.M, BM);
   g.tiles_n = ff_cdiv(g.N, BN);
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * g.tiles_n), dim3(256), bytes,
-                     st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256),
+                     bytes, st, g);
   FF_CHECK_LAUNCH();
   return FF_OK;
 }
 
 }  // namespace
 
-extern "C" int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split, const float* W,
-                           int ldw, const float* bias, const float* residual, int ldr, float* C,
-                           int ldc, int M, int N, int K, int act, int tile, ff_stream_t stream) {
-  if (M == 0 || N == 0) return FF_OK;
+extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
+                                   const float* W, int ldw, const float* bias, const float* residual,
+                                   int ldr, float* C, int ldc, int M, int N, int K, int act, int tile,
+                                   int batch, long long stride_a, long long stride_w,
+                                   long long stride_c, ff_stream_t stream) {
+  if (M == 0 || N == 0 || batch == 0) return FF_OK;
   FF_CHECK_ARG(M > 0 && N > 0 && K > 0 && (K & 3) == 0, "ff_gemm_f32: bad M=%d N=%d K=%d (K %% 4)", M, N, K);
   FF_CHECK_ARG(A && W && C, "ff_gemm_f32: null operand");
   FF_CHECK_ARG((lda & 3) == 0 && (ldw & 3) == 0 && lda >= K && ldw >= K && ldc >= N,
@@ -187,24 +193,33 @@ extern "C" int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
   FF_CHECK_ARG(tile >= 0 && tile <= 3, "ff_gemm_f32: tile must be 0..3");
+  FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
+               "ff_gemm_f32: bad batch arguments");
+  FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
   if (A2) FF_CHECK_ARG(n_split > 0 && n_split < N && (n_split % 64) == 0, "ff_gemm_f32: n_split must be a multiple of 64 inside (0,N)");
-  GemmArgs g{A, A2, W, bias, residual, C, lda, ldw, ldr, ldc, M, N, K, A2 ? n_split : N, act, 0, 0};
+  GemmArgs g{A, A2, W, bias, residual, C, lda, ldw, ldr, ldc, M, N, K, A2 ? n_split : N, act, 0, 0,
+             stride_a, stride_w, stride_c};
   const bool split128 = !A2 || (n_split % 128) == 0;
   if (tile == 0) {
-    // Fill heuristic: 256 CUs, up to 2 resident blocks each.  Prefer the largest tile that still
-    // gives every CU at least ~2 blocks; small problems take 64x64 tiles for parallelism.
-    const long t128 = (long)ff_cdiv(M, 128) * ff_cdiv(N, 128);
-    const long t12864 = (long)ff_cdiv(M, 128) * ff_cdiv(N, 64);
-    if (split128 && t128 >= 1024) tile = 3;
-    else if (t12864 >= 768) tile = 2;
-    else tile = 1;
+    // Measured on MI355X over the path's shapes (tools/bench_gemm.py, M = 256..9216, K = 512/1024):
+    // the 64x64 block tile wins or ties everywhere below ~3000 tiles because it is the only one
+    // that keeps several blocks resident per CU; larger tiles only pay for very large M.
+    const long t128 = (long)ff_cdiv(M, 128) * ff_cdiv(N, 128) * batch;
+    tile = (split128 && t128 >= 4096) ? 3 : 1;
   }
   if (tile == 3 && !split128) tile = 2;
   hipStream_t st = (hipStream_t)stream;
-  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K, st);
+  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
   switch (tile) {
-    case 1: return launch_gemm<64, 64, 32, 32>(g, st);
-    case 2: return launch_gemm<128, 64, 64, 32>(g, st);
-    default: return launch_gemm<128, 128, 64, 64>(g, st);
+    case 1: return launch_gemm<64, 64, 32, 32>(g, batch, st);
+    case 2: return launch_gemm<128, 64, 64, 32>(g, batch, st);
+    default: return launch_gemm<128, 128, 64, 64>(g, batch, st);
   }
+}
+
+extern "C" int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split, const float* W,
+                           int ldw, const float* bias, const float* residual, int ldr, float* C,
+                           int ldc, int M, int N, int K, int act, int tile, ff_stream_t stream) {
+  return ff_gemm_f32_batched(A, lda, A2, n_split, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, tile,
+                             1, 0, 0, 0, stream);
 }

@@ -89,6 +89,9 @@ SIGNATURES = {
                              C.c_int, fptr]),
     "ff_gemm_f32": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "ff_gemm_f32_batched": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_longlong, C.c_longlong, C.c_longlong, fptr]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_pointer_argmax": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int,
                                     C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int,

@@ -82,6 +82,17 @@ int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split,
                 const float* residual, int ldr, float* C, int ldc,
                 int M, int N, int K, int act, int tile, ff_stream_t stream);
 
+/* Same product for `batch` independent problems in one launch: problem z uses A + z*stride_a
+ * (and A2 + z*stride_a), W + z*stride_w, C + z*stride_c (strides in elements; bias is shared;
+ * residual unsupported for batch > 1).  Used for the pointer logits, one weight matrix
+ * (= the wireframe's edge embeddings) per wireframe. */
+int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
+                        const float* W, int ldw, const float* bias,
+                        const float* residual, int ldr, float* C, int ldc,
+                        int M, int N, int K, int act, int tile,
+                        int batch, long long stride_a, long long stride_w, long long stride_c,
+                        ff_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * G4/G5/G6  Multi-head attention core: softmax(q k^T * scale + mask) v for `num_groups` groups
  * that each share one key/value set, `num_heads` heads of FF_HEAD_DIM columns.  Replaces the
@@ -123,8 +134,14 @@ int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
  *   logit[b,s] = < memory[w(b), s, :], p[b, :] >,  w(b) = b / seqs_per_group
  *   masked (mask[w,s] != 0, s >= kv_len[w], or extra_mask[b,s] != 0) -> -FLT_MAX (finfo.min, not -inf)
  *   next_tok[b] = argmax_s (lowest index on ties)
- * One wavefront per sequence; p in registers, embedding rows streamed with coalesced float4
- * loads, 64-lane butterfly reduction per logit.  Optional outputs (NULL to skip):
+ * Two code paths, same results up to fp32 summation order:
+ *   logits == NULL : streaming kernel, one wavefront per sequence; p in registers, embedding rows
+ *                    streamed with coalesced float4 loads, 64-lane butterfly reduction per logit;
+ *   logits != NULL : [B, ldlogits] scratch/output: raw logits by the batched f32-MFMA GEMM (one
+ *                    problem per wireframe: [seqs_per_group, E] x [E, S]), then one wavefront per
+ *                    sequence masks its row in place and reduces (value, index) pairs by shuffles
+ *                    (what the engine uses: 40x faster at 256 sequences per wireframe).
+ * Optional outputs (NULL to skip):
  *   best/second [B]   top-2 logits (parity margins),  logits [B, ldlogits] masked logits,
  *   next_rows [B, ldnext] = memory[w(b), next_tok[b], :]  (next decoder input row),
  *   count_lt / count_eq: *count_lt += #{b: next_tok[b] >= lt_bound}, *count_eq += #{b: next_tok[b] == eq_value}

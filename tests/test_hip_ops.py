@@ -217,6 +217,15 @@ def test_pointer_argmax(ops, W, F, S, E):
     nxt = res["next"].cpu().long()
     assert torch.equal(res["rows"].cpu(), mem[torch.arange(B) // F, nxt])
     assert counters.cpu().tolist() == [int((nxt >= 4).sum()), int((nxt == 3).sum())]
+    # the streaming path (no logits buffer) must agree with the GEMM path
+    counters.zero_()
+    res2 = ops.pointer_argmax(p.cuda(), mem.cuda(), mask.to(torch.uint8).cuda(), kv_len.cuda(),
+                              seqs_per_group=F, want_rows=True, counters=counters, ge_bound=4, eq_value=3)
+    decisive = (top2[:, 0] - top2[:, 1]) > 1e-3 if S > 1 else torch.ones(B, dtype=torch.bool)
+    assert torch.equal(res2["next"].cpu()[decisive], res["next"].cpu()[decisive])
+    assert float((res2["best"].cpu() - res["best"].cpu()).abs().max()) < 1e-4 * float(top2[:, 0].abs().max())
+    if S > 1:
+        assert float((res2["second"].cpu() - res["second"].cpu()).abs().max()) < 1e-4 * float(top2[:, 0].abs().max())
 
 
 def test_pointer_ties_and_all_masked(ops):
