@@ -44,9 +44,14 @@ def main():
             flops = 2.0 * M * N * K
             iters = max(3, min(50, int(2e11 / flops)))
             res = []
+            # as on the path: N=512 products accumulate into the residual stream (residual aliases
+            # the output), N=1024 is the ReLU feed-forward layer, N=1536 the plain q|k|v projection
+            resid = out if N == 512 else None
+            act = 1 if N == 1024 else 0
             for tile in tiles:
-                dt = timeit(lambda: ops.linear(a, w, b, tile=tile, out=out), iters)
+                dt = timeit(lambda: ops.linear(a, w, b, act=act, residual=resid, tile=tile, out=out), iters)
                 res.append(flops / dt / 1e12)
+                out.normal_()
             dt = timeit(lambda: torch.addmm(b, a, w.t(), out=out), iters)
             print("%8d %5d %5d | %s | %8.1f" % (M, K, N, " ".join("%10.1f" % r for r in res), flops / dt / 1e12))
 
