@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--wireframes-per-gpu", type=int, default=1)
     ap.add_argument("--edges", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=0, help="wireframes per micro-batch (0 = all)")
+    ap.add_argument("--chunk-seqs", type=int, default=0, help="sequences per intra-wireframe group (0 = off)")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams for the micro-batches")
+    ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")
     ap.add_argument("--cpu-anchors", type=int, default=32, help="anchor sequences in the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch threads for the CPU oracle")
     ap.add_argument("--cpu-timeout", type=int, default=150, help="wall-clock cap of the CPU sample [s]")
@@ -95,6 +98,8 @@ def main():
     model.load_state_dict(sd)
     model = model.eval().to(dev)
     model.chunk_wireframes = args.chunk
+    model.chunk_seqs, model.num_streams = args.chunk_seqs, args.streams
+    model.sync_every = args.sync_every
     seeds = [rank * W + i for i in range(W)]
     batch_cpu = make_wireframes(n, n, T, "parallel", seeds=seeds)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
@@ -158,12 +163,24 @@ def main():
         with torch.no_grad():
             model(dict(batch))
         L.check(lib.ff_profile_end(ms, work, cnt, ncat), "ff_profile_end")
-        names = ["gemm_f32_kernel", "attention_kernel", "layernorm_kernel", "pointer_kernel", "row_ops"]
+        names = ["gemm_pipe_kernel", "attention_kernel", "layernorm_kernel", "pointer_kernels", "row_ops"]
         total_ms = sum(ms)
         ach = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel come from the committed PMC passes
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 fetch correction):
+        # bench.py cannot run the profiler around itself.
+        traffic, traffic_src = None, None
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+        if cands and n == 256 and W == 1:
+            with open(cands[-1]) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
         result["roofline"] = {
             "kernel": names[0], "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+            "alg_bytes_per_launch": None,
             "launches_per_step": int(cnt[0]), "avg_launch_us": 1e3 * ms[0] / max(1, cnt[0]),
             "alg_flop_per_launch": work[0] / max(1, cnt[0]),
             "share_of_kernel_time": ms[0] / total_ms if total_ms > 0 else None,

@@ -8,6 +8,7 @@
 #include "faceformer_hip.h"
 
 #define FF_WAVE 64
+#define FF_MAX_STREAMS 8
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -13,6 +13,8 @@
 //                               the active rows of step t are the first t*Bc rows: every GEMM of
 //                               the step is one dense [t*Bc, K] x [K, N] product)
 // Sequences b of a micro-batch belong to wireframe w0 + b / F; nothing is replicated per sequence.
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 
 #include "ff_common.h"
@@ -54,9 +56,9 @@ __global__ void init_tokens_kernel(int* tok, int B, int F, const int* num_input,
 
 // steps_done from the per-step counters, then predict[b, j] (int64) = token or 0 after the stop.
 __global__ void finalize_kernel(const int* __restrict__ tok_all, const int* __restrict__ cnt_ge,
-                                const int* __restrict__ cnt_eq, int variant, int N, int Btot,
-                                int Bchunk, int T, int steps_enqueued, int no_stop,
-                                int64_t* __restrict__ predict, int* __restrict__ steps_done_out) {
+                                const int* __restrict__ cnt_eq, int variant, int N, int Btot, int T,
+                                int steps_enqueued, int no_stop, int64_t* __restrict__ predict,
+                                int* __restrict__ steps_done_out) {
   int steps = steps_enqueued;
   if (no_stop) {
   } else if (variant == FF_PARALLEL) {
@@ -74,13 +76,7 @@ __global__ void finalize_kernel(const int* __restrict__ tok_all, const int* __re
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / T), j = (int)(i % T);
-    int64_t v = 0;
-    if (j <= steps) {
-      const int c = b / Bchunk, b0 = c * Bchunk;
-      const int Bc = (Btot - b0) < Bchunk ? (Btot - b0) : Bchunk;
-      v = tok_all[(size_t)T * b0 + (size_t)j * Bc + (b - b0)];
-    }
-    predict[i] = v;
+    predict[i] = (j <= steps) ? (int64_t)tok_all[(size_t)j * Btot + b] : (int64_t)0;
   }
 }
 
@@ -104,26 +100,47 @@ int gemm(const float* A, int lda, const float* A2, int n_split, const float* W, 
   return ff_gemm_f32(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, 0, st);
 }
 
+// Scratch of one in-flight micro-batch (one set per stream): R = t*Bc active rows, position-major.
+struct Scratch {
+  float *x, *y, *yq, *qkv, *o, *h, *p, *logits;
+};
+
 struct DecodeBuffers {
   float *mem_pos, *kvc[FF_MAX_LAYERS];
   float *x0_all, *qkv0_all;
-  int* tok_all;
-  float *x, *y, *yq, *qkv, *o, *h, *p, *logits;
+  int* tok_all;   // [T, Btot] global, position-major
+  Scratch scr[FF_MAX_STREAMS];
   int *cnt_ge, *cnt_eq, *steps_dev;
 };
 
+// A micro-batch is a contiguous range [b0, b0 + Bc) of the global sequence index b = w*F + f:
+// either whole wireframes (nw >= 1, Fc = F) or a group of Fc < F sequences of ONE wireframe.
 struct Chunk {
-  int w0, nw, b0, Bc;
-  float* x0;
-  float* qkv0;
-  int* tok;
+  int w0, nw, Fc, b0, Bc, sid;
+  float* x0;     // [T, Bc, E]
+  float* qkv0;   // [T, Bc, 3E] or null
 };
+
+struct Plan {
+  int cw, cs, ns;       // wireframes per chunk, sequences per sub-wireframe chunk (0: none), streams
+  size_t max_bc;
+};
+
+Plan make_plan(const ff_decode_params* p) {
+  Plan pl;
+  pl.cw = (p->chunk_wireframes <= 0 || p->chunk_wireframes > p->N) ? p->N : p->chunk_wireframes;
+  pl.cs = (p->chunk_seqs > 0 && p->chunk_seqs < p->F) ? p->chunk_seqs : 0;
+  if (pl.cs) pl.cw = 1;
+  pl.ns = p->num_streams < 1 ? 1 : (p->num_streams > FF_MAX_STREAMS ? FF_MAX_STREAMS : p->num_streams);
+  pl.max_bc = pl.cs ? (size_t)pl.cs : (size_t)pl.cw * p->F;
+  return pl;
+}
 
 size_t layout_decode(const ff_model* m, const ff_decode_params* p, Bump& bp, DecodeBuffers* out) {
   const int E = m->E, FFd = m->FF, S = p->L + m->num_token, T = p->T;
   const size_t Btot = (size_t)p->N * p->F;
-  const int cw = (p->chunk_wireframes <= 0 || p->chunk_wireframes > p->N) ? p->N : p->chunk_wireframes;
-  const size_t Bch = (size_t)cw * p->F;
+  const Plan pl = make_plan(p);
+  const size_t Bch = pl.max_bc;
   const size_t Rmax = (size_t)(T - 1 > 0 ? T - 1 : 1) * Bch;
   DecodeBuffers b;
   memset(&b, 0, sizeof(b));
@@ -132,14 +149,17 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, Bump& bp, Dec
   b.x0_all = bp.take<float>((size_t)T * Btot * E);
   b.tok_all = bp.take<int>((size_t)T * Btot);
   b.qkv0_all = (p->flags & FF_REUSE_LAYER0_QKV) ? bp.take<float>((size_t)T * Btot * 3 * E) : nullptr;
-  b.x = bp.take<float>(Rmax * E);
-  b.y = bp.take<float>(Rmax * E);
-  b.yq = bp.take<float>(Rmax * E);
-  b.qkv = bp.take<float>(Rmax * 3 * E);
-  b.o = bp.take<float>(Rmax * E);
-  b.h = bp.take<float>(Rmax * FFd);
-  b.p = bp.take<float>(Bch * E);
-  b.logits = bp.take<float>(Bch * (size_t)S);
+  for (int s = 0; s < pl.ns; ++s) {
+    Scratch& c = b.scr[s];
+    c.x = bp.take<float>(Rmax * E);
+    c.y = bp.take<float>(Rmax * E);
+    c.yq = bp.take<float>(Rmax * E);
+    c.qkv = bp.take<float>(Rmax * 3 * E);
+    c.o = bp.take<float>(Rmax * E);
+    c.h = bp.take<float>(Rmax * FFd);
+    c.p = bp.take<float>(Bch * E);
+    c.logits = bp.take<float>(Bch * (size_t)S);
+  }
   b.cnt_ge = bp.take<int>(T);
   b.cnt_eq = bp.take<int>(T);
   b.steps_dev = bp.take<int>(4);
@@ -150,10 +170,10 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, Bump& bp, Dec
 // One decoder pass over the current prefix (t positions) of one micro-batch.
 // full_rows: evaluate every layer for all rows and project all rows into proj_all (ld = E rows
 // position-major within the chunk); otherwise the result is p[Bc, E] for the newest position.
-int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuffers& buf,
+int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuffers& bufs, const Scratch& buf,
                  const Chunk& ck, const unsigned char* mask, const int* kv_len, int t, bool full_rows,
                  float* proj_all, hipStream_t st) {
-  const int E = m->E, FFd = m->FF, H = m->H, S = prm->L + m->num_token, F = prm->F, T = prm->T;
+  const int E = m->E, FFd = m->FF, H = m->H, S = prm->L + m->num_token, F = ck.Fc, T = prm->T;
   const int Bc = ck.Bc, R = t * Bc, nd = m->num_dec_layers;
   const size_t newoff = (size_t)(t - 1) * Bc;
   const bool reuse0 = (prm->flags & FF_REUSE_LAYER0_QKV) != 0 && ck.qkv0 != nullptr;
@@ -214,7 +234,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       ff_attn_desc d;
       memset(&d, 0, sizeof(d));
       d.q = qc + roff * E;      d.ldq = E;
-      d.k = buf.kvc[l] + (size_t)ck.w0 * S * 2 * E;      d.ldk = 2 * E;
+      d.k = bufs.kvc[l] + (size_t)ck.w0 * S * 2 * E;     d.ldk = 2 * E;
       d.v = d.k + E;            d.ldv = 2 * E;
       d.o = buf.o + roff * E;   d.ldo = E;
       d.num_groups = ck.nw; d.num_heads = H;
@@ -245,6 +265,29 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     FF_RETURN_IF(ff_layernorm(buf.x + newoff * E, E, m->dec_norm_w, m->dec_norm_b, m->ln_eps, buf.y, E, nullptr, 0,
                               nullptr, 0, 1, 1, Bc, E, st));
     FF_RETURN_IF(gemm(buf.y, E, nullptr, 0, m->proj_w, E, m->proj_b, nullptr, 0, buf.p, E, Bc, E, E, 0, st));
+  }
+  return FF_OK;
+}
+
+// Internal side streams + fork/join events (created once per process).
+struct StreamPool {
+  hipStream_t side[FF_MAX_STREAMS];
+  hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];
+  int created;
+  bool events;
+};
+StreamPool g_pool = {{}, nullptr, {}, 0, false};
+
+int pool_get(int n) {
+  if (!g_pool.events) {
+    FF_CHECK_HIP(hipEventCreateWithFlags(&g_pool.fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < FF_MAX_STREAMS; ++i)
+      FF_CHECK_HIP(hipEventCreateWithFlags(&g_pool.join_ev[i], hipEventDisableTiming));
+    g_pool.events = true;
+  }
+  while (g_pool.created < n) {
+    FF_CHECK_HIP(hipStreamCreateWithFlags(&g_pool.side[g_pool.created], hipStreamNonBlocking));
+    g_pool.created++;
   }
   return FF_OK;
 }
@@ -339,7 +382,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_CHECK_ARG(T - 1 <= m->qpos_len, "ff_decode: T-1=%d exceeds the query position table (%d rows)", T - 1, m->qpos_len);
   FF_CHECK_ARG(p->variant != FF_PARALLEL || F <= S, "ff_decode: F=%d anchors exceed S=%d", F, S);
   FF_CHECK_ARG(!(p->flags & FF_RETURN_POINTER) || pointer_out, "ff_decode: pointer_out required");
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t main_st = (hipStream_t)stream;
 
   Bump bp(workspace, workspace_bytes);
   DecodeBuffers buf;
@@ -347,60 +390,88 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   if (!bp.ok) { ff_set_error("ff_decode: workspace too small (%zu needed, %zu given)", bp.off, workspace_bytes); return FF_ERR_WORKSPACE; }
 
   const int Btot = N * F;
-  const int cw = (p->chunk_wireframes <= 0 || p->chunk_wireframes > N) ? N : p->chunk_wireframes;
-  const int Bch = cw * F;
+  const Plan pl = make_plan(p);
   std::vector<Chunk> chunks;
-  for (int w0 = 0; w0 < N; w0 += cw) {
-    Chunk c;
-    c.w0 = w0; c.nw = (N - w0) < cw ? (N - w0) : cw;
-    c.b0 = w0 * F; c.Bc = c.nw * F;
-    c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
-    c.tok = buf.tok_all + (size_t)T * c.b0;
-    c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
-    chunks.push_back(c);
+  for (int w0 = 0; w0 < N; w0 += pl.cw) {
+    const int nw = (N - w0) < pl.cw ? (N - w0) : pl.cw;
+    const int fstep = pl.cs ? pl.cs : F;
+    for (int f0 = 0; f0 < F; f0 += fstep) {
+      Chunk c;
+      c.w0 = w0; c.nw = nw;
+      c.Fc = (F - f0) < fstep ? (F - f0) : fstep;
+      c.b0 = w0 * F + f0;
+      c.Bc = nw * c.Fc;
+      c.sid = (int)(chunks.size() % pl.ns);
+      c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
+      c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
+      chunks.push_back(c);
+    }
+  }
+  const int ns = pl.ns < (int)chunks.size() ? pl.ns : (int)chunks.size();
+  // With more than one stream ALL micro-batch work runs on the internal pool (the caller's stream is
+  // often the legacy default stream, whose implicit synchronisation would serialise the others).
+  hipStream_t sts[FF_MAX_STREAMS];
+  sts[0] = main_st;
+  if (ns > 1) {
+    FF_RETURN_IF(pool_get(ns));
+    for (int s = 0; s < ns; ++s) sts[s] = g_pool.side[s];
   }
 
-  // ---- per-batch invariants: memory + pos, cross-attention K|V of every layer --------------------
+  // ---- per-batch invariants (main stream): memory + pos, cross-attention K|V of every layer ----
   const int RS = N * S;
-  FF_RETURN_IF(ff_add_pos(memory, E, m->pos_table, E, 1, S, buf.mem_pos, E, RS, E, st));
+  FF_RETURN_IF(ff_add_pos(memory, E, m->pos_table, E, 1, S, buf.mem_pos, E, RS, E, main_st));
   for (int l = 0; l < m->num_dec_layers; ++l) {
     const ff_mha_weights& c = m->dec[l].cross_attn;
     FF_RETURN_IF(gemm(buf.mem_pos, E, memory, E, c.in_proj_w + (size_t)E * E, E, c.in_proj_b + E, nullptr, 0,
-                      buf.kvc[l], 2 * E, RS, 2 * E, E, 0, st));
+                      buf.kvc[l], 2 * E, RS, 2 * E, E, 0, main_st));
   }
-  FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * T, st));
-  FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * T, st));
-
-  // ---- start tokens and first decoder input rows -------------------------------------------------
-  for (const Chunk& c : chunks) {
-    hipLaunchKernelGGL(init_tokens_kernel, dim3(ff_cdiv(c.Bc, 256)), dim3(256), 0, st, c.tok, c.Bc, F, num_input,
-                       p->variant, m->num_token - 1, p->tok_sos, c.b0);
-    FF_CHECK_LAUNCH();
-    FF_RETURN_IF(ff_gather_rows(memory + (size_t)c.w0 * S * E, S, E, c.tok, c.Bc, F, c.x0, E, st));
+  FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * T, main_st));
+  FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * T, main_st));
+  // start tokens (anchors / SOS) for every sequence
+  hipLaunchKernelGGL(init_tokens_kernel, dim3(ff_cdiv(Btot, 256)), dim3(256), 0, main_st, buf.tok_all, Btot, F,
+                     num_input, p->variant, m->num_token - 1, p->tok_sos, 0);
+  FF_CHECK_LAUNCH();
+  if (ns > 1) {  // fork
+    FF_CHECK_HIP(hipEventRecord(g_pool.fork_ev, main_st));
+    for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], g_pool.fork_ev, 0));
   }
+  // first decoder input rows
+  for (const Chunk& c : chunks)
+    FF_RETURN_IF(ff_gather_rows(memory + (size_t)c.w0 * S * E, S, E, buf.tok_all + c.b0, c.Bc, c.Fc, c.x0, E,
+                                sts[c.sid]));
 
-  // ---- greedy loop ---------------------------------------------------------------------------------
+  auto sync_all = [&]() -> int {
+    for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamSynchronize(sts[s]));
+    return FF_OK;
+  };
+
+  // ---- greedy loop -----------------------------------------------------------------------------------
   const int max_steps = T - 1;
+  const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
+  const auto host_t0 = std::chrono::steady_clock::now();
   int enq = 0;
   std::vector<int> hcnt(T > 0 ? T : 1);
   bool stopped = false;
   for (int step = 0; step < max_steps && !stopped; ++step) {
     const int t = step + 1;
     for (const Chunk& c : chunks) {
-      FF_RETURN_IF(decoder_pass(m, p, buf, c, mask, kv_len, t, false, nullptr, st));
+      hipStream_t st = sts[c.sid];
+      const Scratch& sc = buf.scr[c.sid];
+      FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
       const size_t trow = (size_t)step * Btot + c.b0;
       FF_RETURN_IF(ff_pointer_argmax(
-          buf.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
-          extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, F, c.tok + (size_t)t * c.Bc,
-          trace_best ? trace_best + trow : nullptr, trace_second ? trace_second + trow : nullptr,
-          trace_logits ? trace_logits + trow * S : buf.logits, S, c.x0 + (size_t)t * c.Bc * E, E,
-          buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st));
+          sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
+          extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,
+          buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
+          trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
+          c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st));
     }
     enq = step + 1;
     if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
+      FF_RETURN_IF(sync_all());
       const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
-      FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, st));
-      FF_CHECK_HIP(hipStreamSynchronize(st));
+      FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+      FF_CHECK_HIP(hipStreamSynchronize(main_st));
       if (p->variant == FF_PARALLEL) {
         for (int s = 0; s < enq; ++s) if (hcnt[s] == 0) { stopped = true; break; }
       } else {
@@ -409,29 +480,43 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       }
     }
   }
+  if (dbg_timing) {
+    const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    FF_CHECK_HIP(hipStreamSynchronize(main_st));
+    const double tot_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks: %.2f ms; until GPU idle: %.2f ms\n", enq,
+            chunks.size(), host_ms, tot_ms);
+  }
+  if (ns > 1) {  // join
+    for (int s = 0; s < ns; ++s) {
+      FF_CHECK_HIP(hipEventRecord(g_pool.join_ev[s], sts[s]));
+      FF_CHECK_HIP(hipStreamWaitEvent(main_st, g_pool.join_ev[s], 0));
+    }
+  }
 
   hipLaunchKernelGGL(finalize_kernel, dim3(ff_cdiv(Btot * T, 256) < 1024 ? ff_cdiv(Btot * T, 256) : 1024),
-                     dim3(256), 0, st, buf.tok_all, buf.cnt_ge, buf.cnt_eq, p->variant, N, Btot, Bch, T, enq,
+                     dim3(256), 0, main_st, buf.tok_all, buf.cnt_ge, buf.cnt_eq, p->variant, N, Btot, T, enq,
                      (p->flags & FF_NO_STOP) ? 1 : 0, predict, buf.steps_dev);
   FF_CHECK_LAUNCH();
   int steps = 0;
-  FF_CHECK_HIP(hipMemcpyAsync(&steps, buf.steps_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  FF_CHECK_HIP(hipMemcpyAsync(&steps, buf.steps_dev, sizeof(int), hipMemcpyDeviceToHost, main_st));
   if (step_counts && enq > 0)
     FF_CHECK_HIP(hipMemcpyAsync(step_counts, (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
-                                sizeof(int) * enq, hipMemcpyDeviceToHost, st));
-  FF_CHECK_HIP(hipStreamSynchronize(st));
+                                sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+  FF_CHECK_HIP(hipStreamSynchronize(main_st));
   if (steps_done) *steps_done = steps;
 
   // ---- optional: project(decoder(...)) of every prefix row at the last executed step
   //      (SurfaceFormer returns it as inputs['pointer'], reference model.py:217) --------------------
   if ((p->flags & FF_RETURN_POINTER) && steps > 0) {
+    FF_CHECK_ARG(m->FF >= m->E, "ff_decode: FF_RETURN_POINTER needs FF >= E");
     for (const Chunk& c : chunks) {
-      float* proj_all = buf.h;  // [steps*Bc, E] fits in the FF-wide scratch (FF >= E on the path)
-      FF_CHECK_ARG(m->FF >= m->E, "ff_decode: FF_RETURN_POINTER needs FF >= E");
-      FF_RETURN_IF(decoder_pass(m, p, buf, c, mask, kv_len, steps, true, proj_all, st));
+      const Scratch& sc = buf.scr[0];
+      float* proj_all = sc.h;  // [steps*Bc, E] fits in the FF-wide scratch
+      FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, steps, true, proj_all, main_st));
       for (int j = 0; j < steps; ++j)
         FF_CHECK_HIP(hipMemcpyAsync(pointer_out + ((size_t)j * Btot + c.b0) * E, proj_all + (size_t)j * c.Bc * E,
-                                    sizeof(float) * c.Bc * E, hipMemcpyDeviceToDevice, st));
+                                    sizeof(float) * c.Bc * E, hipMemcpyDeviceToDevice, main_st));
     }
   }
   return FF_OK;

@@ -386,6 +386,38 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
     }
   };
 
+  // ---- epilogue operands first: bias and residual tile are fetched BEFORE the K loop (their
+  //      latency hides under it; the residual tile is only overwritten by this block, at the end) ----
+  float bv[NI];
+  int colc[NI];
+  float rv[MI][NI][16];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n0 + wn0 + ni * 32 + l32;
+    colc[ni] = col < g.N ? col : g.N - 1;
+    bv[ni] = g.bias ? g.bias[colc[ni]] : 0.f;
+  }
+  if (g.res) {
+    const float* rp = g.res + bz * g.batch_stride_c;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int row = m0 + wm0 + mi * 32 + 4 * half + (e & 3) + 8 * (e >> 2);
+          row = row < g.M ? row : g.M - 1;
+          rv[mi][ni][e] = rp[(size_t)row * g.ldr + colc[ni]];
+        }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[mi][ni][e] = 0.f;
+  }
+
   // ---- prologue ----
   load_into(ra[0], rw[0], 0);
   load_into(ra[1], rw[1], 1);
@@ -418,47 +450,17 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
     { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
   }
 
-  // ---- epilogue (same as gemm_f32_kernel) ----
-  float bv[NI];
-  int colc[NI];
+  // ---- epilogue: bias, activation, residual (already in registers), store ----
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int col = n0 + wn0 + ni * 32 + l32;
-    colc[ni] = col < g.N ? col : g.N - 1;
-    bv[ni] = g.bias ? g.bias[colc[ni]] : 0.f;
-  }
-  if (g.res) {
-    const float* rp = g.res + bz * g.batch_stride_c;
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        float rv[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          int row = m0 + wm0 + mi * 32 + 4 * half + (e & 3) + 8 * (e >> 2);
-          row = row < g.M ? row : g.M - 1;
-          rv[e] = rp[(size_t)row * g.ldr + colc[ni]];
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[mi][ni][e] + bv[ni];
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          acc[mi][ni][e] = v + rv[e];
-        }
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[mi][ni][e] + bv[ni];
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        acc[mi][ni][e] = v + rv[mi][ni][e];
       }
-  } else {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[mi][ni][e] + bv[ni];
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          acc[mi][ni][e] = v;
-        }
-  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

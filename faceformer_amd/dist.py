@@ -76,7 +76,8 @@ def decode_sharded(model, inputs, dist_mod, group=None):
         eng, memory, mask, kv_len = model._encode(sub)
         out = eng.decode(memory, mask, kv_len, variant, T=T, F=F,
                          num_input=num_input[lo:hi] if parallel else None,
-                         chunk_wireframes=model.chunk_wireframes, sync_every=0, flags=model.decode_flags,
+                         chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
+                         num_streams=model.num_streams, sync_every=0, flags=model.decode_flags,
                          tok_sos=model.token.SOS if not parallel else 1,
                          tok_eos=model.token.EOS if not parallel else 3, no_stop=True)
         local[: hi - lo] = out["predict"].view(hi - lo, F, T)

@@ -117,7 +117,8 @@ class PathEngine:
         return memory, kv_len
 
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
-               chunk_wireframes=0, sync_every=4, flags=DEFAULT_FLAGS, tok_sos=1, tok_eos=3,
+               chunk_wireframes=0, chunk_seqs=0, num_streams=1, sync_every=4, flags=DEFAULT_FLAGS,
+               tok_sos=1, tok_eos=3,
                trace=False, return_pointer=False, no_stop=False):
         """Greedy decode. Returns dict(predict [N*F, T] int64, steps, [pointer], [trace tensors])."""
         _dev(memory, "memory")
@@ -126,6 +127,7 @@ class PathEngine:
         prm = _L.DecodeParams()
         prm.variant, prm.N, prm.L, prm.F, prm.T = variant, N, L, F, T
         prm.chunk_wireframes, prm.sync_every = chunk_wireframes, sync_every
+        prm.chunk_seqs, prm.num_streams = chunk_seqs, num_streams
         prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0) | (_L.FF_NO_STOP if no_stop else 0)
         prm.tok_sos, prm.tok_eos = tok_sos, tok_eos
         B = N * F

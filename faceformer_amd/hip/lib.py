@@ -71,7 +71,8 @@ class Model(C.Structure):
 class DecodeParams(C.Structure):
     _fields_ = [
         ("variant", C.c_int), ("N", C.c_int), ("L", C.c_int), ("F", C.c_int), ("T", C.c_int),
-        ("chunk_wireframes", C.c_int), ("sync_every", C.c_int), ("flags", C.c_int),
+        ("chunk_wireframes", C.c_int), ("chunk_seqs", C.c_int), ("num_streams", C.c_int),
+        ("sync_every", C.c_int), ("flags", C.c_int),
         ("tok_sos", C.c_int), ("tok_eos", C.c_int),
     ]
 

@@ -46,6 +46,8 @@ class SurfaceFormerBase(nn.Module):
         # engine knobs (not part of the reference surface)
         self.decode_flags = DEFAULT_FLAGS
         self.chunk_wireframes = 0      # micro-batch size in wireframes (0 = whole batch)
+        self.chunk_seqs = 0            # >0: split every wireframe into groups of this many sequences
+        self.num_streams = 1           # micro-batches are issued round-robin on this many HIP streams
         self.sync_every = 4            # host evaluation period of the stop rule
         self._engine_obj = None
 

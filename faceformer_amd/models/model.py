@@ -36,7 +36,8 @@ class SurfaceFormer(SurfaceFormerBase):
                              "needed" % (label.size(1), T - 1))
         eng, memory, mask, kv_len = self._encode(inputs)
         out = eng.decode(memory, mask, kv_len, _L.FF_SEQ2SEQ, T=T, F=1,
-                         chunk_wireframes=self.chunk_wireframes, sync_every=1,
+                         chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
+                         num_streams=self.num_streams, sync_every=1,
                          flags=self.decode_flags, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
                          return_pointer=True)
         inputs["embedding"] = memory

@@ -44,7 +44,8 @@ class SurfaceFormer_Parallel(SurfaceFormerBase):
         if len(num_input) != memory.size(0):
             raise ValueError("num_input has %d entries for a batch of %d" % (len(num_input), memory.size(0)))
         out = eng.decode(memory, mask, kv_len, _L.FF_PARALLEL, T=T, F=F, num_input=num_input,
-                         chunk_wireframes=self.chunk_wireframes, sync_every=self.sync_every,
+                         chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
+                         num_streams=self.num_streams, sync_every=self.sync_every,
                          flags=self.decode_flags)
         inputs["predict"] = out["predict"].view(-1, F, T)
         return inputs

@@ -230,6 +230,10 @@ typedef struct ff_decode_params {
   int F;                /* sequences per wireframe: max(num_input) (parallel) or 1 (seq2seq) */
   int T;                /* max_face_length / label_seq_length; at most T-1 decode steps */
   int chunk_wireframes; /* wireframes per micro-batch (<=0: all) */
+  int chunk_seqs;       /* >0 and < F: additionally split every wireframe into groups of this many
+                           sequences (sequences are independent; groups decode concurrently) */
+  int num_streams;      /* micro-batches are issued round-robin on this many HIP streams (internal
+                           pool, forked from / joined into `stream`); <=1: everything on `stream` */
   int sync_every;       /* evaluate the stop rule on the host every k steps (<=0: only at the end) */
   int flags;            /* ff_decode_flags */
   int tok_sos, tok_eos; /* seq2seq start / stop tokens */

@@ -38,7 +38,8 @@ def run_traced(model, case, batch):
         ni = [int(n) for n in batch["num_input"]]
         out = eng.decode(memory, mask, kv_len, L.FF_PARALLEL, T=T, F=max(ni), num_input=ni, trace=True,
                          sync_every=model.sync_every, flags=model.decode_flags,
-                         chunk_wireframes=model.chunk_wireframes)
+                         chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
+                         num_streams=model.num_streams)
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          flags=model.decode_flags, return_pointer=True,
@@ -102,13 +103,17 @@ def test_golden_parity(hip_lib, name):
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak",
                                   "par_full_n40_gain4", "seq_small_gain4", "seq_small_eos"])
-@pytest.mark.parametrize("flags,chunk,sync", [(0, 0, 1), (3, 0, 0), (3, 1, 3), (1, 2, 1), (2, 1, 0)])
-def test_engine_options_do_not_change_results(hip_lib, name, flags, chunk, sync):
-    """Pruning flags, micro-batching and the host sync period are pure scheduling choices."""
+@pytest.mark.parametrize("flags,chunk,sync,cseq,nstr", [(0, 0, 1, 0, 1), (3, 0, 0, 0, 1), (3, 1, 3, 0, 2),
+                                                        (1, 2, 1, 0, 3), (2, 1, 0, 0, 1), (3, 0, 2, 5, 4),
+                                                        (3, 0, 0, 7, 2), (0, 0, 1, 3, 8)])
+def test_engine_options_do_not_change_results(hip_lib, name, flags, chunk, sync, cseq, nstr):
+    """Pruning flags, micro-batching (by wireframe or by sequence group), concurrent streams and the
+    host sync period are pure scheduling choices."""
     case, z = load_golden(name)
     sd, batch = case_weights_and_batch(case)
     model = build_model(case, sd, "cuda")
     model.decode_flags, model.chunk_wireframes, model.sync_every = flags, chunk, sync
+    model.chunk_seqs, model.num_streams = cseq, nstr
     out = run_traced(model, case, batch_to(batch, "cuda"))
     compare_with_golden(case, z, out)
 
