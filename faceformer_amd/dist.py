@@ -88,3 +88,65 @@ def decode_sharded(model, inputs, dist_mod, group=None):
     full, _ = apply_global_stop(full, counts[: T - 1].tolist(), N, variant)
     inputs["predict"] = full if parallel else full.view(N, T)
     return inputs
+
+
+# ---- predicted face-loop JSON over the wire ---------------------------------------------------------
+def gather_json_records(records, dist_mod, group=None, device=None):
+    """All-gather variable-length JSON strings: every rank passes the list of records it owns (in
+    wireframe order) and receives the concatenation over ranks in rank order.  Wire format: per rank a
+    uint8 buffer of [u32 little-endian length | utf-8 bytes]* padded to the longest rank (two
+    collectives: sizes, then one `all_gather_into_tensor` of the padded payload over RCCL/gloo)."""
+    import struct
+    world = dist_mod.get_world_size(group)
+    blob = b"".join(struct.pack("<I", len(b)) + b for b in (r.encode("utf-8") for r in records))
+    dev = device if device is not None else torch.device("cpu")
+    size = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist_mod.all_gather_into_tensor(sizes, size, group=group)
+    sizes = sizes.tolist()
+    width = max(max(sizes), 1)
+    send = torch.zeros(width, dtype=torch.uint8, device=dev)
+    if blob:
+        send[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    recv = torch.empty(world * width, dtype=torch.uint8, device=dev)
+    dist_mod.all_gather_into_tensor(recv, send, group=group)
+    raw = recv.cpu().numpy().tobytes()
+    out = []
+    for r in range(world):
+        buf, pos = raw[r * width: r * width + sizes[r]], 0
+        while pos < len(buf):
+            (n,) = struct.unpack_from("<I", buf, pos)
+            out.append(buf[pos + 4: pos + 4 + n].decode("utf-8"))
+            pos += 4 + n
+    return out
+
+
+def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominant_directions=None,
+                        pairings=None, is_coedge=False, tol=2e-4):
+    """decode_sharded + face parsing of the rank's own wireframes + JSON all-gather: every rank returns
+    the list of N per-wireframe JSON records (`edges`, `dominant_directions`, `pred_faces`,
+    `label_faces`; reference trainer.py:118-136).  `edges[i]` / `dominant_directions[i]` / `pairings[i]`
+    are the raw-data entries of wireframe i when available (else the record carries empty lists)."""
+    from . import faces as FZ
+    from .models import SurfaceFormer_Parallel
+    out = decode_sharded(model, inputs, dist_mod, group)
+    rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
+    N = inputs["input"].size(0)
+    lo, hi, _ = shard_range(N, rank, world)
+    parallel = isinstance(model, SurfaceFormer_Parallel)
+    pred = out["predict"][lo:hi].cpu().numpy()
+    labels = inputs["label"][lo:hi].cpu().numpy()
+    recs = []
+    for k, i in enumerate(range(lo, hi)):
+        n = int(inputs["num_input"][i]) if "num_input" in inputs else int((~inputs["input_mask"][i]).sum())
+        fn = FZ.parse_parallel_faces if parallel else FZ.parse_faces
+        pf, lf = fn(pred[k], labels[k], n, model.token)
+        if is_coedge and edges is not None:
+            pf = FZ.postprocess_faces(pf, edges[i], pairings[i] if pairings else {}, tol)
+            lf = FZ.postprocess_faces(lf, edges[i], pairings[i] if pairings else {}, tol)
+        m = FZ.face_metrics(pf, lf)
+        recs.append(FZ.dumps_record(FZ.faces_record(
+            edges[i] if edges is not None else [], dominant_directions[i] if dominant_directions is not None else [],
+            m["predictions"], m["labels"])))
+    dev = out["predict"].device if dist_mod.get_backend(group) == "nccl" else torch.device("cpu")
+    return gather_json_records(recs, dist_mod, group, device=dev)

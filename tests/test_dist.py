@@ -60,6 +60,15 @@ def _worker(rank, world, port, name, ret):
     model._encode = lambda sub: (eng, (lo, hi), None, None)   # carries the shard range to the stand-in
     out = ffd.decode_sharded(model, dict(batch), dist)
     ok = np.array_equal(out["predict"].numpy(), z["predict"])
+    # face-loop JSON of every wireframe on every rank (parsed locally, gathered as bytes)
+    import json
+    from faceformer_amd import faces as FZ
+    recs = ffd.decode_to_face_json(model, dict(batch), dist)
+    ok = ok and len(recs) == batch["input"].size(0)
+    for i, r in enumerate(recs):
+        pf, _ = FZ.parse_parallel_faces(z["predict"][i], batch["label"][i].numpy(), batch["num_input"][i], token_ns())
+        want = [[t, list(f)] for t, f in FZ.unique_faces_with_majority_type(pf)]
+        ok = ok and json.loads(r)["pred_faces"] == want
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -77,6 +86,31 @@ def test_sharded_decode_equals_single_process_gloo(name):
         p.join(180)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True}
+
+
+def _json_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from faceformer_amd import dist as ffd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    mine = [["a" * 5, "{\"k\": [1, 2]}"], [], ["\u00e9" * 300]][rank]
+    got = ffd.gather_json_records(mine, dist)
+    ret[rank] = got == ["a" * 5, "{\"k\": [1, 2]}", "\u00e9" * 300]
+    dist.destroy_process_group()
+
+
+def test_gather_json_records_ragged_gloo():
+    world = 3
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_json_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True, 2: True}
 
 
 def test_shard_range_and_global_stop():

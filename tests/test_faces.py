@@ -1,0 +1,96 @@
+"""CPU: face parsing / post-processing / JSON record against input-output pairs
+captured from the imported reference (oracle/make_golden_faces.py)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, token_ns
+from faceformer_amd import faces as F
+
+
+@pytest.fixture(scope="module")
+def cases():
+    with open(os.path.join(GOLDEN, "faces_cases.json")) as f:
+        return json.load(f)
+
+
+def as_faces(x):
+    return [(int(t), tuple(int(i) for i in idx)) for t, idx in x]
+
+
+def test_parse_parallel_faces_matches_reference(cases):
+    tok = token_ns()
+    assert len(cases["parallel"]) >= 10
+    for c in cases["parallel"]:
+        pred, lab = np.asarray(c["predicts"]), np.asarray(c["labels"])
+        p0, l0 = pred.copy(), lab.copy()
+        pf, lf = F.parse_parallel_faces(pred, lab, c["num_edges"], tok)
+        assert pf == as_faces(c["pred_faces"])
+        assert lf == as_faces(c["label_faces"])
+        assert np.array_equal(pred, p0) and np.array_equal(lab, l0)   # inputs are not mutated
+
+
+def test_parse_faces_matches_reference(cases):
+    tok = token_ns()
+    for c in cases["seq"]:
+        pf, lf = F.parse_faces(np.asarray(c["predicts"]), np.asarray(c["labels"]), c["num_edges"], tok)
+        assert pf == as_faces(c["pred_faces"])
+        assert lf == as_faces(c["label_faces"])
+
+
+def test_token_namespace_variants():
+    """token may be a namespace, a CfgNode or a dict."""
+    from faceformer_amd.config import load_cfg
+    cfg = load_cfg("")
+    rows = np.array([[5, 6, 2, 9], [4, 4, 4, 4], [3, 0, 0, 0]])
+    a = F.parse_parallel_faces(rows, rows, 10, token_ns())
+    b = F.parse_parallel_faces(rows, rows, 10, cfg.model.token)
+    c = F.parse_parallel_faces(rows, rows, 10, dict(cfg.model.token))
+    assert a == b == c
+    assert a[0] == [(1, (1, 2)), (3, (0, 0, 0, 0))]   # unterminated row: type = last token - offset
+
+
+def test_is_face_enclosed_and_filter_match_reference(cases):
+    for c in cases["enclosed"]:
+        got = F.is_face_enclosed(c["edges"], c["face"], c["tol"])
+        want = c["result"]
+        assert (got is False and want is False) or [list(lp) for lp in got] == want
+    for c in cases["filter"]:
+        faces = [(t, tuple(f)) for t, f in c["faces"]]
+        got = F.filter_faces_by_encloseness(c["edges"], faces, c["tol"])
+        want = [(t, tuple(tuple(lp) for lp in loops)) for t, loops in c["result"]]
+        assert got == want
+        assert len(got) >= 1
+    for c in cases["coedge"]:
+        assert F.map_coedge_into_edges(c["pairings"], c["indices"]) == c["result"]
+
+
+def test_oriented_edges_and_coedge_filter():
+    edges = [[[0, 0], [1, 0]], [[1, 1], [1, 0]], [[1, 1], [0, 0]]]
+    assert F.is_face_enclosed(edges, [(0, 0), (1, 1), (2, 0)], 1e-6) == [[(0, 0), (1, 1), (2, 0)]]
+    assert F.is_face_enclosed(edges, [0, 1, 2], 1e-6) is False
+    faces = [(0, ((0, 1, 2),)), (1, ((3, 4),)), (0, ((5,),))]
+    kept = F.filter_faces_by_coedge({3: 0, 5: 9}, faces)
+    assert kept == [faces[0], faces[2]]       # face 1 reuses edge 0 through its co-edge 3
+
+
+def test_metrics_majority_vote_and_json_roundtrip():
+    pred = [(0, (3, 1, 2)), (1, (1, 2, 3)), (1, (2, 3, 1)), (2, (7, 8))]
+    lab = [(1, (1, 2, 3)), (0, (4, 5, 6))]
+    m = F.face_metrics(pred, lab)
+    assert m["predictions"] == [(1, (1, 2, 3)), (2, (7, 8))]
+    assert m["precision"] == 0.5 and m["recall"] == 0.5 and m["type_acc"] == 1.0
+    assert F.face_metrics([], lab)["precision"] == 0
+    rec = F.faces_record(np.zeros((2, 2, 2)), [[1.0, 0.0]], m["predictions"], m["labels"])
+    back = json.loads(F.dumps_record(rec))
+    assert set(back) == {"edges", "dominant_directions", "pred_faces", "label_faces"}
+    assert back["pred_faces"] == [[1, [1, 2, 3]], [2, [7, 8]]]
+
+
+def test_postprocess_pipeline():
+    sq = [[[0, 0], [1, 0]], [[1, 0], [1, 1]], [[1, 1], [0, 1]], [[0, 1], [0, 0]]]
+    out = F.postprocess_faces([(0, (2, 3, 0, 1)), (1, (0, 1))], sq, {"3": 7}, 2e-4)
+    assert out == [(0, [0, 1, 2, 7])]
