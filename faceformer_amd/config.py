@@ -48,7 +48,7 @@ class CfgNode(dict):
         self[name] = value
 
     def __setitem__(self, key, value):
-        if object.__getattribute__(self, CfgNode._FROZEN):
+        if self.is_frozen():
             raise AttributeError("CfgNode is immutable (frozen); cannot set '{}'".format(key))
         super().__setitem__(key, value)
 
@@ -74,7 +74,9 @@ class CfgNode(dict):
 
     # -- freeze ------------------------------------------------------------------------------
     def is_frozen(self):
-        return object.__getattribute__(self, CfgNode._FROZEN)
+        # instances revived by a foreign pickle (dict-subclass protocol: __new__ + SETITEMS, no
+        # __init__) have no flag yet: they count as mutable
+        return self.__dict__.get(CfgNode._FROZEN, False)
 
     def _set_frozen(self, flag):
         object.__setattr__(self, CfgNode._FROZEN, flag)

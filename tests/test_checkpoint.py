@@ -1,0 +1,60 @@
+"""CPU: Lightning-style checkpoint loader on a synthetic checkpoint whose
+hyper-parameters are pickled as `fvcore.common.config.CfgNode` -- a package that is NOT installed."""
+import sys
+import types
+
+import pytest
+import torch
+
+from conftest import token_ns
+
+
+def _write_fake_ckpt(path, model, cfg_dict):
+    mod_a, mod_b, mod_c = types.ModuleType("fvcore"), types.ModuleType("fvcore.common"), types.ModuleType("fvcore.common.config")
+
+    class CfgNode(dict):
+        pass
+    CfgNode.__module__, CfgNode.__qualname__ = "fvcore.common.config", "CfgNode"
+    mod_c.CfgNode = CfgNode
+    pl_mod = types.ModuleType("pytorch_lightning_fake_callbacks")
+
+    class ModelCheckpoint:
+        def __init__(self):
+            self.best = 0.5
+    ModelCheckpoint.__module__, ModelCheckpoint.__qualname__ = "pytorch_lightning_fake_callbacks", "ModelCheckpoint"
+    pl_mod.ModelCheckpoint = ModelCheckpoint
+    sys.modules.update({"fvcore": mod_a, "fvcore.common": mod_b, "fvcore.common.config": mod_c,
+                        "pytorch_lightning_fake_callbacks": pl_mod})
+    try:
+        def to_node(d):
+            return CfgNode({k: to_node(v) if isinstance(v, dict) else v for k, v in d.items()})
+        ckpt = {"epoch": 3, "state_dict": {"model." + k: v for k, v in model.state_dict().items()},
+                "hyper_parameters": to_node(cfg_dict), "callbacks": {"ckpt": ModelCheckpoint()}}
+        torch.save(ckpt, path)
+    finally:
+        for k in ("fvcore", "fvcore.common", "fvcore.common.config", "pytorch_lightning_fake_callbacks"):
+            sys.modules.pop(k, None)
+
+
+def test_load_checkpoint_without_fvcore(tmp_path):
+    from faceformer_amd.checkpoint import load_lightning_checkpoint, model_from_checkpoint
+    from faceformer_amd.config import CfgNode
+    from faceformer_amd.models import SurfaceFormer_Parallel
+    tok = dict(PAD=0, SOS=1, SEP=2, EOS=3, DIR0=4, DIR1=5, len=4, face_type_offset=1)
+    mcfg = dict(num_model=128, num_head=2, num_feedforward=256, num_encoder_layers=1, num_decoder_layers=2,
+                dropout=0.2, num_points_per_line=50, num_lines=12, point_dim=2, max_face_length=6,
+                max_num_faces=42, label_seq_length=20, token=tok)
+    model = SurfaceFormer_Parallel(**{**mcfg, "token": token_ns()})
+    path = str(tmp_path / "last.ckpt")
+    _write_fake_ckpt(path, model, {"model_class": "SurfaceFormer_Parallel", "root_dir": "/stale/path", "model": mcfg})
+    assert "fvcore" not in sys.modules
+    sd, hp = load_lightning_checkpoint(path)
+    assert isinstance(hp, CfgNode) and hp.model.token.len == 4 and hp["root_dir"] == "/stale/path"
+    assert set(sd) == set(model.state_dict()) and not any(k.startswith("model.") for k in sd)
+    m2 = model_from_checkpoint(path)
+    assert isinstance(m2, SurfaceFormer_Parallel) and not m2.training
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+    torch.save({"foo": 1}, str(tmp_path / "bad.ckpt"))
+    with pytest.raises(ValueError):
+        load_lightning_checkpoint(str(tmp_path / "bad.ckpt"))

@@ -9,6 +9,8 @@ Token equality is REQUIRED wherever the reference's own top-2 margin exceeds tha
 different fp32 summation order may legitimately flip an exact or near tie); once a sequence has taken
 a different (tied) branch its later tokens are no longer comparable and are skipped.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -191,3 +193,49 @@ def test_sharded_equals_single(hip_lib, name):
         if created:
             dist.destroy_process_group()
     assert np.array_equal(out["predict"].cpu().numpy(), z["predict"])
+
+
+def test_cli_decode_writes_reference_json(hip_lib, tmp_path):
+    """main.py test branch end to end on the GPU: synthetic Lightning checkpoint + wireframe JSONs ->
+    per-sample JSON records whose faces equal the oracle's parsed faces."""
+    import json
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    import main as cli
+    from faceformer_amd import faces as FZ
+    from faceformer_amd.config import load_cfg
+    from faceformer_amd.models import SurfaceFormer_Parallel
+    from faceformer_amd.synth import make_state_dict, state_dict_spec
+    from conftest import token_ns
+    from oracle import refpath
+    root = tmp_path / "data"
+    (root / "json").mkdir(parents=True)
+    rng = np.random.default_rng(5)
+    names = []
+    for i in range(2):
+        n = 9 + i
+        raw = {"edges": [rng.uniform(-1, 1, size=(2, 2)).tolist() for _ in range(n)],
+               "faces_indices": [[0, [[0, 1, 2]]], [1, [[3, 4, 5, 6]]]], "pairings": {}, "dominant_directions": [[1, 0, 0]]}
+        json.dump(raw, open(root / "json" / ("%08d.json" % i), "w"))
+        names.append("json/%08d.json" % i)
+    open(root / "test.txt", "w").write("\n".join(names) + "\n")
+    cfg = load_cfg("configs/ours.yml", ["model.num_lines", "16", "model.max_face_length", "8", "model.num_model", "128",
+                                         "model.num_head", "2", "model.num_feedforward", "256",
+                                         "model.num_encoder_layers", "2", "model.num_decoder_layers", "2",
+                                         "root_dir", str(root), "post_process.is_coedge", "False"])
+    spec = state_dict_spec("parallel", 16, 8, 128, 256, 2, 2)
+    sd = make_state_dict(spec, "gain4", 3)
+    ckpt = tmp_path / "last.ckpt"
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "hyper_parameters": dict(cfg)}, ckpt)
+    out_dir = cli.run_test(cfg, str(ckpt), out_dir=str(tmp_path / "out"))
+    from faceformer_amd import datasets as D
+    ds = D.ABCDataset_Parallel(str(root), ["test.txt"], cfg.model)
+    for i in range(2):
+        rec = json.load(open(os.path.join(out_dir, "%08d.json" % i)))
+        assert set(rec) == {"edges", "dominant_directions", "pred_faces", "label_faces"}
+        batch = D.collate([ds[i]])
+        ref = refpath.parallel_forward_eval(sd, batch, num_head=2)
+        pf, lf = FZ.parse_parallel_faces(ref["predict"][0].numpy(), ds[i]["label"], len(ds.raw_datas[i]["edges"]), token_ns())
+        m = FZ.face_metrics(pf, lf)
+        assert rec["pred_faces"] == [[t, list(f)] for t, f in m["predictions"]]
+        assert sorted(map(tuple, map(lambda x: (x[0], tuple(x[1])), rec["label_faces"]))) == sorted(m["labels"])
