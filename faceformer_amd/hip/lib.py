@@ -117,6 +117,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # Load order matters inside a torch process: torch ships its own libamdhip64 (same SONAME as the
+    # system ROCm one this library is linked against).  Importing torch first makes the dynamic loader
+    # resolve our HIP calls to the runtime torch already initialised -- two runtimes in one process
+    # cannot see each other's devices or streams.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise HipExtensionError(
             "HIP extension not built: %s is missing. Run `python -m faceformer_amd.hip.build` "
