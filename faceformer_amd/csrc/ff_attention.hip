@@ -20,6 +20,10 @@
 
 namespace {
 
+// 2^x on the transcendental unit (v_exp_f32) without the subnormal-range fix-up of exp2f: softmax
+// terms below 2^-126 are irrelevant next to a maximum term of 1.
+__device__ __forceinline__ float ff_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 constexpr int KC = 64;     // keys per LDS chunk
 constexpr int K_LD = 68;   // padded K row (floats)
 constexpr int V_LD = 64;
@@ -158,18 +162,20 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
       const float m_new = fmaxf(m_run, tmax);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m_run - m_safe);
+      const float alpha = ff_exp2(m_run - m_safe);
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[r] - m_safe);
+        const float p = ff_exp2(s[r] - m_safe);
         s[r] = p;
         psum += p;
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;
+      if (!__all(alpha == 1.0f)) {  // the running max moved for some query of this wave
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+      }
       // ---- O^T += V^T P^T ----
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -247,7 +253,214 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
   }
 }
 
+// ---- wave-independent variant ------------------------------------------------------------------------
+// No block barrier and no shared staging: every wave owns one unit = (32 queries of one (group, head)) x
+// (every ks-th 32-key tile).  K tiles go through a wave-private LDS patch (coalesced row loads in,
+// MFMA-fragment ds_read_b128 out; LDS operations of one wave are ordered, so only a compiler fence
+// sits between them), V fragments are loaded straight into registers (each load instruction reads two
+// full 128-byte row segments), the next K tile is prefetched into registers under the MFMA chains.
+// With ks > 1 the ks waves that share the queries combine their (max, sum, O) through LDS at the end --
+// the launch then has ks x more independent units, which is what the small-t steps of the decode
+// need (a (wireframe, head) pair offers only F*t/32 query tiles; at t = 1 that is 64 units on 1024 SIMDs).
+template <int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_desc d, int q_tiles, int ks,
+                                                                      long total_units) {
+  constexpr int PATCH = 32 * K_LD;  // 2176 floats per wave: K tile, later the combine record
+  __shared__ __attribute__((aligned(16))) float lds[NWAVES * PATCH + NWAVES * 32];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  float* Kw = lds + wave * PATCH;
+  float* Mw = lds + NWAVES * PATCH + wave * 32;
+
+  const int units_per_block = NWAVES / ks;
+  const long unit = (long)blockIdx.x * units_per_block + wave / ks;
+  const int kg = wave % ks;
+  const bool unit_valid = unit < total_units;
+  const long uc = unit_valid ? unit : total_units - 1;
+  const int qt = (int)(uc % q_tiles);
+  const int gh_i = (int)(uc / q_tiles);
+  const int g = gh_i / d.num_heads, h = gh_i % d.num_heads;
+
+  const int qi = qt * 32 + l32;
+  const bool q_valid = unit_valid && qi < d.nq;
+  const int qc = qi < d.nq ? qi : d.nq - 1;
+  const size_t qrow = (size_t)g * d.q_group_stride + (size_t)(qc / d.q_inner) * d.q_outer_stride +
+                      (size_t)(qc % d.q_inner);
+  const float qscale = d.scale * 1.4426950408889634f;
+  float qreg[32];
+  {
+    const float* qp = d.q + qrow * d.ldq + h * FF_HEAD_DIM + half * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(qp + c * 4);
+      qreg[c * 4 + 0] = t.x * qscale;
+      qreg[c * 4 + 1] = t.y * qscale;
+      qreg[c * 4 + 2] = t.z * qscale;
+      qreg[c * 4 + 3] = t.w * qscale;
+    }
+  }
+  int nk = d.nk;
+  if (d.kv_len) {
+    const int kl = d.kv_len[g];
+    nk = kl < nk ? kl : nk;
+  }
+  const int ntiles = (nk + 31) >> 5;
+  const float* kbase = d.k + (size_t)g * d.k_group_stride * d.ldk + h * FF_HEAD_DIM;
+  const float* vbase = d.v + (size_t)g * d.k_group_stride * d.ldv + h * FF_HEAD_DIM;
+  const unsigned char* mrow = d.key_mask ? d.key_mask + (size_t)g * d.mask_stride : nullptr;
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+
+  // K staging: lane -> (row = lane/16 + 4p, 16-byte column lane%16): 4 full 256-byte rows per instruction
+  const int srow = lane >> 4, sc4 = lane & 15;
+  f32x4 kst[8];
+  auto load_k = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int key = kt * 32 + srow + 4 * p;
+      const int kc = key < nk ? key : (nk > 0 ? nk - 1 : 0);
+      f32x4 v = *reinterpret_cast<const f32x4*>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
+      kst[p] = key < nk ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto wave_fence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  int kt = kg;
+  if (kt < ntiles) load_k(kt);
+  for (; kt < ntiles; kt += ks) {
+    // ---- K tile: registers -> private LDS patch -> MFMA fragments ----
+#pragma unroll
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(Kw + (srow + 4 * p) * K_LD + sc4 * 4) = kst[p];
+    if (mrow) {
+      if (lane < 32) {
+        const int key = kt * 32 + lane;
+        Mw[lane] = (key < nk && mrow[key] == 0) ? 0.f : -INFINITY;
+      }
+    }
+    wave_fence();
+    f32x4 kf[8];
+#pragma unroll
+    for (int cg = 0; cg < 8; ++cg) kf[cg] = *reinterpret_cast<const f32x4*>(Kw + l32 * K_LD + half * 32 + cg * 4);
+    wave_fence();  // fragments are in registers: the K patch may be overwritten (Mw stays valid)
+    // ---- V fragments of this tile straight to registers; next K tile in flight ----
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int kc = key < nk ? key : (nk > 0 ? nk - 1 : 0);
+      const float* vp = vbase + (size_t)kc * d.k_stride * d.ldv + l32;
+      const float a = vp[0], b = vp[32];
+      v0[r] = key < nk ? a : 0.f;
+      v1[r] = key < nk ? b : 0.f;
+    }
+    if (kt + ks < ntiles) load_k(kt + ks);
+    // ---- S^T tile ----
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int cg = 0; cg < 8; ++cg) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].x, qreg[cg * 4 + 0], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].y, qreg[cg * 4 + 1], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].z, qreg[cg * 4 + 2], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].w, qreg[cg * 4 + 3], s, 0, 0, 0);
+    }
+    // ---- online softmax ----
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int keyl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int key = kt * 32 + keyl;
+      float mv = mrow ? Mw[keyl] : ((key < nk) ? 0.f : -INFINITY);
+      if (d.causal && key > qi) mv = -INFINITY;
+      const float v = s[r] + mv;
+      s[r] = v;
+      tmax = fmaxf(tmax, v);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = ff_exp2(m_run - m_safe);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = ff_exp2(s[r] - m_safe);
+      s[r] = p;
+      psum += p;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {  // the running max moved for some query of this wave
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
+    }
+  }
+
+  if (ks > 1) {
+    // ---- combine the ks key groups of a unit through LDS (record: O[32 regs][64 lanes], m, l) ----
+    wave_fence();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { Kw[e * 64 + lane] = o0[e]; Kw[(16 + e) * 64 + lane] = o1[e]; }
+    Kw[32 * 64 + lane] = m_run;   // 2048 + 64 + 64 = 2176 = PATCH exactly
+    Kw[33 * 64 + lane] = l_run;
+    __syncthreads();
+    if (kg != 0) return;
+    float m_star = m_run;
+    for (int j = 1; j < ks; ++j) m_star = fmaxf(m_star, lds[(wave + j) * PATCH + 32 * 64 + lane]);
+    const float ms = (m_star == -INFINITY) ? 0.f : m_star;
+    const float sc0 = ff_exp2(m_run - ms);
+    l_run *= sc0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] *= sc0; o1[e] *= sc0; }
+    for (int j = 1; j < ks; ++j) {
+      const float* rec = lds + (wave + j) * PATCH;
+      const float scj = ff_exp2(rec[32 * 64 + lane] - ms);
+      l_run += rec[33 * 64 + lane] * scj;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        o0[e] += rec[e * 64 + lane] * scj;
+        o1[e] += rec[(16 + e) * 64 + lane] * scj;
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, FF_WAVE);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q_valid) {
+    float* op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 a = {o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv, o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv};
+      f32x4 b = {o1[g4 * 4 + 0] * inv, o1[g4 * 4 + 1] * inv, o1[g4 * 4 + 2] * inv, o1[g4 * 4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
+      *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = b;
+    }
+  }
+}
+
+int g_attention_algo = 0;  // 0 = automatic, 1 = block-shared LDS staging, 2 = wave-independent
+
 }  // namespace
+
+extern "C" int ff_set_attention_algo(int algo) {
+  const int old = g_attention_algo;
+  g_attention_algo = algo;
+  return old;
+}
 
 extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   FF_CHECK_ARG(desc != nullptr, "ff_attention: null descriptor");
@@ -269,6 +482,25 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   const long blocks = gh * q_tiles;
   FF_CHECK_ARG(blocks < 2147483647L, "ff_attention: grid too large");
   FFProfScope prof(FF_CAT_ATTN, 4.0 * FF_HEAD_DIM * (double)gh * d.nq * d.nk, st);
+  // automatic: the wave-independent kernel (with key splitting) wins while the launch cannot fill the
+  // chip (measured crossover on MI355X: ~1500 units of 32 queries); above that the block-shared LDS
+  // staging moves 4x fewer bytes from L2 and is faster.
+  const bool use_wave = g_attention_algo == 2 ||
+                        (g_attention_algo == 0 && gh * ff_cdiv(d.nq, 32) < 1536);
+  if (use_wave) {
+    // wave-independent kernel: units = (group, head, 32-query tile); split the key tiles over ks waves
+    // when the launch would otherwise leave SIMDs idle (ks | 4, at most one key tile per wave).
+    const int qt = ff_cdiv(d.nq, 32);
+    const long units = gh * qt;
+    const int key_tiles = ff_cdiv(d.nk, 32);
+    int ks = 1;
+    while (ks < 4 && units * ks < 2048 && key_tiles >= 2 * ks) ks *= 2;
+    const long nblocks = (units + (4 / ks) - 1) / (4 / ks);
+    FF_CHECK_ARG(nblocks < 2147483647L, "ff_attention: grid too large");
+    hipLaunchKernelGGL((attention_wave_kernel<4>), dim3((unsigned)nblocks), dim3(256), 0, st, d, qt, ks, units);
+    FF_CHECK_LAUNCH();
+    return FF_OK;
+  }
   if (nw == 4)
     hipLaunchKernelGGL((attention_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, st, d, q_tiles);
   else if (nw == 2)

@@ -492,6 +492,213 @@ int launch_pipe(GemmArgs g, int batch, hipStream_t st) {
   return FF_OK;
 }
 
+// ---- persistent variant of the pipelined 64x64 kernel --------------------------------------------
+// A fixed grid of blocks (2 per CU) walks the tile list; the software pipeline of gemm_pipe_kernel
+// (3-buffer LDS ring, fragment prefetch, staging registers 2 slices ahead, MFMA-interleaved issue) runs
+// over the FLAT sequence of (tile, K-slice) pairs, so the global loads of the next tile's first slices
+// are already in flight while the current tile finishes: no pipeline fill/drain (an HBM round trip plus
+// the store tail, ~9k cycles) per tile, only per block.  Bias and residual of a tile are fetched when
+// its first slice is computed and consumed after its last one.  Requires K % 32 == 0 and K >= 128.
+__global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total_tiles) {
+  constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4, RPP = 32, KF = BK / 8;
+  constexpr int BUF_FLOATS = (BM + BN) * LDS_LD;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  const int c4 = tid & 7, r = tid >> 3;
+  const int nsl = g.K / BK;
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+
+  // ---- this block's tile list: XCD x = blockIdx % 8 owns a contiguous range of logical tiles ----
+  const int G = gridDim.x;
+  int first, stride, limit;
+  if ((G & 7) == 0) {
+    const int x = blockIdx.x & 7, q = total_tiles >> 3, rem = total_tiles & 7;
+    const int lo = (x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q;
+    limit = lo + q + (x < rem ? 1 : 0);
+    first = lo + (blockIdx.x >> 3);
+    stride = G >> 3;
+  } else {
+    first = blockIdx.x; stride = G; limit = total_tiles;
+  }
+  if (first >= limit) return;
+  const int my_tiles = (limit - first + stride - 1) / stride;
+
+  // ---- load cursor (runs 4 slices ahead of the MFMA chain, crosses tile boundaries early) ----
+  const float* a_ptr[2];
+  const float* w_ptr[2];
+  auto set_load_tile = [&](int k) {
+    const int id = first + (k < my_tiles ? k : my_tiles - 1) * stride;
+    const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
+    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
+    const float* Asrc = ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + (long long)bz * g.batch_stride_a;
+    const float* W = g.W + (long long)bz * g.batch_stride_w;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int row = m0 + r + RPP * p;
+      row = row < g.M ? row : g.M - 1;
+      a_ptr[p] = Asrc + (size_t)row * g.lda + c4 * 4;
+      int n = n0 + r + RPP * p;
+      n = n < g.N ? n : g.N - 1;
+      w_ptr[p] = W + (size_t)n * g.ldw + c4 * 4;
+    }
+  };
+  int ld_k = 0, ld_j = 0;
+  set_load_tile(0);
+  f32x4 ra[2][2], rw[2][2];
+  auto load_next = [&](f32x4* xa, f32x4* xw) {  // loads slice (ld_k, ld_j); branch-free
+    const int k0 = ld_j * BK;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      xa[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + k0);
+      xw[p] = *reinterpret_cast<const f32x4*>(w_ptr[p] + k0);
+    }
+  };
+  auto advance = [&]() {  // block-uniform; past the last tile the cursor stays on the last slice
+    if (++ld_j == nsl) {
+      if (ld_k + 1 < my_tiles) { ld_j = 0; ++ld_k; set_load_tile(ld_k); }
+      else ld_j = nsl - 1;
+    }
+  };
+  float* const st_a = lds + r * LDS_LD + c4 * 4;
+  float* const st_w = st_a + BM * LDS_LD;
+  auto store_from = [&](const f32x4* xa, const f32x4* xw, int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + RPP * p * LDS_LD) = xa[p];
+      *reinterpret_cast<f32x4*>(st_w + buf * BUF_FLOATS + RPP * p * LDS_LD) = xw[p];
+    }
+  };
+  const float* const fr_a = lds + (wm0 + l32) * LDS_LD + half * (BK / 2);
+  const float* const fr_w = lds + BM * LDS_LD + (wn0 + l32) * LDS_LD + half * (BK / 2);
+  f32x4 fa[2][KF], fb[2][KF];
+  auto read_frags = [&](f32x4* xa, f32x4* xb, int buf) {
+#pragma unroll
+    for (int kk = 0; kk < KF; ++kk) {
+      xa[kk] = *reinterpret_cast<const f32x4*>(fr_a + buf * BUF_FLOATS + kk * 4);
+      xb[kk] = *reinterpret_cast<const f32x4*>(fr_w + buf * BUF_FLOATS + kk * 4);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto mfma_frags = [&](const f32x4* xa, const f32x4* xb) {
+#pragma unroll
+    for (int kk = 0; kk < KF; ++kk)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk][c], xb[kk][c], acc, 0, 0, 0);
+  };
+  auto interleave = [&]() {  // 16 MFMAs: 8 ds_read, 4 ds_write, 4 global_load in their shadows
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+  };
+
+  // ---- compute-side tile state (epilogue operands) ----
+  int cp_k = 0, cp_j = 0;
+  int e_row0 = 0, e_col = 0;
+  long long e_coff = 0;
+  bool e_colok = false;
+  float bv = 0.f, rv[16];
+  auto begin_tile = [&](int k) {  // decode the tile and fetch bias / residual (used nsl slices later)
+    const int id = first + k * stride;
+    const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
+    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
+    e_row0 = m0 + wm0 + 4 * half;
+    e_col = n0 + wn0 + l32;
+    e_colok = e_col < g.N;
+    e_coff = (long long)bz * g.batch_stride_c;
+    const int colc = e_colok ? e_col : g.N - 1;
+    bv = g.bias ? g.bias[colc] : 0.f;
+    if (g.res) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int row = e_row0 + (e & 3) + 8 * (e >> 2);
+        row = row < g.M ? row : g.M - 1;
+        rv[e] = g.res[e_coff + (size_t)row * g.ldr + colc];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+    }
+  };
+  auto end_tile = [&]() {
+    float* cp = g.C + e_coff;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = e_row0 + (e & 3) + 8 * (e >> 2);
+      float v = acc[e] + bv;
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      v += rv[e];
+      if (row < g.M && e_colok) cp[(size_t)row * g.ldc + e_col] = v;
+      acc[e] = 0.f;
+    }
+  };
+
+  // ---- prologue: slices 0,1 -> LDS; slices 2,3 -> staging registers ----
+  load_next(ra[0], rw[0]); advance();
+  load_next(ra[1], rw[1]); advance();
+  store_from(ra[0], rw[0], 0);
+  store_from(ra[1], rw[1], 1);
+  load_next(ra[0], rw[0]); advance();
+  load_next(ra[1], rw[1]); advance();
+  begin_tile(0);
+  __syncthreads();
+  read_frags(fa[0], fb[0], 0);
+
+  int b0 = 0, b1 = 1, b2 = 2;
+  const int total_slices = my_tiles * nsl;   // nsl is even (checked on the host)
+  for (int s = 0; s < total_slices; s += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      read_frags(fa[u ^ 1], fb[u ^ 1], b1);
+      store_from(ra[u], rw[u], b2);
+      load_next(ra[u], rw[u]);
+      mfma_frags(fa[u], fb[u]);
+      interleave();
+      advance();
+      if (++cp_j == nsl) {  // block-uniform: last slice of the tile just issued
+        end_tile();
+        cp_j = 0;
+        if (++cp_k < my_tiles) begin_tile(cp_k);
+      }
+      __syncthreads();
+      { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
+    }
+  }
+}
+
+int launch_persist(GemmArgs g, int batch, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float);
+  if (!attr_set) {
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_set = true;
+  }
+  g.tiles_m = ff_cdiv(g.M, 64);
+  g.tiles_n = ff_cdiv(g.N, 64);
+  const long total = (long)g.tiles_m * g.tiles_n * batch;
+  int grid = total < 512 ? (int)total : 512;   // 256 CUs x 2 resident blocks (55 KB LDS each)
+  hipLaunchKernelGGL(gemm_persist_kernel, dim3(grid), dim3(256), bytes, st, g, (int)total);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
 // ---- 8-wave, in-block split-K variant of the 64x64 tile ---------------------------------------
 // Same 64x64 output tile and LDS image as the BK=64 kernel, but 512 threads: waves 0-3 multiply the
 // first 32 k of every 64-wide slice, waves 4-7 the second 32 (both groups cover the whole tile), and
@@ -665,7 +872,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 20, "ff_gemm_f32: tile must be 0..6, 13..20 (7..12: timing ablations)");
+  FF_CHECK_ARG(tile >= 0 && tile <= 21, "ff_gemm_f32: tile must be 0..6, 13..21 (7..12: timing ablations)");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
@@ -676,8 +883,9 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
   if (tile == 0) {
     // Measured on MI355X over the path's shapes (tools/gemm_probe_multi.py under rocprofv3, M = 256..9216,
     // K = 512/1024): the pipelined 64x64 tile wins or ties everywhere -- it is the only shape that
-    // keeps several blocks resident per CU at these sizes.
-    tile = 17;
+    // keeps several blocks resident per CU at these sizes; its persistent form (21) adds 4-6 % by
+    // carrying the software pipeline across tile boundaries.
+    tile = 21;
   }
   if (tile == 3 && !split128) tile = 2;
   hipStream_t st = (hipStream_t)stream;
@@ -695,6 +903,9 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
     case 18: return launch_pipe<64, 64, 32, 32, 64>(g, batch, st);
     case 19: return launch_pipe<128, 128, 64, 64, 32>(g, batch, st);
     case 20: return launch_pipe<128, 64, 64, 32, 32>(g, batch, st);
+    case 21:
+      if (K % 64 == 0 && K >= 128) return launch_persist(g, batch, st);
+      return launch_pipe<64, 64, 32, 32, 32>(g, batch, st);
     case 13: return launch_ks<1>(g, batch, st);
     case 14: return launch_ks<2>(g, batch, st);
     case 7: return launch_gemm<64, 64, 32, 32, 32, 1>(g, batch, st);

@@ -164,3 +164,8 @@ def gather_rows(memory, tok, seqs_per_group=1):
     _L.check(_L.load().ff_gather_rows(_p(memory.contiguous()), S, E, _p(tok), tok.numel(),
                                       seqs_per_group, _p(out), E, _stream()), "ff_gather_rows")
     return out
+
+
+def set_attention_algo(algo):
+    """0 automatic, 1 block-shared LDS staging, 2 wave-independent; returns the previous value."""
+    return _L.load().ff_set_attention_algo(int(algo))

@@ -125,6 +125,9 @@ typedef struct ff_attn_desc {
 } ff_attn_desc;
 
 int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
+/* Kernel selection for ff_attention (tuning / tests): 0 automatic, 1 block-shared LDS staging,
+ * 2 wave-independent with in-block key splitting.  Returns the previous value. */
+int ff_set_attention_algo(int algo);
 
 /* ---------------------------------------------------------------------------------------------
  * G7/G8/G9  Pointer head: logits of every sequence against the edge embeddings of its wireframe,

@@ -10,6 +10,13 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 2], ids=["attn-lds", "attn-wave"])
+def attn_algo(ops, request):
+    old = ops.set_attention_algo(request.param)
+    yield request.param
+    ops.set_attention_algo(old)
+
+
 @pytest.fixture(scope="module")
 def ops(hip_lib):
     if not torch.cuda.is_available():
@@ -57,7 +64,7 @@ def test_add_pos_and_gather(ops):
 
 
 # ---- GEMM -------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
                                    (520, 512, 100), (4100, 1024, 512), (64, 260, 512), (130, 96, 36)])
 def test_gemm_bias_act_residual(ops, M, N, K, tile):
@@ -77,12 +84,12 @@ def test_gemm_identity_layout(ops):
     K = 64
     eye = torch.eye(K)
     w = rnd(96, K, seed=9)
-    for tile in (1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20):
+    for tile in (1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20, 21):
         out = ops.linear(eye.cuda(), w.cuda(), None, tile=tile)
         assert torch.equal(out.cpu(), w.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 def test_gemm_split_a_and_inplace_residual(ops, tile):
     M, E = 300, 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
@@ -112,7 +119,7 @@ def ref_attention(q, k, v, mask=None, causal=False):
 
 @pytest.mark.parametrize("G,H,nq,nk", [(2, 2, 33, 33), (1, 8, 260, 260), (3, 2, 5, 100), (4, 1, 1, 1),
                                        (2, 8, 140, 70), (1, 2, 64, 64), (1, 1, 65, 129)])
-def test_attention_group_major_with_mask(ops, G, H, nq, nk):
+def test_attention_group_major_with_mask(ops, attn_algo, G, H, nq, nk):
     """Encoder-style layout: rows = g*len + i; padding mask + kv_len."""
     E = H * 64
     q, k, v = rnd(G * nq, E, seed=1), rnd(G * nk, E, seed=2), rnd(G * nk, E, seed=3)
@@ -136,7 +143,7 @@ def test_attention_group_major_with_mask(ops, G, H, nq, nk):
 
 @pytest.mark.parametrize("t,B,H,causal", [(1, 5, 2, False), (7, 40, 8, False), (36, 24, 8, False),
                                           (70, 3, 2, False), (9, 4, 2, True), (258, 2, 8, False)])
-def test_attention_position_major_self(ops, t, B, H, causal):
+def test_attention_position_major_self(ops, attn_algo, t, B, H, causal):
     """Decoder self-attention layout: rows = j*B + b, packed q|k|v buffer (ld = 3E)."""
     E = H * 64
     qkv = rnd(t * B, 3 * E, seed=5)
@@ -150,7 +157,7 @@ def test_attention_position_major_self(ops, t, B, H, causal):
 
 
 @pytest.mark.parametrize("t,F,W,S", [(1, 3, 2, 30), (5, 7, 3, 50), (12, 40, 1, 44), (36, 33, 2, 260)])
-def test_attention_cross_shared_kv(ops, t, F, W, S):
+def test_attention_cross_shared_kv(ops, attn_algo, t, F, W, S):
     """Decoder cross-attention: F sequences of a wireframe share its K/V; queries position-major."""
     H, E = 8, 512
     B = W * F
@@ -174,7 +181,7 @@ def test_attention_cross_shared_kv(ops, t, F, W, S):
     assert rel_err(out, ref) < 5e-6
 
 
-def test_attention_online_softmax_rescale_branch(ops):
+def test_attention_online_softmax_rescale_branch(ops, attn_algo):
     """Spike one late key so the running max jumps in a later key tile (forces the rescale path)."""
     H, E, nq, nk = 1, 64, 40, 200
     q, k, v = rnd(nq, E, seed=1), rnd(nk, E, seed=2), rnd(nk, E, seed=3)
