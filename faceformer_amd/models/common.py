@@ -119,6 +119,17 @@ class SurfaceFormerBase(nn.Module):
         memory, kv_len = eng.encode(inp.to(torch.float32).flatten(-2, -1), mask)
         return eng, memory, mask, kv_len
 
+    def _extra_mask(self, inputs):
+        """Optional `inputs['extra_mask']` (bool, one row per decoded sequence, True = edge the pointer
+        may not select, e.g. a co-edge adjacency rule; not a reference key): the never-masked
+        special-token columns are prepended and the mask is OR-ed into the pointer's padding mask
+        inside the kernel."""
+        extra = inputs.get("extra_mask")
+        if extra is None:
+            return None
+        pad = torch.zeros((extra.size(0), self.num_token), dtype=torch.bool, device=extra.device)
+        return torch.cat([pad, extra.to(torch.bool)], dim=1).to(torch.uint8).contiguous()
+
     def forward(self, inputs):
         if self.training:
             return self.forward_train(inputs)

@@ -39,7 +39,7 @@ class SurfaceFormer(SurfaceFormerBase):
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
                          num_streams=self.num_streams, sync_every=1,
                          flags=self.decode_flags, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
-                         return_pointer=True)
+                         return_pointer=True, extra_mask=self._extra_mask(inputs))
         inputs["embedding"] = memory
         inputs["pointer"] = out["pointer"].transpose(0, 1)
         inputs["predict"] = out["predict"]

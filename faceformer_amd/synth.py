@@ -155,3 +155,12 @@ def make_wireframes(num_edges, num_lines, seq_len, kind="parallel", seeds=(0,), 
         "label": torch.from_numpy(label),
         "num_input": [int(n) for n in num_edges],
     }
+
+
+def make_extra_mask(case, batch):
+    """Seeded extra pointer mask for the golden cases that carry `extra_mask_seed`: bool [B, L] (True =
+    forbidden edge) with B = N*F sequences (parallel) or N (seq2seq); ~20 % of the real edges masked."""
+    g = np.random.default_rng([0xC0ED, int(case["extra_mask_seed"])])
+    n_wf, L = batch["input"].shape[0], batch["input"].shape[1]
+    B = n_wf * max(batch["num_input"]) if case["kind"] == "parallel" else n_wf
+    return torch.from_numpy(g.random((B, L)) < 0.2)

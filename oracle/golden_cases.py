@@ -48,6 +48,16 @@ CASES = [
          wseed=0, n_edges=[20, 13], seeds=[1, 2]),
     dict(name="seq_small_eos", kind="seq2seq", model=_m(SMALL, 16, 20), recipe="gain4",
          wseed=6, n_edges=[12], seeds=[3]),
+    # config E style: ragged batch with up to 300 edges (S = 304 > 288: attention key chunking, pointer
+    # tail), small model dims so the reference finishes in seconds
+    dict(name="par_small_ragged300", kind="parallel", model=_m(SMALL, 300, 6), recipe="gain4",
+         wseed=5, n_edges=[300, 64, 129], seeds=[21, 22, 23], keep_logit_rows=[0, 7, 299, 300, 363, 600, 728, 899]),
+    # config D style: an extra pointer mask OR-ed into the padding mask (the reference has no such
+    # operand: the golden comes from the reference with the mask argument of select_next widened)
+    dict(name="seq_small_extramask", kind="seq2seq", model=_m(SMALL, 24, 30), recipe="gain4",
+         wseed=2, n_edges=[20, 13], seeds=[1, 2], extra_mask_seed=9),
+    dict(name="par_small_extramask", kind="parallel", model=_m(SMALL, 24, 9), recipe="gain4",
+         wseed=0, n_edges=[20, 13], seeds=[1, 2], extra_mask_seed=4),
     # configs/seq2seq.yml sizes (config A): L=110, T=259, one 64-edge wireframe
     dict(name="seq_full_A64_gain4", kind="seq2seq", model=_m(FULL, 110, 259), recipe="gain4",
          wseed=0, n_edges=[64], seeds=[3], slow=True),

@@ -76,6 +76,14 @@ def run_case(case, ref_models):
     batch = make_wireframes(case["n_edges"], m["L"], seq_len, kind, seeds=case["seeds"])
     b_ref, b_orc = _clone_batch(batch), _clone_batch(batch)
 
+    extra = None
+    if case.get("extra_mask_seed") is not None:
+        from faceformer_amd.synth import make_extra_mask
+        extra = make_extra_mask(case, batch)                     # [B, L] bool
+        full = torch.cat([torch.zeros(extra.size(0), 4, dtype=torch.bool), extra], dim=1)
+        orig_select = model.select_next
+        model.select_next = lambda e, p, m: orig_select(e, p, m | full)   # same fill value, OR-ed mask
+
     rec = []
     orig_argmax = torch.argmax
 
@@ -95,9 +103,9 @@ def run_case(case, ref_models):
     trace = {}
     t0 = time.time()
     if kind == "parallel":
-        out_orc = refpath.parallel_forward_eval(sd, b_orc, num_head=m["H"], trace=trace)
+        out_orc = refpath.parallel_forward_eval(sd, b_orc, num_head=m["H"], trace=trace, extra_mask=extra)
     else:
-        out_orc = refpath.seq2seq_forward_eval(sd, b_orc, num_head=m["H"], trace=trace)
+        out_orc = refpath.seq2seq_forward_eval(sd, b_orc, num_head=m["H"], trace=trace, extra_mask=extra)
     t_orc = time.time() - t0
 
     ref_logits = [r.squeeze(-1) for r in rec]

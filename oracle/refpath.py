@@ -136,7 +136,7 @@ def _dims(sd):
 
 @torch.no_grad()
 def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=None,
-                          anchor_limit=None, stop_rule=True, num_anchors=None):
+                          anchor_limit=None, stop_rule=True, num_anchors=None, extra_mask=None):
     """SurfaceFormer_Parallel.forward_eval (reference model_para.py:181-241).
 
     `trace`: optional dict; receives 'logits' (list of BxS tensors per step) and 'memory'.
@@ -181,6 +181,8 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
         trace["counts"] = []
     memory = memory.repeat_interleave(max_num_edges, 1)
     input_mask = input_mask.repeat_interleave(max_num_edges, 0)
+    if extra_mask is not None:  # [N*F, L] bool, per sequence; special-token columns are never masked
+        extra_mask = torch.cat([torch.zeros((extra_mask.size(0), num_token)).type_as(extra_mask), extra_mask], dim=1)
 
     for step in range(T - 1):
         target = predicts.unsqueeze(-1).repeat(1, 1, num_model)
@@ -188,7 +190,7 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
         pointer = decoder(sd, tgt, memory, input_mask, pos_embed, query_pos_embed[: step + 1],
                           num_head, n_dec)
         pointer = F.linear(pointer, sd["project.weight"], sd["project.bias"])
-        next_token, logit = select_next(memory, pointer, input_mask)
+        next_token, logit = select_next(memory, pointer, input_mask, extra_mask)
         if trace is not None:
             trace["logits"].append(logit.clone())
         predicts = torch.cat((predicts, next_token), dim=0)

@@ -53,6 +53,9 @@ def case_weights_and_batch(case):
     spec = state_dict_spec(case["kind"], m["L"], m["seq_len"], m["E"], m["FF"], m["enc"], m["dec"])
     sd = make_state_dict(spec, case["recipe"], case["wseed"])
     batch = make_wireframes(case["n_edges"], m["L"], m["seq_len"], case["kind"], seeds=case["seeds"])
+    if case.get("extra_mask_seed") is not None:
+        from faceformer_amd.synth import make_extra_mask
+        batch["extra_mask"] = make_extra_mask(case, batch)
     return sd, batch
 
 

@@ -13,10 +13,11 @@ def _check(name):
     case, z = load_golden(name)
     sd, batch = case_weights_and_batch(case)
     trace = {}
+    extra = batch.pop("extra_mask", None)
     if case["kind"] == "parallel":
-        out = refpath.parallel_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace)
+        out = refpath.parallel_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace, extra_mask=extra)
     else:
-        out = refpath.seq2seq_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace)
+        out = refpath.seq2seq_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace, extra_mask=extra)
     assert np.array_equal(out["predict"].numpy(), z["predict"])
     assert len(trace["logits"]) == int(z["steps"])
     rows = z["logit_rows"]

@@ -36,15 +36,16 @@ def run_traced(model, case, batch):
     kind = case["kind"]
     eng, memory, mask, kv_len = model._encode(batch)
     T = case["model"]["seq_len"]
+    extra = model._extra_mask(batch)
     if kind == "parallel":
         ni = [int(n) for n in batch["num_input"]]
         out = eng.decode(memory, mask, kv_len, L.FF_PARALLEL, T=T, F=max(ni), num_input=ni, trace=True,
-                         sync_every=model.sync_every, flags=model.decode_flags,
+                         extra_mask=extra, sync_every=model.sync_every, flags=model.decode_flags,
                          chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                          num_streams=model.num_streams)
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
-                         flags=model.decode_flags, return_pointer=True,
+                         extra_mask=extra, flags=model.decode_flags, return_pointer=True,
                          chunk_wireframes=model.chunk_wireframes)
     out["memory"] = memory
     return out
@@ -104,7 +105,8 @@ def test_golden_parity(hip_lib, name):
 
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak",
-                                  "par_full_n40_gain4", "seq_small_gain4", "seq_small_eos"])
+                                  "par_full_n40_gain4", "seq_small_gain4", "seq_small_eos",
+                                  "par_small_extramask", "par_small_ragged300"])
 @pytest.mark.parametrize("flags,chunk,sync,cseq,nstr", [(0, 0, 1, 0, 1), (3, 0, 0, 0, 1), (3, 1, 3, 0, 2),
                                                         (1, 2, 1, 0, 3), (2, 1, 0, 0, 1), (3, 0, 2, 5, 4),
                                                         (3, 0, 0, 7, 2), (0, 0, 1, 3, 8)])
