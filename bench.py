@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--wireframes-per-gpu", type=int, default=1)
     ap.add_argument("--edges", type=int, default=256)
-    ap.add_argument("--chunk", type=int, default=0, help="wireframes per micro-batch (0 = all)")
+    ap.add_argument("--chunk", type=int, default=16, help="wireframes per micro-batch (0 = all)")
     ap.add_argument("--chunk-seqs", type=int, default=0, help="sequences per intra-wireframe group (0 = off)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams for the micro-batches")
     ap.add_argument("--attn-algo", type=int, default=0, help="ff_attention kernel: 0 auto, 1 LDS-shared, 2 wave")

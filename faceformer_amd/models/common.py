@@ -45,7 +45,7 @@ class SurfaceFormerBase(nn.Module):
 
         # engine knobs (not part of the reference surface)
         self.decode_flags = DEFAULT_FLAGS
-        self.chunk_wireframes = 0      # micro-batch size in wireframes (0 = whole batch)
+        self.chunk_wireframes = 16     # micro-batch size in wireframes (0 = whole batch); 8-32 measured best
         self.chunk_seqs = 0            # >0: split every wireframe into groups of this many sequences
         self.num_streams = 1           # micro-batches are issued round-robin on this many HIP streams
         self.sync_every = 4            # host evaluation period of the stop rule

@@ -75,7 +75,8 @@ int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div
  * W is the nn.Linear weight layout [N,K]; Asel = A for n < n_split and A2 for n >= n_split
  * (lets one launch produce q,k from `LN(x)+pos` and v from `LN(x)`); pass A2 = NULL to disable.
  * bias / residual may be NULL.  residual may alias C.  act: 0 = identity, 1 = ReLU.
- * tile: 0 = automatic, 1 = 64x64, 2 = 128x64, 3 = 128x128 block tiles (for tuning / tests).
+ * tile (tuning / tests): 0 = automatic (3), 1 = generic 64x64 (any K), 2 = pipelined 64x64,
+ * 3 = persistent pipelined 64x64 (default on the path), 4 = pipelined 128x64, 5 = pipelined 128x128.
  * ------------------------------------------------------------------------------------------- */
 int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split,
                 const float* W, int ldw, const float* bias,

@@ -64,7 +64,7 @@ def test_add_pos_and_gather(ops):
 
 
 # ---- GEMM -------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
                                    (520, 512, 100), (4100, 1024, 512), (64, 260, 512), (130, 96, 36)])
 def test_gemm_bias_act_residual(ops, M, N, K, tile):
@@ -84,12 +84,12 @@ def test_gemm_identity_layout(ops):
     K = 64
     eye = torch.eye(K)
     w = rnd(96, K, seed=9)
-    for tile in (1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20, 21):
+    for tile in (1, 2, 3, 4, 5):
         out = ops.linear(eye.cuda(), w.cuda(), None, tile=tile)
         assert torch.equal(out.cpu(), w.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_gemm_split_a_and_inplace_residual(ops, tile):
     M, E = 300, 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)

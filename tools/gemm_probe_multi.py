@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from faceformer_amd.hip import ops  # noqa: E402
 
-tiles = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,17,18").split(",")]
+tiles = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3").split(",")]
 Ms = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "256,1024,4096,9216").split(",")]
 cfgs = []
 for M in Ms:
