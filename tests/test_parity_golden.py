@@ -241,3 +241,29 @@ def test_cli_decode_writes_reference_json(hip_lib, tmp_path):
         m = FZ.face_metrics(pf, lf)
         assert rec["pred_faces"] == [[t, list(f)] for t, f in m["predictions"]]
         assert sorted(map(tuple, map(lambda x: (x[0], tuple(x[1])), rec["label_faces"]))) == sorted(m["labels"])
+
+
+@pytest.mark.parametrize("name", ["par_small_gain4", "par_full_n40_gain4", "par_full_n40_default"])
+def test_error_against_fp64_truth_is_fp32_class(hip_lib, name):
+    """Whose logits are closer to exact arithmetic?  The oracle restated in float64 is the truth; the
+    HIP path's first-step logits must be no further from it than a small multiple of the distance of
+    the reference's own fp32 CPU logits (both are fp32 evaluations with different summation orders)."""
+    from oracle import refpath
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    tr64 = {}
+    refpath.parallel_forward_eval(sd64, b64, num_head=case["model"]["H"], trace=tr64)
+    truth = tr64["logits"][0].numpy()                       # step 0: identical prefixes by construction
+    rows = z["logit_rows"]
+    ref32 = z["logits"][0]                                   # reference fp32 (golden), selected rows
+    model = build_model(case, sd, "cuda")
+    out = run_traced(model, case, batch_to(batch, "cuda"))
+    hip = out["logits"][0].cpu().numpy()[rows]
+    live = ref32 > np.finfo(np.float32).min
+    err_ref = np.abs(ref32.astype(np.float64) - truth[rows])[live].max()
+    err_hip = np.abs(hip.astype(np.float64) - truth[rows])[live].max()
+    scale = np.abs(truth[rows][live]).max()
+    print(name, "max |logit| %.1f  err(reference fp32) %.3g  err(HIP) %.3g" % (scale, err_ref, err_hip))
+    assert err_hip <= 4.0 * err_ref + 1e-6 * scale
