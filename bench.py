@@ -166,7 +166,7 @@ def main():
         with torch.no_grad():
             model(dict(batch))
         L.check(lib.ff_profile_end(ms, work, cnt, ncat), "ff_profile_end")
-        names = ["gemm_pipe_kernel", "attention_kernel", "layernorm_kernel", "pointer_kernels", "row_ops"]
+        names = ["gemm_persist_kernel", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops"]
         total_ms = sum(ms)
         ach = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         # HBM bytes per launch of the dominant kernel come from the committed PMC passes
