@@ -22,6 +22,9 @@
 // 128x64 / 128x128 at every M of the path because they are the only shape that keeps >= 2 blocks per
 // CU; wave-private tiles (no barrier, 2x the L2 traffic) and in-block split-K lost; barriers and the
 // phase of co-resident blocks do not matter.
+#include <mutex>
+#include <vector>
+
 #include "ff_common.h"
 
 namespace {
@@ -563,6 +566,252 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
   }
 }
 
+// ---- stream-K form of the persistent kernel -----------------------------------------------------------------
+// The persistent kernel hands out WHOLE tiles, so a launch whose tile count is not a multiple of the
+// resident blocks pays a full extra round (288 tiles on 256 CUs cost 2 tile times, 32 tiles keep 224
+// CUs idle while 32 blocks run the whole K chain).  Here the launch is cut into `unit`s of two K-slices
+// and every block gets the same number of consecutive units of the flat (tile, unit) sequence, so a
+// block's range is: the END part of its first tile, whole tiles, the BEGINNING part of its last tile.
+//   * beginning part (tile not finished by this block): computed FIRST, raw accumulators written to
+//     this block's 16 KB workspace slot, flag[block] = epoch (release, agent scope);
+//   * whole tiles: as in the persistent kernel;
+//   * end part: computed LAST; the block owns the tile: it waits for the flags of the lower-numbered
+//     blocks that hold the tile's earlier units (they published at the very start of their run, so the
+//     wait is over before it begins), adds their partials in ascending block order (deterministic sum)
+//     and runs the normal bias / activation / residual epilogue.
+// A block therefore only ever waits on blocks that publish before doing anything else: no deadlock even
+// when not all blocks are resident.  Flags carry a 64-bit launch epoch, so they are never reset.
+struct StreamK {
+  float* ws;                   // [grid][16 accumulator registers][256 threads]
+  unsigned long long* flags;   // [grid]
+  unsigned long long epoch;
+  int upt;                     // units per tile = K / 64
+  int base, rem;               // block lb owns base + (lb < rem) units
+};
+
+__global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK sk) {
+  constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4, KF = BK / 8;
+  constexpr int BUF_FLOATS = (BM + BN) * LDS_LD;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  const int c4 = tid & 7, r = tid >> 3;
+  const int nsl = g.K / BK;
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+
+  // logical block index: the blocks of one XCD (blockIdx % 8) own neighbouring unit ranges
+  const int G = gridDim.x;
+  const int lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int upt = sk.upt;
+  const int u0 = lb * sk.base + (lb < sk.rem ? lb : sk.rem);
+  const int u1 = u0 + sk.base + (lb < sk.rem ? 1 : 0);
+  if (u0 >= u1) return;
+  const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
+  const int ja = u0 - k0 * upt;  // first unit of tile k0 in the range
+  const int jb = u1 - k1 * upt;  // one past the last unit of tile k1 in the range (1..upt)
+  const bool has_c = jb < upt;                           // beginning part of k1: contributed
+  const bool has_o = ja > 0 && !(k0 == k1 && has_c);     // end part of k0: owned, needs the fix-up
+  const int kf0 = k0 + (ja > 0 ? 1 : 0);
+  const int nfull = (k1 + (has_c ? 0 : 1) - kf0) > 0 ? (k1 + (has_c ? 0 : 1) - kf0) : 0;
+  const int nseg = (has_c ? 1 : 0) + nfull + (has_o ? 1 : 0);
+  // segment p in execution order -> (tile, first slice, slice count, kind 0 whole / 1 contribute / 2 own+fix)
+  auto segment = [&](int p, int& tile, int& j0, int& n, int& kind) {
+    if (has_c && p == 0) {
+      tile = k1; j0 = 2 * (k1 == k0 ? ja : 0); n = 2 * jb - j0; kind = 1;
+    } else {
+      const int q = p - (has_c ? 1 : 0);
+      if (q < nfull) { tile = kf0 + q; j0 = 0; n = nsl; kind = 0; }
+      else { tile = k0; j0 = 2 * ja; n = nsl - j0; kind = 2; }
+    }
+  };
+
+  // load cursor
+  const float* a_ptr[2];
+  const float* w_ptr[2];
+  auto set_load_tile = [&](int id) {
+    const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
+    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
+    const float* Asrc = ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + (long long)bz * g.batch_stride_a;
+    const float* W = g.W + (long long)bz * g.batch_stride_w;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int row = m0 + r + 32 * p;
+      row = row < g.M ? row : g.M - 1;
+      a_ptr[p] = Asrc + (size_t)row * g.lda + c4 * 4;
+      int n = n0 + r + 32 * p;
+      n = n < g.N ? n : g.N - 1;
+      w_ptr[p] = W + (size_t)n * g.ldw + c4 * 4;
+    }
+  };
+  int ld_p = 0, ld_j, ld_end;
+  {
+    int tile, j0, n, kind;
+    segment(0, tile, j0, n, kind);
+    set_load_tile(tile);
+    ld_j = j0; ld_end = j0 + n;
+  }
+  f32x4 ra[2][2], rw[2][2];
+  auto load_next = [&](f32x4* xa, f32x4* xw) {
+    const int kk0 = ld_j * BK;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      xa[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + kk0);
+      xw[p] = *reinterpret_cast<const f32x4*>(w_ptr[p] + kk0);
+    }
+  };
+  auto advance = [&]() {  // block-uniform; past the last segment the cursor stays on its last slice
+    if (++ld_j == ld_end) {
+      if (ld_p + 1 < nseg) {
+        int tile, j0, n, kind;
+        segment(++ld_p, tile, j0, n, kind);
+        set_load_tile(tile);
+        ld_j = j0; ld_end = j0 + n;
+      } else {
+        ld_j = ld_end - 1;
+      }
+    }
+  };
+  float* const st_a = lds + r * LDS_LD + c4 * 4;
+  float* const st_w = st_a + BM * LDS_LD;
+  auto store_from = [&](const f32x4* xa, const f32x4* xw, int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + 32 * p * LDS_LD) = xa[p];
+      *reinterpret_cast<f32x4*>(st_w + buf * BUF_FLOATS + 32 * p * LDS_LD) = xw[p];
+    }
+  };
+  const float* const fr_a = lds + (wm0 + l32) * LDS_LD + half * (BK / 2);
+  const float* const fr_w = lds + BM * LDS_LD + (wn0 + l32) * LDS_LD + half * (BK / 2);
+  f32x4 fa[2][KF], fb[2][KF];
+  auto read_frags = [&](f32x4* xa, f32x4* xb, int buf) {
+#pragma unroll
+    for (int kk = 0; kk < KF; ++kk) {
+      xa[kk] = *reinterpret_cast<const f32x4*>(fr_a + buf * BUF_FLOATS + kk * 4);
+      xb[kk] = *reinterpret_cast<const f32x4*>(fr_w + buf * BUF_FLOATS + kk * 4);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto mfma_frags = [&](const f32x4* xa, const f32x4* xb) {
+#pragma unroll
+    for (int kk = 0; kk < KF; ++kk)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk][c], xb[kk][c], acc, 0, 0, 0);
+  };
+
+  // compute-side segment state
+  int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
+  int e_row0 = 0, e_col = 0;
+  long long e_coff = 0;
+  bool e_colok = false;
+  float bv = 0.f, rv[16];
+  auto begin_segment = [&](int p) {
+    int id, j0;
+    segment(p, id, j0, cp_n, cp_kind);
+    cp_cnt = 0;
+    if (cp_kind == 1) return;  // raw partial: no epilogue operands
+    const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
+    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
+    e_row0 = m0 + wm0 + 4 * half;
+    e_col = n0 + wn0 + l32;
+    e_colok = e_col < g.N;
+    e_coff = (long long)bz * g.batch_stride_c;
+    const int colc = e_colok ? e_col : g.N - 1;
+    bv = g.bias ? g.bias[colc] : 0.f;
+    if (g.res) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int row = e_row0 + (e & 3) + 8 * (e >> 2);
+        row = row < g.M ? row : g.M - 1;
+        rv[e] = g.res[e_coff + (size_t)row * g.ldr + colc];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+    }
+  };
+  // Partials and flags cross XCDs (one L2 each).  An agent-scope release / acquire pair would write
+  // back and invalidate the WHOLE L2 of both blocks (buffer_wbl2 / buffer_inv: measured 2-4x slower
+  // launches), so only these few words are made coherent: relaxed agent-scope atomic stores / loads
+  // (sc1 accesses that bypass the non-coherent cache levels), ordered by vmcnt(0) + the block barrier
+  // on the writer and by the data dependence on the flag on the reader.
+  auto end_segment = [&]() {
+    if (cp_kind == 1) {  // hand over the raw accumulators: slot[lb][e][tid]
+      float* wp = sk.ws + (size_t)lb * 4096 + tid;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        __hip_atomic_store(wp + e * 256, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc[e] = 0.f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(sk.flags + lb, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
+      const int ub = k0 * upt;
+      const int big = sk.rem * (sk.base + 1);
+      const int c0 = ub < big ? ub / (sk.base + 1) : sk.rem + (ub - big) / sk.base;
+      for (int c = c0; c < lb; ++c) {
+        while (__hip_atomic_load(sk.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const float* rp = sk.ws + (size_t)c * 4096 + tid;
+        float t[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          t[e] = __hip_atomic_load(rp + e * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += t[e];
+      }
+    }
+    float* cp = g.C + e_coff;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = e_row0 + (e & 3) + 8 * (e >> 2);
+      float v = acc[e] + bv;
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      v += rv[e];
+      if (row < g.M && e_colok) cp[(size_t)row * g.ldc + e_col] = v;
+      acc[e] = 0.f;
+    }
+  };
+
+  // prologue: slices 0,1 -> LDS; slices 2,3 -> staging registers
+  load_next(ra[0], rw[0]); advance();
+  load_next(ra[1], rw[1]); advance();
+  store_from(ra[0], rw[0], 0);
+  store_from(ra[1], rw[1], 1);
+  load_next(ra[0], rw[0]); advance();
+  load_next(ra[1], rw[1]); advance();
+  begin_segment(0);
+  __syncthreads();
+  read_frags(fa[0], fb[0], 0);
+
+  int b0 = 0, b1 = 1, b2 = 2;
+  const int total_slices = 2 * (u1 - u0);
+  for (int s = 0; s < total_slices; s += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      read_frags(fa[u ^ 1], fb[u ^ 1], b1);
+      store_from(ra[u], rw[u], b2);
+      load_next(ra[u], rw[u]);
+      mfma_frags(fa[u], fb[u]);
+      ff_interleave_hints<16, 8, 4, 4>();
+      advance();
+      if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
+        end_segment();
+        if (++cp_p < nseg) begin_segment(cp_p);
+      }
+      __syncthreads();
+      { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
+    }
+  }
+}
+
 template <typename K>
 int set_lds_limit(K kernel, int bytes, bool* done) {
   if (!*done) {
@@ -614,7 +863,87 @@ int launch_persist(GemmArgs g, int batch, hipStream_t st) {
   return FF_OK;
 }
 
+// Stream-K workspace: one per (device, stream) -- launches on one stream are ordered, launches on
+// different streams may overlap and must not share partial-tile slots.  Allocated on first use, kept
+// for the life of the process (512 slots x 16 KB + flags).
+constexpr int SK_MAX_GRID = 512;
+struct SkWorkspace {
+  int device;
+  hipStream_t st;
+  float* ws;
+  unsigned long long* flags;
+  unsigned long long epoch;
+};
+std::mutex g_sk_mu;
+std::vector<SkWorkspace> g_sk;
+int g_sk_min_units = 2;      // smallest range handed to a block (units of 64 k)
+int g_sk_two_per_cu = 2048;  // from this many units on, 512 blocks (2 per CU); below, at most 256
+double g_sk_fix_units = 2.5;  // what cutting tiles costs a launch, in units of per-CU work (policy only)
+
+int sk_acquire(hipStream_t st, StreamK* out) {
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  for (SkWorkspace& w : g_sk)
+    if (w.device == dev && w.st == st) {
+      out->ws = w.ws; out->flags = w.flags; out->epoch = ++w.epoch;
+      return FF_OK;
+    }
+  SkWorkspace w{dev, st, nullptr, nullptr, 0};
+  FF_CHECK_HIP(hipMalloc(&w.ws, (size_t)SK_MAX_GRID * 4096 * sizeof(float)));
+  FF_CHECK_HIP(hipMalloc(&w.flags, SK_MAX_GRID * sizeof(unsigned long long)));
+  FF_CHECK_HIP(hipMemset(w.flags, 0, SK_MAX_GRID * sizeof(unsigned long long)));
+  FF_CHECK_HIP(hipDeviceSynchronize());
+  w.epoch = 1;
+  g_sk.push_back(w);
+  out->ws = w.ws; out->flags = w.flags; out->epoch = 1;
+  return FF_OK;
+}
+
+// mode 0: whole tiles (persistent kernel) or equal unit ranges, whichever the cost model prefers; 2: unit ranges
+int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
+  if (g.K % 64 != 0 || g.K < 128) return launch_pipe<64, 64, 32, 32>(g, batch, st);
+  static bool attr_set = false;
+  constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float);
+  FF_RETURN_IF(set_lds_limit(&gemm_streamk_kernel, bytes, &attr_set));
+  g.tiles_m = ff_cdiv(g.M, 64);
+  g.tiles_n = ff_cdiv(g.N, 64);
+  StreamK sk;
+  sk.upt = g.K / 64;
+  const long tiles = (long)g.tiles_m * g.tiles_n * batch;
+  const long units = tiles * sk.upt;
+  FF_CHECK_ARG(units < (1L << 30), "ff_gemm_f32: problem too large for the stream-K launcher");
+  // Whole tiles (no exchange) when they spread evenly enough over the 256 CUs, otherwise equal unit
+  // ranges: per-CU cost in units, the cut costing about g_sk_fix_units on top of the even share.
+  const long cus = SK_MAX_GRID / 2;
+  const double whole_cost = (double)((tiles + cus - 1) / cus) * sk.upt;
+  const double split_cost = (double)units / cus + g_sk_fix_units;
+  if (mode == 0 && whole_cost <= split_cost) return launch_persist(g, batch, st);
+  long grid;
+  if (units >= g_sk_two_per_cu) grid = SK_MAX_GRID;
+  else {
+    grid = ff_cdiv((int)units, g_sk_min_units);
+    if (grid > cus) grid = cus;
+  }
+  if (grid > units) grid = units;
+  sk.base = (int)(units / grid);
+  sk.rem = (int)(units % grid);
+  FF_RETURN_IF(sk_acquire(st, &sk));
+  hipLaunchKernelGGL(gemm_streamk_kernel, dim3((int)grid), dim3(256), bytes, st, g, sk);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
 }  // namespace
+
+extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths) {
+  FF_CHECK_ARG(min_units >= 1 && two_per_cu_units >= 1 && fix_tenths >= 0, "ff_set_gemm_tuning: bad arguments");
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  g_sk_min_units = min_units;
+  g_sk_two_per_cu = two_per_cu_units;
+  g_sk_fix_units = 0.1 * fix_tenths;
+  return FF_OK;
+}
 
 extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
                                    const float* W, int ldw, const float* bias, const float* residual,
@@ -630,7 +959,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 5, "ff_gemm_f32: tile must be 0..5");
+  FF_CHECK_ARG(tile >= 0 && tile <= 7, "ff_gemm_f32: tile must be 0..7");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
@@ -638,7 +967,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
   GemmArgs g{A, A2, W, bias, residual, C, lda, ldw, ldr, ldc, M, N, K, A2 ? n_split : N, act, 0, 0,
              stride_a, stride_w, stride_c};
   const bool split128 = !A2 || (n_split % 128) == 0;
-  if (tile == 0) tile = 3;  // persistent pipelined 64x64 (falls back by itself for K tails)
+  if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
   if (tile == 5 && !split128) tile = 4;
   hipStream_t st = (hipStream_t)stream;
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
@@ -647,6 +976,8 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
     case 2: return launch_pipe<64, 64, 32, 32>(g, batch, st);
     case 3: return launch_persist(g, batch, st);
     case 4: return launch_pipe<128, 64, 64, 32>(g, batch, st);
+    case 6: return launch_streamk(g, batch, st, 2);
+    case 7: return launch_streamk(g, batch, st, 0);
     default: return launch_pipe<128, 128, 64, 64>(g, batch, st);
   }
 }

@@ -95,6 +95,7 @@ SIGNATURES = {
                                       C.c_longlong, C.c_longlong, C.c_longlong, fptr]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),
+    "ff_set_gemm_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ff_pointer_argmax": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int,
                                     C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int,
                                     fptr, C.c_int, fptr, C.c_int, fptr]),

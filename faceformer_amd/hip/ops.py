@@ -169,3 +169,10 @@ def gather_rows(memory, tok, seqs_per_group=1):
 def set_attention_algo(algo):
     """0 automatic, 1 block-shared LDS staging, 2 wave-independent; returns the previous value."""
     return _L.load().ff_set_attention_algo(int(algo))
+
+
+def set_gemm_tuning(min_units=2, two_per_cu_units=2048, fix_tenths=25):
+    """Launch shape of the stream-K projection kernel (see include/faceformer_hip.h); no arguments =
+    the defaults."""
+    _L.check(_L.load().ff_set_gemm_tuning(int(min_units), int(two_per_cu_units), int(fix_tenths)),
+             "ff_set_gemm_tuning")

@@ -75,8 +75,13 @@ int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div
  * W is the nn.Linear weight layout [N,K]; Asel = A for n < n_split and A2 for n >= n_split
  * (lets one launch produce q,k from `LN(x)+pos` and v from `LN(x)`); pass A2 = NULL to disable.
  * bias / residual may be NULL.  residual may alias C.  act: 0 = identity, 1 = ReLU.
- * tile (tuning / tests): 0 = automatic (3), 1 = generic 64x64 (any K), 2 = pipelined 64x64,
- * 3 = persistent pipelined 64x64 (default on the path), 4 = pipelined 128x64, 5 = pipelined 128x128.
+ * tile (tuning / tests): 0 = automatic (7), 1 = generic 64x64 (any K), 2 = pipelined 64x64,
+ * 3 = persistent pipelined 64x64, 4 = pipelined 128x64, 5 = pipelined 128x128, 6 = stream-K form of 3
+ * (every block gets the same number of 64-wide K units; tiles cut between blocks are summed by the
+ * owning block in a fixed order, so results are run-to-run deterministic), 7 = the stream-K kernel
+ * with the launch shape (whole tiles or equal unit ranges) chosen per problem by a cost model: the
+ * default on the path.  Kernels 6/7 keep an internal 8 MB workspace per (device, stream), allocated
+ * at the first launch on that stream.
  * ------------------------------------------------------------------------------------------- */
 int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split,
                 const float* W, int ldw, const float* bias,
@@ -93,6 +98,12 @@ int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
                         int M, int N, int K, int act, int tile,
                         int batch, long long stride_a, long long stride_w, long long stride_c,
                         ff_stream_t stream);
+
+/* Launch-shape tuning of the stream-K kernel (process-wide; tests and tools/): a block is never handed
+ * fewer than `min_units` K units (of 64); launches with at least `two_per_cu_units` units use 512
+ * blocks (two per CU), smaller ones at most 256; tile 7 cuts tiles only when that saves more than
+ * `fix_tenths`/10 units of per-CU work. */
+int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths);
 
 /* ---------------------------------------------------------------------------------------------
  * G4/G5/G6  Multi-head attention core: softmax(q k^T * scale + mask) v for `num_groups` groups

@@ -64,7 +64,7 @@ def test_add_pos_and_gather(ops):
 
 
 # ---- GEMM -------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
                                    (520, 512, 100), (4100, 1024, 512), (64, 260, 512), (130, 96, 36)])
 def test_gemm_bias_act_residual(ops, M, N, K, tile):
@@ -84,12 +84,12 @@ def test_gemm_identity_layout(ops):
     K = 64
     eye = torch.eye(K)
     w = rnd(96, K, seed=9)
-    for tile in (1, 2, 3, 4, 5):
+    for tile in (1, 2, 3, 4, 5, 6, 7):
         out = ops.linear(eye.cuda(), w.cuda(), None, tile=tile)
         assert torch.equal(out.cpu(), w.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_gemm_split_a_and_inplace_residual(ops, tile):
     M, E = 300, 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
@@ -103,6 +103,37 @@ def test_gemm_split_a_and_inplace_residual(ops, tile):
     ops.linear(out[:, :E], wo.cuda(), None, residual=x, out=x, tile=tile)
     ref2 = x0.double().cpu() + ref[:, :E] @ wo.double().t()
     assert rel_err(x, ref2) < 3e-6
+
+
+@pytest.mark.parametrize("min_units,two_per_cu", [(1, 1), (1, 1 << 30), (2, 2048), (3, 100), (7, 5000)])
+@pytest.mark.parametrize("M,N,K,batch", [(256, 512, 512, 1), (64, 64, 512, 1), (2304, 512, 512, 1),
+                                         (1100, 1536, 512, 1), (4400, 512, 1024, 1), (200, 260, 512, 3),
+                                         (9216, 512, 128, 1)])
+def test_gemm_streamk_splits(ops, M, N, K, batch, min_units, two_per_cu):
+    """Stream-K launch shapes that cut tiles between 2..16 blocks (contribute / own+fix paths), with
+    bias, ReLU and an aliased residual; twice the same launch must give bit-identical results."""
+    ops.set_gemm_tuning(min_units, two_per_cu, 25)
+    try:
+        if batch == 1:
+            a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+            ref = torch.relu(a.double() @ w.double().t() + bias.double()) + res.double()
+            x = res.cuda()
+            ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=x, out=x, tile=6)
+            assert rel_err(x, ref) < 3e-6
+            y = res.cuda()
+            ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=y, out=y, tile=6)
+            assert torch.equal(x, y)
+        else:
+            a, w = rnd(batch, M, K, seed=5), rnd(batch, N, K, seed=6, scale=0.1)
+            out = torch.empty(batch, M, N, device="cuda")
+            L = ops._L
+            ac, wc = a.cuda(), w.cuda()
+            L.check(L.load().ff_gemm_f32_batched(ac.data_ptr(), K, None, 0, wc.data_ptr(), K, None, None, 0,
+                                                 out.data_ptr(), N, M, N, K, 0, 6, batch, M * K, N * K, M * N,
+                                                 torch.cuda.current_stream().cuda_stream), "ff_gemm_f32_batched")
+            assert rel_err(out, a.double() @ w.double().transpose(1, 2)) < 3e-6
+    finally:
+        ops.set_gemm_tuning()
 
 
 # ---- attention --------------------------------------------------------------------------------------
