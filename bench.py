@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--chunk-seqs", type=int, default=0, help="sequences per intra-wireframe group (0 = off)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams for the micro-batches")
     ap.add_argument("--attn-algo", type=int, default=0, help="ff_attention kernel: 0 auto, 1 LDS-shared, 2 wave")
+    ap.add_argument("--gemm-tuning", default="", help="min_units,two_per_cu_units,fix_tenths of ff_set_gemm_tuning")
     ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")
     ap.add_argument("--cpu-anchors", type=int, default=32, help="anchor sequences in the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch threads for the CPU oracle")
@@ -103,6 +104,8 @@ def main():
     model.sync_every = args.sync_every
     from faceformer_amd.hip import ops as _ops
     _ops.set_attention_algo(args.attn_algo)
+    if args.gemm_tuning:
+        _ops.set_gemm_tuning(*[int(v) for v in args.gemm_tuning.split(",")])
     seeds = [rank * W + i for i in range(W)]
     batch_cpu = make_wireframes(n, n, T, "parallel", seeds=seeds)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}

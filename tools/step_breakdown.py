@@ -21,3 +21,12 @@ for i, st in enumerate(d):
     tot += t1 - t0
     print("%2d %8.1f %7.1f %6.1f %6.1f %5.1f %d" % (i + 1, (t1 - t0) / 1e3, g / 1e3, a / 1e3, l / 1e3, o / 1e3, len(st)))
 print("total ms", tot / 1e6)
+if len(sys.argv) > 2:  # kernel-by-kernel listing of the given steps (1-based)
+    import re
+    for t in [int(x) for x in sys.argv[2].split(",")]:
+        print("---- step", t)
+        prev = None
+        for n, s, e in d[t - 1]:
+            short = re.sub(r"\(anonymous namespace\)::|void |\(.*$", "", n)[:60]
+            print("%-60s %7.1f us  gap %5.1f" % (short, (e - s) / 1e3, 0.0 if prev is None else (s - prev) / 1e3))
+            prev = e
