@@ -219,13 +219,14 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
 // Everything that is not an MFMA sits between the MFMAs of the chain (sched_group_barrier); nothing but
 // the barrier separates the chains of consecutive slices.  Slices past the end are clamped to the last
 // slice (a few redundant loads instead of branches in the loop body).
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
-  constexpr int BK = 32, LDS_LD = BK + 4, KF = BK / 8;
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(256, (BK == 16 ? 2 : 1)) void gemm_pipe_kernel(GemmArgs g) {
+  constexpr int LDS_LD = BK + 4, KF = BK / 8;
+  constexpr int TPR = BK / 4, RPP = 256 / TPR;  // threads per staged row, rows per staging pass
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-  constexpr int A_PASSES = BM / 32, W_PASSES = BN / 32;
+  constexpr int A_PASSES = BM / RPP, W_PASSES = BN / RPP;
   constexpr int BUF_FLOATS = (BM + BN) * LDS_LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -239,19 +240,19 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
   const float* __restrict__ W = g.W + bz * g.batch_stride_w;
   float* __restrict__ Cout = g.C + bz * g.batch_stride_c;
 
-  const int c4 = tid & 7, r = tid >> 3;
+  const int c4 = tid % TPR, r = tid / TPR;
   f32x4 ra[2][A_PASSES], rw[2][W_PASSES];
   const float* a_ptr[A_PASSES];
   const float* w_ptr[W_PASSES];
 #pragma unroll
   for (int p = 0; p < A_PASSES; ++p) {
-    int row = m0 + r + 32 * p;
+    int row = m0 + r + RPP * p;
     row = row < g.M ? row : g.M - 1;
     a_ptr[p] = Asrc + (size_t)row * g.lda + c4 * 4;
   }
 #pragma unroll
   for (int p = 0; p < W_PASSES; ++p) {
-    int n = n0 + r + 32 * p;
+    int n = n0 + r + RPP * p;
     n = n < g.N ? n : g.N - 1;
     w_ptr[p] = W + (size_t)n * g.ldw + c4 * 4;
   }
@@ -268,10 +269,10 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
   auto store_from = [&](const f32x4* xa, const f32x4* xw, int buf) {
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p)
-      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + 32 * p * LDS_LD) = xa[p];
+      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + RPP * p * LDS_LD) = xa[p];
 #pragma unroll
     for (int p = 0; p < W_PASSES; ++p)
-      *reinterpret_cast<f32x4*>(st_w + buf * BUF_FLOATS + 32 * p * LDS_LD) = xw[p];
+      *reinterpret_cast<f32x4*>(st_w + buf * BUF_FLOATS + RPP * p * LDS_LD) = xw[p];
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -319,14 +320,15 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
   // under it; the residual tile is only overwritten by this block, at the end)
   float bv[NI];
   int colc[NI];
-  float rv[MI][NI][16];
+  constexpr bool PRE = MI * NI < 4;  // four accumulators: no registers left for a residual prefetch
+  float rv[PRE ? MI : 1][PRE ? NI : 1][16];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int col = n0 + wn0 + ni * 32 + l32;
     colc[ni] = col < g.N ? col : g.N - 1;
     bv[ni] = g.bias ? g.bias[colc[ni]] : 0.f;
   }
-  if (g.res) {
+  if (PRE && g.res) {
     const float* rp = g.res + bz * g.batch_stride_c;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
           row = row < g.M ? row : g.M - 1;
           rv[mi][ni][e] = rp[(size_t)row * g.ldr + colc[ni]];
         }
-  } else {
+  } else if (PRE) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -382,12 +384,23 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(GemmArgs g) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int col = n0 + wn0 + ni * 32 + l32;
+      float rl[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (PRE) {
+          rl[e] = rv[PRE ? mi : 0][PRE ? ni : 0][e];
+        } else {
+          int row = m0 + wm0 + mi * 32 + 4 * half + (e & 3) + 8 * (e >> 2);
+          row = row < g.M ? row : g.M - 1;
+          rl[e] = g.res ? g.res[bz * g.batch_stride_c + (size_t)row * g.ldr + colc[ni]] : 0.f;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm0 + mi * 32 + 4 * half + (e & 3) + 8 * (e >> 2);
         float v = acc[mi][ni][e] + bv[ni];
         if (g.act == 1) v = fmaxf(v, 0.f);
-        v += rv[mi][ni][e];
+        v += rl[e];
         if (row < g.M && col < g.N) Cout[(size_t)row * g.ldc + col] = v;
       }
     }
@@ -573,18 +586,19 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
 // and every block gets the same number of consecutive units of the flat (tile, unit) sequence, so a
 // block's range is: the END part of its first tile, whole tiles, the BEGINNING part of its last tile.
 //   * beginning part (tile not finished by this block): computed FIRST, raw accumulators written to
-//     this block's 16 KB workspace slot, flag[block] = epoch (release, agent scope);
+//     this block's 16 KB workspace slot, then flag[block] = 1;
 //   * whole tiles: as in the persistent kernel;
 //   * end part: computed LAST; the block owns the tile: it waits for the flags of the lower-numbered
 //     blocks that hold the tile's earlier units (they published at the very start of their run, so the
 //     wait is over before it begins), adds their partials in ascending block order (deterministic sum)
 //     and runs the normal bias / activation / residual epilogue.
 // A block therefore only ever waits on blocks that publish before doing anything else: no deadlock even
-// when not all blocks are resident.  Flags carry a 64-bit launch epoch, so they are never reset.
+// when not all blocks are resident.  Every flagged slot has exactly one reader, which clears the flag
+// after use: the workspace is clean again at the end of every launch (and a launch captured in a
+// hipGraph replays correctly).
 struct StreamK {
   float* ws;                   // [grid][16 accumulator registers][256 threads]
-  unsigned long long* flags;   // [grid]
-  unsigned long long epoch;
+  unsigned int* flags;         // [grid]: 1 = slot holds a partial tile
   int upt;                     // units per tile = K / 64
   int base, rem;               // block lb owns base + (lb < rem) units
 };
@@ -748,7 +762,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(sk.flags + lb, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(sk.flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
     if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
@@ -756,7 +770,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       const int big = sk.rem * (sk.base + 1);
       const int c0 = ub < big ? ub / (sk.base + 1) : sk.rem + (ub - big) / sk.base;
       for (int c = c0; c < lb; ++c) {
-        while (__hip_atomic_load(sk.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch)
+        while (__hip_atomic_load(sk.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
           __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         const float* rp = sk.ws + (size_t)c * 4096 + tid;
@@ -767,6 +781,8 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] += t[e];
       }
+      __syncthreads();  // every thread is past its flag polls
+      if (tid < lb - c0) __hip_atomic_store(sk.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     float* cp = g.C + e_coff;
 #pragma unroll
@@ -835,15 +851,15 @@ int launch_generic(GemmArgs g, int batch, hipStream_t st) {
   return FF_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch_pipe(GemmArgs g, int batch, hipStream_t st) {
-  if (g.K % 32 != 0) return launch_generic<BM, BN, WM, WN>(g, batch, st);
+  if (g.K % BK != 0) return launch_generic<BM, BN, WM, WN>(g, batch, st);
   static bool attr_set = false;
-  constexpr int bytes = 3 * (BM + BN) * 36 * (int)sizeof(float);
-  FF_RETURN_IF(set_lds_limit(&gemm_pipe_kernel<BM, BN, WM, WN>, bytes, &attr_set));
+  constexpr int bytes = 3 * (BM + BN) * (BK + 4) * (int)sizeof(float);
+  FF_RETURN_IF(set_lds_limit(&gemm_pipe_kernel<BM, BN, WM, WN, BK>, bytes, &attr_set));
   g.tiles_m = ff_cdiv(g.M, BM);
   g.tiles_n = ff_cdiv(g.N, BN);
-  hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), bytes, st,
+  hipLaunchKernelGGL((gemm_pipe_kernel<BM, BN, WM, WN, BK>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), bytes, st,
                      g);
   FF_CHECK_LAUNCH();
   return FF_OK;
@@ -871,8 +887,7 @@ struct SkWorkspace {
   int device;
   hipStream_t st;
   float* ws;
-  unsigned long long* flags;
-  unsigned long long epoch;
+  unsigned int* flags;
 };
 std::mutex g_sk_mu;
 std::vector<SkWorkspace> g_sk;
@@ -886,17 +901,16 @@ int sk_acquire(hipStream_t st, StreamK* out) {
   std::lock_guard<std::mutex> lock(g_sk_mu);
   for (SkWorkspace& w : g_sk)
     if (w.device == dev && w.st == st) {
-      out->ws = w.ws; out->flags = w.flags; out->epoch = ++w.epoch;
+      out->ws = w.ws; out->flags = w.flags;
       return FF_OK;
     }
-  SkWorkspace w{dev, st, nullptr, nullptr, 0};
+  SkWorkspace w{dev, st, nullptr, nullptr};
   FF_CHECK_HIP(hipMalloc(&w.ws, (size_t)SK_MAX_GRID * 4096 * sizeof(float)));
-  FF_CHECK_HIP(hipMalloc(&w.flags, SK_MAX_GRID * sizeof(unsigned long long)));
-  FF_CHECK_HIP(hipMemset(w.flags, 0, SK_MAX_GRID * sizeof(unsigned long long)));
+  FF_CHECK_HIP(hipMalloc(&w.flags, SK_MAX_GRID * sizeof(unsigned int)));
+  FF_CHECK_HIP(hipMemset(w.flags, 0, SK_MAX_GRID * sizeof(unsigned int)));
   FF_CHECK_HIP(hipDeviceSynchronize());
-  w.epoch = 1;
   g_sk.push_back(w);
-  out->ws = w.ws; out->flags = w.flags; out->epoch = 1;
+  out->ws = w.ws; out->flags = w.flags;
   return FF_OK;
 }
 
@@ -959,7 +973,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 7, "ff_gemm_f32: tile must be 0..7");
+  FF_CHECK_ARG(tile >= 0 && tile <= 8, "ff_gemm_f32: tile must be 0..8");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
@@ -968,7 +982,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
              stride_a, stride_w, stride_c};
   const bool split128 = !A2 || (n_split % 128) == 0;
   if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
-  if (tile == 5 && !split128) tile = 4;
+  if ((tile == 5 || tile == 8) && !split128) tile = 4;
   hipStream_t st = (hipStream_t)stream;
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
   switch (tile) {
@@ -978,6 +992,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
     case 4: return launch_pipe<128, 64, 64, 32>(g, batch, st);
     case 6: return launch_streamk(g, batch, st, 2);
     case 7: return launch_streamk(g, batch, st, 0);
+    case 8: return launch_pipe<128, 128, 64, 64, 16>(g, batch, st);
     default: return launch_pipe<128, 128, 64, 64>(g, batch, st);
   }
 }
