@@ -1,0 +1,703 @@
+// fp32-accurate dense projection on the bf16 matrix cores ("3 x bf16"):
+//     C = act(Asel * W^T + bias) + residual,   A fp32 [M,K], W fp32 [N,K] given as three bf16 planes.
+//
+// Every fp32 value is split EXACTLY into three bf16 terms, x = x1 + x2 + x3 (round-to-nearest each
+// time, |x - x1 - x2 - x3| <= 2^-25 |x|), and a product is evaluated as the six partial products whose
+// weight is >= 2^-16:  x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1); what is dropped is <= 2^-24 |xy|,
+// the size of one fp32 rounding.  bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16
+// accumulates in fp32, so the result carries the error of an ordinary fp32 dot product (measured against
+// fp64: tools/ubench/gemm_bf16x3.hip, tests/test_hip_ops.py::test_gemm_x3_*) while the matrix pipe runs
+// at 2.5 PF/s / 6 = 417 TF/s fp32-equivalent instead of the 157 TF/s of v_mfma_f32_32x32x2_f32.
+//
+// Plane layout: [plane][k / 16][row][k % 16].  A K-slice of 16 is then 32 contiguous bytes per row AND
+// contiguous over rows: a staging instruction that covers 32 rows reads one aligned 1 KB block (eight full
+// 128-byte lines).  With row-major [row][K] planes the same instruction touched 32 lines for 32 bytes each
+// and the kernel ran at the L2 -> CU line bandwidth (4x the bytes it needed; measured 121 -> 192 TF/s
+// with the loads removed).
+//
+// Weights are split once (ff_split_weight_bf16x3, at model bind time); activations are split on the
+// fly while they are staged into LDS (44 VALU ops per thread and 16-wide K slice, hidden under the 24
+// MFMAs of the slice).
+//
+// Kernel: the stream-K flat (tile, slice) pipeline of ff_gemm.hip's gemm_streamk_kernel with
+//   * 128x128 block tiles, 4 waves x (64x64) = four 32x32 accumulators per wave, K slices of 16;
+//   * LDS: [3-slot ring][3 planes][256 rows][32 B], 16-byte chunk c of row r stored at c ^ ((r >> 4) & 1)
+//     (ds_read_b128 serves lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} together over 64 banks: rows 8 apart
+//     share a bank octet and must use different halves; no padding needed): 72 KB -> two blocks per CU;
+//   * per slice and wave: 12 ds_read_b128 (this slice's fragments; the co-resident block covers their
+//     latency -- a second fragment set does not fit in 256 VGPRs), 6 ds_write_b64 + 3 ds_write_b128
+//     (slice +2), 5 global loads (slice +4), 24 MFMAs, one barrier;
+//   * equal ranges of 32-wide K units per block, partial tiles (64 KB) handed over through sc1 accesses
+//     and summed by the owning block in ascending block order (deterministic).
+#include <mutex>
+#include <vector>
+
+#include "ff_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct X3Args {
+  const float* A;
+  const float* A2;
+  const unsigned short* Wp;  // [3][K/16][N][16] bf16 (see "plane layout" above)
+  const float* bias;
+  const float* res;
+  float* C;
+  int lda, ldr, ldc;
+  int M, N, K;
+  int n_split, act;
+  int tiles_m, tiles_n;
+  long long plane_stride;  // elements between two planes of Wp
+  // A given pre-split (gemm_x3p_kernel): [3][K/16][a_rows][16] bf16 planes, and optional planes output
+  const unsigned short* Ap;
+  const unsigned short* Ap2;
+  long long a_plane_stride;
+  int a_rows;
+  unsigned short* Cp;      // optional: C also written as planes [3][N/16][c_rows][16] (input of the next product)
+  long long c_plane_stride;
+  int c_rows;
+  float* ws;               // [grid][64 accumulator registers][256 threads]
+  unsigned int* flags;     // [grid]: 1 = slot holds a partial tile
+  int upt;                 // units (32 k) per tile
+  int base, rem;           // block lb owns base + (lb < rem) units
+};
+
+// x (two floats) -> packed bf16 pairs of the three terms
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 b1 = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+  p1 = __builtin_bit_cast(unsigned, b1);
+  const float r0 = x0 - __builtin_bit_cast(float, p1 << 16);
+  const float r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  const bf16x2 b2 = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+  p2 = __builtin_bit_cast(unsigned, b2);
+  const float s0 = r0 - __builtin_bit_cast(float, p2 << 16);
+  const float s1 = r1 - __builtin_bit_cast(float, p2 & 0xffff0000u);
+  const bf16x2 b3 = __builtin_convertvector(f32x2{s0, s1}, bf16x2);
+  p3 = __builtin_bit_cast(unsigned, b3);
+}
+
+__global__ void split_weight_kernel(const float* __restrict__ W, int ldw, int N, int K,
+                                    unsigned short* __restrict__ P) {
+  const size_t n2 = (size_t)N * (K / 2);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / (K / 2), c = (i % (K / 2)) * 2;
+    unsigned p1, p2, p3;
+    split2(W[row * ldw + c], W[row * ldw + c + 1], p1, p2, p3);
+    unsigned* o = reinterpret_cast<unsigned*>(P);
+    const size_t plane = (size_t)N * K / 2;
+    const size_t at = ((c >> 4) * (size_t)N + row) * 8 + ((c & 15) >> 1);  // [k/16][row][16] in bf16 pairs
+    o[at] = p1;
+    o[plane + at] = p2;
+    o[2 * plane + at] = p3;
+  }
+}
+
+// End of a segment of the flat (tile, slice) sequence: hand the partial tile over (kind 1), or finish the
+// tile -- after adding the partials of the lower-numbered blocks (kind 2) -- with bias / activation /
+// residual and the store(s).  Shared by both kernels.
+__device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2][2], int cp_kind, int lb, int k0,
+                                               int e_m0, int e_n0) {
+  constexpr int BM = 128, BN = 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int upt = g.upt;
+  {
+    if (cp_kind == 1) {  // hand over the raw accumulators: slot[lb][64][tid]
+      float* wp = g.ws + (size_t)lb * (BM * BN) + tid;
+      asm volatile("" : "+v"(wp));  // keep the 64 slot addresses out of the loop-invariant (hoisted, spilled) set
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            __hip_atomic_store(wp + ((mi * 2 + ni) * 16 + e) * 256, acc[mi][ni][e], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            acc[mi][ni][e] = 0.f;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(g.flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
+      const int ub = k0 * upt;
+      const int big = g.rem * (g.base + 1);
+      const int c0 = ub < big ? ub / (g.base + 1) : g.rem + (ub - big) / g.base;
+      for (int c = c0; c < lb; ++c) {
+        while (__hip_atomic_load(g.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const float* rp = g.ws + (size_t)c * (BM * BN) + tid;
+        asm volatile("" : "+v"(rp));
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            float t[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              t[e] = __hip_atomic_load(rp + ((mi * 2 + ni) * 16 + e) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] += t[e];
+          }
+      }
+      __syncthreads();  // every thread is past its flag polls
+      if (tid < lb - c0) __hip_atomic_store(g.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // bias, activation, residual, store; the residual of a sub-tile is read before its stores
+    // (it may alias C)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      int col = e_n0 + wn0 + ni * 32 + l32;
+      asm volatile("" : "+v"(col));  // opaque: the address arithmetic below must not be hoisted out of the K loop
+      const bool colok = col < g.N;
+      const int colc = colok ? col : g.N - 1;
+      const float bv = g.bias ? g.bias[colc] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        int rbase = e_m0 + wm0 + mi * 32 + 4 * half;
+        asm volatile("" : "+v"(rbase));
+        float rl[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int row = rbase + (e & 3) + 8 * (e >> 2);
+          row = row < g.M ? row : g.M - 1;
+          rl[e] = g.res ? g.res[(size_t)row * g.ldr + colc] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = rbase + (e & 3) + 8 * (e >> 2);
+          float v = acc[mi][ni][e] + bv;
+          if (g.act == 1) v = fmaxf(v, 0.f);
+          v += rl[e];
+          if (row < g.M && colok) {
+            if (g.C) g.C[(size_t)row * g.ldc + col] = v;
+            if (g.Cp) {  // exact three-term split of the result for the next product
+              const unsigned u1 = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
+              const float r1 = v - __builtin_bit_cast(float, u1);
+              const unsigned u2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+              const float r2 = r1 - __builtin_bit_cast(float, u2);
+              unsigned short* cp = g.Cp + ((size_t)(col >> 4) * g.c_rows + row) * 16 + (col & 15);
+              cp[0] = (unsigned short)(u1 >> 16);
+              cp[g.c_plane_stride] = (unsigned short)(u2 >> 16);
+              cp[2 * g.c_plane_stride] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+            }
+          }
+          acc[mi][ni][e] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
+  constexpr int BM = 128, BN = 128, BK = 16;
+  constexpr int PLANE_B = (BM + BN) * 32, BUF_B = 3 * PLANE_B;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int nsl = g.K / BK;
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+
+  // ---- this block's unit range and its segments (see gemm_streamk_kernel) ----
+  const int G = gridDim.x;
+  const int lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int upt = g.upt;
+  const int u0 = lb * g.base + (lb < g.rem ? lb : g.rem);
+  const int u1 = u0 + g.base + (lb < g.rem ? 1 : 0);
+  if (u0 >= u1) return;
+  const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
+  const int ja = u0 - k0 * upt;
+  const int jb = u1 - k1 * upt;
+  const bool has_c = jb < upt;
+  const bool has_o = ja > 0 && !(k0 == k1 && has_c);
+  const int kf0 = k0 + (ja > 0 ? 1 : 0);
+  const int nfull = (k1 + (has_c ? 0 : 1) - kf0) > 0 ? (k1 + (has_c ? 0 : 1) - kf0) : 0;
+  const int nseg = (has_c ? 1 : 0) + nfull + (has_o ? 1 : 0);
+  auto segment = [&](int p, int& tile, int& j0, int& n, int& kind) {
+    if (has_c && p == 0) {
+      tile = k1; j0 = 2 * (k1 == k0 ? ja : 0); n = 2 * jb - j0; kind = 1;
+    } else {
+      const int q = p - (has_c ? 1 : 0);
+      if (q < nfull) { tile = kf0 + q; j0 = 0; n = nsl; kind = 0; }
+      else { tile = k0; j0 = 2 * ja; n = nsl - j0; kind = 2; }
+    }
+  };
+
+  // ---- staging maps ----
+  // A (fp32): thread (ar, ac) loads 4 floats of rows ar, ar + 64; written as 3 x 8 bytes per row
+  const int ar = tid >> 2, ac = tid & 3;
+  // W (bf16 planes): thread (wr, wh) loads 8 bf16 of row wr in each of the three planes
+  const int wr = tid >> 1, wh = tid & 1;
+  const float* a_ptr[2];
+  const unsigned short* w_ptr;
+  auto set_load_tile = [&](int id) {
+    const int rem2 = id % tiles_mn;
+    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
+    const float* Asrc = (g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int row = m0 + ar + 64 * p;
+      row = row < g.M ? row : g.M - 1;
+      a_ptr[p] = Asrc + (size_t)row * g.lda + ac * 4;
+    }
+    int n = n0 + wr;
+    n = n < g.N ? n : g.N - 1;
+    w_ptr = g.Wp + (size_t)n * 16 + wh * 8;
+  };
+  int ld_p = 0, ld_j, ld_end;
+  {
+    int tile, j0, n, kind;
+    segment(0, tile, j0, n, kind);
+    set_load_tile(tile);
+    ld_j = j0; ld_end = j0 + n;
+  }
+  f32x4 sa[2][2];
+  u32x4 sw[2][3];
+  auto load_next = [&](f32x4* xa, u32x4* xw) {
+    const int kk0 = ld_j * BK;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) xa[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + kk0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      xw[q] = *reinterpret_cast<const u32x4*>(w_ptr + q * g.plane_stride + (size_t)ld_j * g.N * 16);
+  };
+  auto advance = [&]() {
+    if (++ld_j == ld_end) {
+      if (ld_p + 1 < nseg) {
+        int tile, j0, n, kind;
+        segment(++ld_p, tile, j0, n, kind);
+        set_load_tile(tile);
+        ld_j = j0; ld_end = j0 + n;
+      } else {
+        ld_j = ld_end - 1;
+      }
+    }
+  };
+  // LDS addresses (bytes inside a ring slot)
+  int sta[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = ar + 64 * p;
+    sta[p] = row * 32 + (((ac >> 1) ^ ((row >> 4) & 1)) * 16) + (ac & 1) * 8;
+  }
+  const int stw = (BM + wr) * 32 + ((wh ^ ((wr >> 4) & 1)) * 16);
+  auto store_from = [&](const f32x4* xa, const u32x4* xw, int buf) {
+    unsigned char* base = lds + buf * BUF_B;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      unsigned a1, a2, a3, b1, b2, b3;
+      split2(xa[p][0], xa[p][1], a1, a2, a3);
+      split2(xa[p][2], xa[p][3], b1, b2, b3);
+      *reinterpret_cast<u32x2*>(base + sta[p]) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(base + PLANE_B + sta[p]) = u32x2{a2, b2};
+      *reinterpret_cast<u32x2*>(base + 2 * PLANE_B + sta[p]) = u32x2{a3, b3};
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(base + q * PLANE_B + stw) = xw[q];
+  };
+  // fragment addresses: the swizzle bit of rows wm0 + mi*32 + l32 only depends on l32
+  const int fchunk = (half ^ ((l32 >> 4) & 1)) * 16;
+  const int fra = (wm0 + l32) * 32 + fchunk;
+  const int frb = (BM + wn0 + l32) * 32 + fchunk;
+  bf16x8 fa[3][2], fb[3][2];
+  auto read_frags = [&](bf16x8 (*xa)[2], bf16x8 (*xb)[2], int buf) {
+    const unsigned char* base = lds + buf * BUF_B;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        xa[p][i] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_B + fra + i * 32 * 32);
+        xb[p][i] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_B + frb + i * 32 * 32);
+      }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  auto mfma_frags = [&](bf16x8 (*xa)[2], bf16x8 (*xb)[2]) {
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[t]][mi], xb[PB[t]][ni], acc[mi][ni], 0, 0, 0);
+  };
+  auto hints = [&]() {
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read
+    }
+  };
+
+  // ---- compute-side segment state ----
+  int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
+  int e_m0 = 0, e_n0 = 0;
+  auto begin_segment = [&](int p) {
+    int id, j0;
+    segment(p, id, j0, cp_n, cp_kind);
+    cp_cnt = 0;
+    const int rem2 = id % tiles_mn;
+    e_m0 = (rem2 / g.tiles_n) * BM;
+    e_n0 = (rem2 % g.tiles_n) * BN;
+  };
+  auto end_segment = [&]() { x3_end_segment(g, acc, cp_kind, lb, k0, e_m0, e_n0); };
+
+  // ---- prologue: slices 0,1 -> LDS; slices 2,3 -> staging registers ----
+  load_next(sa[0], sw[0]); advance();
+  load_next(sa[1], sw[1]); advance();
+  store_from(sa[0], sw[0], 0);
+  store_from(sa[1], sw[1], 1);
+  load_next(sa[0], sw[0]); advance();
+  load_next(sa[1], sw[1]); advance();
+  begin_segment(0);
+  __syncthreads();
+
+  int b0 = 0, b1 = 1, b2 = 2;
+  const int total_slices = 2 * (u1 - u0);
+  for (int s = 0; s < total_slices; s += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      read_frags(fa, fb, b0);
+      store_from(sa[u], sw[u], b2);
+      load_next(sa[u], sw[u]);
+      mfma_frags(fa, fb);
+      hints();
+      advance();
+      if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
+        end_segment();
+        if (++cp_p < nseg) begin_segment(cp_p);
+        // Drain the vector-memory counter on this (rare) path: otherwise the compiler's wait-count
+        // analysis merges the unknown state left by the loops above into the K loop and opens every
+        // slice with s_waitcnt vmcnt(0), i.e. exposes the full latency of the loads issued one slice ago.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
+      __syncthreads();
+      { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
+    }
+  }
+}
+
+// ---- both operands pre-split: every byte reaches LDS by DMA ------------------------------------------------
+// When the producer of A already wrote it as three bf16 planes (LayerNorm, attention and the previous
+// projection do, on the large-M steps), nothing has to pass through registers: each wave issues six
+// global_load_lds_dwordx4 per slice (one instruction = 32 rows x 32 B of one plane = 1 KB, lane-linear in
+// LDS; the chunk swizzle is applied to the GLOBAL address a lane reads).  Ring of three slots, data two
+// slices ahead: slice s+2 is issued in iteration s into the slot whose last readers finished before the
+// previous barrier, and "s_waitcnt vmcnt(6); s_barrier" at the end of iteration s retires slice s+1 for
+// every wave while the six pieces of slice s+2 stay in flight.  Raw s_barrier: __syncthreads() would
+// drain the DMA queue (its release fence waits for vmcnt(0)).
+__global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
+  constexpr int BM = 128, BN = 128, BK = 16;
+  constexpr int PLANE_B = (BM + BN) * 32, BUF_B = 3 * PLANE_B;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int nsl = g.K / BK;
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+
+  const int G = gridDim.x;
+  const int lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int upt = g.upt;
+  const int u0 = lb * g.base + (lb < g.rem ? lb : g.rem);
+  const int u1 = u0 + g.base + (lb < g.rem ? 1 : 0);
+  if (u0 >= u1) return;
+  const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
+  const int ja = u0 - k0 * upt;
+  const int jb = u1 - k1 * upt;
+  const bool has_c = jb < upt;
+  const bool has_o = ja > 0 && !(k0 == k1 && has_c);
+  const int kf0 = k0 + (ja > 0 ? 1 : 0);
+  const int nfull = (k1 + (has_c ? 0 : 1) - kf0) > 0 ? (k1 + (has_c ? 0 : 1) - kf0) : 0;
+  const int nseg = (has_c ? 1 : 0) + nfull + (has_o ? 1 : 0);
+  auto segment = [&](int p, int& tile, int& j0, int& n, int& kind) {
+    if (has_c && p == 0) {
+      tile = k1; j0 = 2 * (k1 == k0 ? ja : 0); n = 2 * jb - j0; kind = 1;
+    } else {
+      const int q = p - (has_c ? 1 : 0);
+      if (q < nfull) { tile = kf0 + q; j0 = 0; n = nsl; kind = 0; }
+      else { tile = k0; j0 = 2 * ja; n = nsl - j0; kind = 2; }
+    }
+  };
+
+  // DMA pieces of this wave: d = 6 * wave + i -> plane d / 8, row block d % 8 (32 rows: 4 x A, 4 x W)
+  const int prow = lane >> 1;                       // row inside the piece
+  const unsigned short* dsrc[6];
+  int ddst[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int d = 6 * wave + i;
+    ddst[i] = (d >> 3) * PLANE_B + (d & 7) * 1024;
+  }
+  auto set_load_tile = [&](int id) {
+    const int rem2 = id % tiles_mn;
+    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
+    const unsigned short* Asrc = (g.Ap2 != nullptr && n0 >= g.n_split) ? g.Ap2 : g.Ap;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int d = 6 * wave + i, plane = d >> 3, rb = d & 7;
+      const int row = (rb & 3) * 32 + prow;                        // row inside the A or W half of the slot
+      const int chunk = (lane & 1) ^ ((row >> 4) & 1);             // logical 16-byte chunk this lane fetches
+      if (rb < 4) {
+        int r = m0 + row;
+        r = r < g.M ? r : g.M - 1;
+        dsrc[i] = Asrc + plane * g.a_plane_stride + (size_t)r * 16 + chunk * 8;
+      } else {
+        int n = n0 + row;
+        n = n < g.N ? n : g.N - 1;
+        dsrc[i] = g.Wp + plane * g.plane_stride + (size_t)n * 16 + chunk * 8;
+      }
+    }
+  };
+  int ld_p = 0, ld_j, ld_end;
+  {
+    int tile, j0, n, kind;
+    segment(0, tile, j0, n, kind);
+    set_load_tile(tile);
+    ld_j = j0; ld_end = j0 + n;
+  }
+  auto issue = [&](int slot) {
+    const size_t ka = (size_t)ld_j * g.a_rows * 16, kw = (size_t)ld_j * g.N * 16;  // k-block stride of A / W planes
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds(dsrc[i] + (((6 * wave + i) & 7) < 4 ? ka : kw),
+                                       (__attribute__((address_space(3))) void*)(lds + slot * BUF_B + ddst[i]), 16, 0, 0);
+  };
+  auto advance = [&]() {
+    if (++ld_j == ld_end) {
+      if (ld_p + 1 < nseg) {
+        int tile, j0, n, kind;
+        segment(++ld_p, tile, j0, n, kind);
+        set_load_tile(tile);
+        ld_j = j0; ld_end = j0 + n;
+      } else {
+        ld_j = ld_end - 1;
+      }
+    }
+  };
+  // Fragment reads are inline asm: the compiler orders an LDS read it can see after ALL outstanding
+  // global_load_lds (s_waitcnt vmcnt(0)), which would collapse the two-slice lead to one.  The DMA ->
+  // read order is established by the counted vmcnt + barrier at the end of the previous iteration.
+  const int fchunk = (half ^ ((l32 >> 4) & 1)) * 16;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)lds);
+  const unsigned fra = lds0 + (wm0 + l32) * 32 + fchunk;
+  const unsigned frb = lds0 + (BM + wn0 + l32) * 32 + fchunk;
+  u32x4 fa[3][2], fb[3][2];
+#define FF_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  auto read_frags = [&](int slot) {
+    const unsigned ra = fra + slot * BUF_B, rb = frb + slot * BUF_B;
+    FF_DSR(fa[0][0], ra, 0);     FF_DSR(fa[0][1], ra, 1024);
+    FF_DSR(fa[1][0], ra, 8192);  FF_DSR(fa[1][1], ra, 9216);
+    FF_DSR(fa[2][0], ra, 16384); FF_DSR(fa[2][1], ra, 17408);
+    FF_DSR(fb[0][0], rb, 0);     FF_DSR(fb[0][1], rb, 1024);
+    FF_DSR(fb[1][0], rb, 8192);  FF_DSR(fb[1][1], rb, 9216);
+    FF_DSR(fb[2][0], rb, 16384); FF_DSR(fb[2][1], rb, 17408);
+  };
+  auto frags_ready = [&]() {  // lgkmcnt(0), tied to the fragment registers so no MFMA moves above it
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
+                   "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]));
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  auto mfma_frags = [&]() {
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][mi]),
+                                                                __builtin_bit_cast(bf16x8, fb[PB[t]][ni]), acc[mi][ni], 0, 0, 0);
+  };
+
+  int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
+  int e_m0 = 0, e_n0 = 0;
+  auto begin_segment = [&](int p) {
+    int id, j0;
+    segment(p, id, j0, cp_n, cp_kind);
+    cp_cnt = 0;
+    const int rem2 = id % tiles_mn;
+    e_m0 = (rem2 / g.tiles_n) * BM;
+    e_n0 = (rem2 % g.tiles_n) * BN;
+  };
+
+  // prologue: slices 0 and 1 in flight, slice 0 landed
+  issue(0); advance();
+  issue(1); advance();
+  begin_segment(0);
+  __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+  __builtin_amdgcn_s_barrier();
+
+  int b0 = 0, b1 = 1, b2 = 2;
+  const int total_slices = 2 * (u1 - u0);
+  for (int s = 0; s < total_slices; ++s) {
+    read_frags(b0);
+    issue(b2);
+    advance();
+    frags_ready();
+    mfma_frags();
+    if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
+      x3_end_segment(g, acc, cp_kind, lb, k0, e_m0, e_n0);
+      if (++cp_p < nseg) begin_segment(cp_p);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // known-empty counter on the rare path (see gemm_x3_kernel)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): slice s+1 has landed, slice s+2 may still be in flight
+    __builtin_amdgcn_s_barrier();
+    { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // do not leave DMA writes to a dead block's LDS in flight
+}
+
+// Partial-tile workspace: one per (device, stream), as in ff_gemm.hip (64 KB slots here).
+constexpr int X3_MAX_GRID = 512;
+struct X3Workspace {
+  int device;
+  hipStream_t st;
+  float* ws;
+  unsigned int* flags;
+};
+std::mutex g_x3_mu;
+std::vector<X3Workspace> g_x3;
+
+int x3_acquire(hipStream_t st, X3Args* out) {
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_x3_mu);
+  for (X3Workspace& w : g_x3)
+    if (w.device == dev && w.st == st) {
+      out->ws = w.ws; out->flags = w.flags;
+      return FF_OK;
+    }
+  X3Workspace w{dev, st, nullptr, nullptr};
+  FF_CHECK_HIP(hipMalloc(&w.ws, (size_t)X3_MAX_GRID * 128 * 128 * sizeof(float)));
+  FF_CHECK_HIP(hipMalloc(&w.flags, X3_MAX_GRID * sizeof(unsigned int)));
+  FF_CHECK_HIP(hipMemset(w.flags, 0, X3_MAX_GRID * sizeof(unsigned int)));
+  FF_CHECK_HIP(hipDeviceSynchronize());
+  g_x3.push_back(w);
+  out->ws = w.ws; out->flags = w.flags;
+  return FF_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ff_split_weight_bytes(int N, int K) { return (size_t)3 * N * K * sizeof(unsigned short); }
+
+extern "C" int ff_split_weight_bf16x3(const float* W, int ldw, int N, int K, void* planes, ff_stream_t stream) {
+  FF_CHECK_ARG(W && planes && N > 0 && K > 0 && (K & 15) == 0 && ldw >= K, "ff_split_weight_bf16x3: bad arguments (K %% 16)");
+  FF_CHECK_ARG(ff_aligned16(planes), "ff_split_weight_bf16x3: planes must be 16-byte aligned");
+  const size_t n2 = (size_t)N * (K / 2);
+  const int grid = (int)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
+                     static_cast<unsigned short*>(planes));
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+extern "C" int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream) {
+  FF_CHECK_ARG(desc != nullptr, "ff_gemm_x3: null descriptor");
+  const ff_gemm_x3_desc d = *desc;
+  const int M = d.M, N = d.N, K = d.K;
+  if (M == 0 || N == 0) return FF_OK;
+  FF_CHECK_ARG(M > 0 && N > 0 && K >= 64 && (K % 32) == 0, "ff_gemm_x3: bad M=%d N=%d K=%d (K %% 32, K >= 64)", M, N, K);
+  const bool apl = d.A_planes != nullptr;
+  FF_CHECK_ARG((d.A || apl) && d.w_planes && (d.C || d.C_planes), "ff_gemm_x3: null operand");
+  FF_CHECK_ARG(ff_aligned16(d.w_planes) && ((size_t)N * K % 8) == 0, "ff_gemm_x3: weight planes must be 16-byte aligned");
+  if (apl) {
+    FF_CHECK_ARG(d.a_rows >= M && d.a_plane_stride >= (long long)(K / 16) * d.a_rows * 16 && ff_aligned16(d.A_planes) &&
+                     (d.a_plane_stride & 7) == 0 && (!d.A2_planes || ff_aligned16(d.A2_planes)),
+                 "ff_gemm_x3: bad activation planes (a_rows=%d)", d.a_rows);
+  } else {
+    FF_CHECK_ARG((d.lda & 3) == 0 && d.lda >= K && ff_aligned16(d.A) && (!d.A2 || ff_aligned16(d.A2)),
+                 "ff_gemm_x3: A/A2 must be 16-byte aligned with lda %% 4 == 0 (lda=%d)", d.lda);
+  }
+  FF_CHECK_ARG(!d.C || d.ldc >= N, "ff_gemm_x3: bad ldc");
+  FF_CHECK_ARG(!d.C_planes || (d.c_rows >= M && (N % 16) == 0 && d.c_plane_stride >= (long long)(N / 16) * d.c_rows * 16),
+               "ff_gemm_x3: bad output planes (c_rows=%d, N %% 16)", d.c_rows);
+  FF_CHECK_ARG(!d.residual || d.ldr >= N, "ff_gemm_x3: bad ldr");
+  FF_CHECK_ARG(d.act == 0 || d.act == 1, "ff_gemm_x3: act must be 0 or 1");
+  const bool two = apl ? d.A2_planes != nullptr : d.A2 != nullptr;
+  if (two) FF_CHECK_ARG(d.n_split > 0 && d.n_split < N && (d.n_split % 128) == 0, "ff_gemm_x3: n_split must be a multiple of 128 inside (0,N)");
+  hipStream_t st = (hipStream_t)stream;
+  X3Args g;
+  memset(&g, 0, sizeof(g));
+  g.A = d.A; g.A2 = d.A2; g.lda = d.lda;
+  g.Ap = static_cast<const unsigned short*>(d.A_planes); g.Ap2 = static_cast<const unsigned short*>(d.A2_planes);
+  g.a_plane_stride = d.a_plane_stride; g.a_rows = d.a_rows;
+  g.Wp = static_cast<const unsigned short*>(d.w_planes); g.bias = d.bias; g.res = d.residual; g.ldr = d.ldr;
+  g.C = d.C; g.ldc = d.ldc;
+  g.Cp = static_cast<unsigned short*>(d.C_planes); g.c_rows = d.c_rows; g.c_plane_stride = d.c_plane_stride;
+  g.M = M; g.N = N; g.K = K; g.n_split = two ? d.n_split : N; g.act = d.act;
+  g.tiles_m = ff_cdiv(M, 128); g.tiles_n = ff_cdiv(N, 128);
+  g.plane_stride = (long long)N * K;
+  g.upt = K / 32;
+  const long units = (long)g.tiles_m * g.tiles_n * g.upt;
+  FF_CHECK_ARG(units < (1L << 30), "ff_gemm_x3: problem too large");
+  long grid;
+  if (units >= 1024) grid = X3_MAX_GRID;
+  else {
+    grid = ff_cdiv((int)units, 2);
+    if (grid > X3_MAX_GRID / 2) grid = X3_MAX_GRID / 2;
+  }
+  if (grid > units) grid = units;
+  g.base = (int)(units / grid);
+  g.rem = (int)(units % grid);
+  FF_RETURN_IF(x3_acquire(st, &g));
+  static bool attr_set = false;
+  constexpr int bytes = 3 * 3 * 256 * 32;
+  if (!attr_set) {
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3p_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_set = true;
+  }
+  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K, st);
+  if (apl) hipLaunchKernelGGL(gemm_x3p_kernel, dim3((int)grid), dim3(256), bytes, st, g);
+  else hipLaunchKernelGGL(gemm_x3_kernel, dim3((int)grid), dim3(256), bytes, st, g);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
+                          const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
+                          int K, int act, ff_stream_t stream) {
+  ff_gemm_x3_desc d;
+  memset(&d, 0, sizeof(d));
+  d.A = A; d.lda = lda; d.A2 = A2; d.n_split = n_split; d.w_planes = w_planes; d.bias = bias;
+  d.residual = residual; d.ldr = ldr; d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.act = act;
+  return ff_gemm_x3_ex(&d, stream);
+}

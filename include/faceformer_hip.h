@@ -99,6 +99,37 @@ int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
                         int batch, long long stride_a, long long stride_w, long long stride_c,
                         ff_stream_t stream);
 
+/* The same product evaluated on the bf16 matrix cores with fp32 accuracy ("3 x bf16"): every fp32
+ * operand is split exactly into three bf16 terms and the six partial products of weight >= 2^-16 are
+ * accumulated in fp32 (v_mfma_f32_32x32x16_bf16); what is dropped is below one fp32 rounding of the
+ * product, so the error is that of an ordinary fp32 dot product (tests compare both with fp64).
+ * W is given pre-split: ff_split_weight_bf16x3 writes its three planes once per weight tensor
+ * (ff_split_weight_bytes(N, K) bytes; layout [3][K/16][N][16] bf16, i.e. a 16-wide K slice of 32 rows is
+ * one contiguous 1 KB block); activations are split inside the kernel.  K % 32 == 0, K >= 64; n_split % 128 == 0.  Keeps an internal 32 MB partial-tile workspace per
+ * (device, stream).  Same replaced call sites as ff_gemm_f32. */
+size_t ff_split_weight_bytes(int N, int K);
+int ff_split_weight_bf16x3(const float* W, int ldw, int N, int K, void* planes, ff_stream_t stream);
+int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
+               const float* bias, const float* residual, int ldr, float* C, int ldc,
+               int M, int N, int K, int act, ff_stream_t stream);
+
+/* Full form.  The activations may arrive pre-split as well (A_planes: [3][K/16][a_rows][16] bf16, planes
+ * a_plane_stride elements apart -- what ff_layernorm / ff_attention / this function write when asked to):
+ * then nothing passes through registers, all operand bytes reach LDS by global_load_lds DMA.  The result
+ * can be written as fp32 (C), as three planes for the next product (C_planes), or both. */
+typedef struct ff_gemm_x3_desc {
+  const float* A; const float* A2; int lda;           /* fp32 activations, split inside the kernel ... */
+  const void* A_planes; const void* A2_planes;        /* ... or pre-split ones (take precedence)       */
+  int a_rows; long long a_plane_stride;
+  int n_split;                                        /* columns >= n_split use A2 / A2_planes          */
+  const void* w_planes;                               /* ff_split_weight_bf16x3 output                  */
+  const float* bias; const float* residual; int ldr;  /* optional                                       */
+  float* C; int ldc;                                  /* optional fp32 output                           */
+  void* C_planes; int c_rows; long long c_plane_stride; /* optional pre-split output, [3][N/16][c_rows][16] */
+  int M, N, K, act;
+} ff_gemm_x3_desc;
+int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream);
+
 /* Launch-shape tuning of the stream-K kernel (process-wide; tests and tools/): a block is never handed
  * fewer than `min_units` K units (of 64); launches with at least `two_per_cu_units` units use 512
  * blocks (two per CU), smaller ones at most 256; tile 7 cuts tiles only when that saves more than

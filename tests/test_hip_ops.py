@@ -136,6 +136,71 @@ def test_gemm_streamk_splits(ops, M, N, K, batch, min_units, two_per_cu):
         ops.set_gemm_tuning()
 
 
+# ---- GEMM on the bf16 matrix cores (3 x bf16 split) ---------------------------------------------------
+def test_split_weight_is_exact(ops):
+    """The three bf16 planes must reproduce the fp32 weight to 2^-25 relative (exact split)."""
+    w = rnd(200, 512, seed=3) * torch.logspace(-6, 3, 512)  # nine decades of magnitudes
+    planes = ops.split_weight(w.cuda())
+    back = ops.planes_to_matrix(planes).cpu()
+    assert float(((back - w.double()).abs() / w.double().abs().clamp_min(1e-30)).max()) < 2.0 ** -24
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
+                                   (4100, 1024, 512), (64, 260, 512), (130, 96, 64), (2304, 512, 512),
+                                   (9216, 1536, 512)])
+def test_gemm_x3_matches_fp64_like_fp32(ops, M, N, K):
+    """3 x bf16 product vs fp64: bias, ReLU and aliased residual; its error must not exceed the f32-MFMA
+    kernel's by more than a small factor (both are 'fp32 dot product' accurate)."""
+    a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    planes = ops.split_weight(w.cuda())
+    ref0 = a.double() @ w.double().t() + bias.double()
+    out = ops.linear_x3(a.cuda(), planes, bias.cuda())
+    e_x3 = rel_err(out, ref0)
+    e_f32 = rel_err(ops.linear(a.cuda(), w.cuda(), bias.cuda()), ref0)
+    assert e_x3 < 3e-6 and e_x3 < 2.0 * e_f32 + 1e-7
+    x = res.cuda()
+    ops.linear_x3(a.cuda(), planes, bias.cuda(), act=1, residual=x, out=x)
+    assert rel_err(x, torch.relu(ref0) + res.double()) < 3e-6
+    y = res.cuda()
+    ops.linear_x3(a.cuda(), planes, bias.cuda(), act=1, residual=y, out=y)
+    assert torch.equal(x, y)  # deterministic
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
+                                   (4100, 1024, 512), (130, 96, 64), (2304, 512, 512), (9216, 1536, 512)])
+def test_gemm_x3_presplit_activations_and_plane_output(ops, M, N, K):
+    """All-DMA kernel: A given as planes; result also written as planes whose sum is the fp32 result."""
+    a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    planes, ap = ops.split_weight(w.cuda()), ops.split_weight(a.cuda())
+    ref = torch.relu(a.double() @ w.double().t() + bias.double()) + res.double()
+    x = res.cuda()
+    if N % 16:
+        pytest.skip("plane output needs N % 16 == 0")
+    op = torch.zeros((3, N // 16, M, 16), device="cuda", dtype=torch.bfloat16)
+    ops.linear_x3(None, planes, bias.cuda(), act=1, residual=x, out=x, x_planes=ap, out_planes=op)
+    assert rel_err(x, ref) < 3e-6
+    assert float((ops.planes_to_matrix(op) - x.double()).abs().max()) == 0.0
+    y = res.cuda()
+    ops.linear_x3(a.cuda(), planes, bias.cuda(), act=1, residual=y, out=y)
+    assert float((x - y).abs().max()) <= 2e-6 * float(ref.abs().max())  # same products, different split of A
+
+
+def test_gemm_x3_split_a(ops):
+    M, E = 300, 512
+    yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
+    out = ops.linear_x3(yq.cuda(), ops.split_weight(w.cuda()), b.cuda(), x2=y.cuda(), n_split=2 * E)
+    ref = torch.cat([yq.double() @ w[: 2 * E].double().t(), y.double() @ w[2 * E:].double().t()], 1) + b.double()
+    assert rel_err(out, ref) < 3e-6
+
+
+def test_gemm_x3_identity_layout(ops):
+    K = 64
+    eye = torch.eye(K)
+    w = rnd(96, K, seed=9)
+    out = ops.linear_x3(eye.cuda(), ops.split_weight(w.cuda()), None)
+    assert float((out.cpu() - w.t()).abs().max()) < 1e-7
+
+
 # ---- attention --------------------------------------------------------------------------------------
 def ref_attention(q, k, v, mask=None, causal=False):
     """q [G,H,nq,64] k,v [G,H,nk,64] fp64; mask [G,nk] bool"""

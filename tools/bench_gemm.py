@@ -52,8 +52,12 @@ def main():
                 dt = timeit(lambda: ops.linear(a, w, b, act=act, residual=resid, tile=tile, out=out), iters)
                 res.append(flops / dt / 1e12)
                 out.normal_()
+            planes = ops.split_weight(w)
+            dt3 = timeit(lambda: ops.linear_x3(a, planes, b, act=act, residual=resid, out=out), iters)
+            out.normal_()
             dt = timeit(lambda: torch.addmm(b, a, w.t(), out=out), iters)
-            print("%8d %5d %5d | %s | %8.1f" % (M, K, N, " ".join("%10.1f" % r for r in res), flops / dt / 1e12))
+            print("%8d %5d %5d | %s | x3 %6.1f | %8.1f" % (M, K, N, " ".join("%10.1f" % r for r in res),
+                                                         flops / dt3 / 1e12, flops / dt / 1e12))
 
 
 if __name__ == "__main__":
