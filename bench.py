@@ -169,7 +169,7 @@ def main():
         with torch.no_grad():
             model(dict(batch))
         L.check(lib.ff_profile_end(ms, work, cnt, ncat), "ff_profile_end")
-        names = ["gemm_persist_kernel", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops"]
+        names = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops"]
         total_ms = sum(ms)
         ach = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         # HBM bytes per launch of the dominant kernel come from the committed PMC passes
@@ -183,7 +183,8 @@ def main():
                 tj = json.load(f)
             traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
         result["roofline"] = {
-            "kernel": names[0], "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+            "kernel": "f32-MFMA GEMM (gemm_streamk_kernel / gemm_persist_kernel: one 64x64 tiling, two launch shapes)",
+            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
             "alg_bytes_per_launch": None,
