@@ -169,6 +169,8 @@ def main():
         with torch.no_grad():
             model(dict(batch))
         L.check(lib.ff_profile_end(ms, work, cnt, ncat), "ff_profile_end")
+        alg_bytes = (ctypes.c_double * ncat)()
+        L.check(lib.ff_profile_bytes(alg_bytes, ncat), "ff_profile_bytes")
         names = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops"]
         total_ms = sum(ms)
         ach = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
@@ -187,7 +189,7 @@ def main():
             "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-            "alg_bytes_per_launch": None,
+            "alg_bytes_per_launch": alg_bytes[0] / max(1, cnt[0]),
             "launches_per_step": int(cnt[0]), "avg_launch_us": 1e3 * ms[0] / max(1, cnt[0]),
             "alg_flop_per_launch": work[0] / max(1, cnt[0]),
             "share_of_kernel_time": ms[0] / total_ms if total_ms > 0 else None,

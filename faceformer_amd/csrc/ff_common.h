@@ -52,6 +52,7 @@ enum ff_prof_cat { FF_CAT_GEMM = 0, FF_CAT_ATTN = 1, FF_CAT_LN = 2, FF_CAT_POINT
 bool ff_prof_enabled();
 void ff_prof_open(int cat, double work, hipStream_t st);
 void ff_prof_close(hipStream_t st);
+void ff_prof_add_bytes(int cat, double bytes);  // algorithmic bytes of the launch (operands read + results written once)
 struct FFProfScope {
   hipStream_t st;
   bool on;

@@ -985,6 +985,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
   if ((tile == 5 || tile == 8) && !split128) tile = 4;
   hipStream_t st = (hipStream_t)stream;
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
+  ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));
   switch (tile) {
     case 1: return launch_generic<64, 64, 32, 32>(g, batch, st);
     case 2: return launch_pipe<64, 64, 32, 32>(g, batch, st);

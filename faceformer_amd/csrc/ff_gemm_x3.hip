@@ -511,20 +511,19 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
   const unsigned frb = lds0 + (BM + wn0 + l32) * 32 + fchunk;
   u32x4 fa[3][2], fb[3][2];
 #define FF_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  // issue order = consumption order of the products: (a2,b0) | (a1,b1) | (a0,b2)
   auto read_frags = [&](int slot) {
     const unsigned ra = fra + slot * BUF_B, rb = frb + slot * BUF_B;
-    FF_DSR(fa[0][0], ra, 0);     FF_DSR(fa[0][1], ra, 1024);
-    FF_DSR(fa[1][0], ra, 8192);  FF_DSR(fa[1][1], ra, 9216);
     FF_DSR(fa[2][0], ra, 16384); FF_DSR(fa[2][1], ra, 17408);
     FF_DSR(fb[0][0], rb, 0);     FF_DSR(fb[0][1], rb, 1024);
+    FF_DSR(fa[1][0], ra, 8192);  FF_DSR(fa[1][1], ra, 9216);
     FF_DSR(fb[1][0], rb, 8192);  FF_DSR(fb[1][1], rb, 9216);
+    FF_DSR(fa[0][0], ra, 0);     FF_DSR(fa[0][1], ra, 1024);
     FF_DSR(fb[2][0], rb, 16384); FF_DSR(fb[2][1], rb, 17408);
   };
-  auto frags_ready = [&]() {  // lgkmcnt(0), tied to the fragment registers so no MFMA moves above it
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
-                   "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]));
-  };
+  // Counted LDS waits (LDS returns in order and the loop holds no scalar loads): each one is tied to the
+  // fragments it releases so that no MFMA using them can be scheduled above it.
+#define FF_LGKM(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
   f32x16 acc[2][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -532,16 +531,24 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-  auto mfma_frags = [&]() {
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
+  auto product = [&](int pa, int pb) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][mi]),
-                                                                __builtin_bit_cast(bf16x8, fb[PB[t]][ni]), acc[mi][ni], 0, 0, 0);
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][mi]),
+                                                              __builtin_bit_cast(bf16x8, fb[pb][ni]), acc[mi][ni], 0, 0, 0);
+  };
+  auto mfma_frags = [&]() {  // small terms first; the first products start while later fragments are in flight
+    FF_LGKM(8, fa[2][0], fa[2][1], fb[0][0], fb[0][1]);
+    product(2, 0);
+    FF_LGKM(4, fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
+    product(1, 1);
+    FF_LGKM(0, fa[0][0], fa[0][1], fb[2][0], fb[2][1]);
+    product(0, 2);
+    product(1, 0);
+    product(0, 1);
+    product(0, 0);
   };
 
   int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
@@ -568,7 +575,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
     read_frags(b0);
     issue(b2);
     advance();
-    frags_ready();
     mfma_frags();
     if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
       x3_end_segment(g, acc, cp_kind, lb, k0, e_m0, e_n0);

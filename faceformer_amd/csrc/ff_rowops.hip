@@ -35,6 +35,7 @@ struct Profiler {
   std::vector<hipEvent_t> pool;
   size_t next = 0;
   std::vector<ProfRec> recs;
+  double bytes[FF_NUM_CAT] = {0, 0, 0, 0, 0};  // algorithmic operand + result bytes per category
   hipEvent_t get() {
     if (next == pool.size()) {
       hipEvent_t e;
@@ -52,6 +53,9 @@ void ff_prof_open(int cat, double work, hipStream_t st) {
   if (r.a) (void)hipEventRecord(r.a, st);
   g_prof.recs.push_back(r);
 }
+void ff_prof_add_bytes(int cat, double bytes) {
+  if (g_prof.enabled && cat >= 0 && cat < FF_NUM_CAT) g_prof.bytes[cat] += bytes;
+}
 void ff_prof_close(hipStream_t st) {
   if (!g_prof.recs.empty() && g_prof.recs.back().b) (void)hipEventRecord(g_prof.recs.back().b, st);
 }
@@ -59,7 +63,13 @@ void ff_prof_close(hipStream_t st) {
 extern "C" int ff_profile_begin(void) {
   g_prof.recs.clear();
   g_prof.next = 0;
+  for (double& b : g_prof.bytes) b = 0;
   g_prof.enabled = true;
+  return FF_OK;
+}
+
+extern "C" int ff_profile_bytes(double* bytes_by_cat, int ncat) {
+  for (int c = 0; c < ncat; ++c) bytes_by_cat[c] = c < FF_NUM_CAT ? g_prof.bytes[c] : 0.0;
   return FF_OK;
 }
 

@@ -49,6 +49,9 @@ int ff_device_count(void);
  * the summed kernel time [ms], algorithmic work (flops for 0/1/3, bytes for 2/4) and launches. */
 int ff_profile_begin(void);
 int ff_profile_end(double* ms_by_cat, double* work_by_cat, long long* launches_by_cat, int ncat);
+/* Algorithmic bytes (operands read once + results written once) summed per category since the last
+ * ff_profile_begin (only the GEMM category is filled in). */
+int ff_profile_bytes(double* bytes_by_cat, int ncat);
 
 /* ---------------------------------------------------------------------------------------------
  * G2  LayerNorm (+ positional add).  Replaces nn.LayerNorm followed by `with_pos_embed`
