@@ -9,11 +9,13 @@
 // half 0: k 0..15, half 1: k 16..31 of the slice -- any k permutation is legal as long as A and W use
 // the same one) with four 16-byte LDS reads per 32x32 sub-tile.
 //
-// Three kernels, one tiling (256 threads = 4 waves, one per SIMD, each owning 32x32 accumulators):
+// Four kernels, one tiling (256 threads = 4 waves, one per SIMD, each owning 32x32 accumulators):
 //   gemm_generic_kernel  two LDS buffers, staging registers two slices ahead; any K (zero-filled tail).
 //   gemm_pipe_kernel     three-buffer LDS ring + fragment prefetch + MFMA-interleaved issue (below).
-//   gemm_persist_kernel  the same pipeline run over the flat (tile, slice) sequence by a fixed grid:
-//                        the default on the path (K = 512 / 1024).
+//   gemm_persist_kernel  the same pipeline run over the flat (tile, slice) sequence by a fixed grid.
+//   gemm_streamk_kernel  the persistent pipeline over equal ranges of K units instead of whole tiles;
+//                        tiles cut between blocks are summed by the owning block (deterministic).
+//                        The path (K = 512 / 1024) uses the last two, picked per launch by a cost model.
 // What the measurements on MI355X said while building them (tools/gemm_probe_multi.py under rocprofv3,
 // tools/gemm_pmc.sh): a wave issues in order, so LDS / VMEM instructions placed before the dependent
 // MFMA chain delay it while the same instructions placed BETWEEN two MFMAs are free (64-cycle shadow):
