@@ -6,9 +6,11 @@
  * (reference faceformer/trainer.py:20,27-28).  This header is the native layer underneath the
  * drop-in Python modules of `faceformer_amd`: every entry point replaces a group of torch operator
  * call sites of the reference (cited per function), takes plain device pointers / sizes and a
- * hipStream_t, returns 0 on success (negative ff_status otherwise), never allocates device memory
- * and never synchronises the device -- except ff_decode(), which owns the greedy loop and may wait
- * on its own stream every `sync_every` steps to evaluate the reference's stop rule.
+ * hipStream_t, returns 0 on success (negative ff_status otherwise) and never synchronises the device
+ * -- except ff_decode(), which owns the greedy loop and may wait on its own stream every `sync_every`
+ * steps to evaluate the reference's stop rule.  Device memory comes from the caller (workspaces); the
+ * one exception is the partial-tile exchange buffer of the stream-K projection kernels, allocated once
+ * per (device, stream) at the first launch on that stream.
  *
  * All tensors are fp32 row-major unless stated; "ld*" are leading dimensions in ELEMENTS.
  * Pointers must be 16-byte aligned and every ld / K / E a multiple of 4 (float4 access).
