@@ -29,6 +29,7 @@
 //     (slice +2), 5 global loads (slice +4), 24 MFMAs, one barrier;
 //   * equal ranges of 32-wide K units per block, partial tiles (64 KB) handed over through sc1 accesses
 //     and summed by the owning block in ascending block order (deterministic).
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -109,17 +110,18 @@ __device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2]
   const int upt = g.upt;
   {
     if (cp_kind == 1) {  // hand over the raw accumulators: slot[lb][64][tid]
-      float* wp = g.ws + (size_t)lb * (BM * BN) + tid;
-      asm volatile("" : "+v"(wp));  // keep the 64 slot addresses out of the loop-invariant (hoisted, spilled) set
+      // slot[lb][16 quads][256 threads] float4, written / read with 16-byte sc1 accesses (inline asm: the
+      // compiler has no vector form of an agent-coherent access; the loads are fenced by the explicit wait)
+      f32x4* wp = reinterpret_cast<f32x4*>(g.ws + (size_t)lb * (BM * BN)) + tid;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            __hip_atomic_store(wp + ((mi * 2 + ni) * 16 + e) * 256, acc[mi][ni][e], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            acc[mi][ni][e] = 0.f;
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + ((mi * 2 + ni) * 4 + q) * 256), "v"(v) : "memory");
+            acc[mi][ni][4 * q] = 0.f; acc[mi][ni][4 * q + 1] = 0.f; acc[mi][ni][4 * q + 2] = 0.f; acc[mi][ni][4 * q + 3] = 0.f;
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -134,19 +136,20 @@ __device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2]
         while (__hip_atomic_load(g.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
           __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        const float* rp = g.ws + (size_t)c * (BM * BN) + tid;
-        asm volatile("" : "+v"(rp));
+        const f32x4* rp = reinterpret_cast<const f32x4*>(g.ws + (size_t)c * (BM * BN)) + tid;
+        f32x4 t[16];  // all 16 loads in flight before the first use: one memory round trip per contributor
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[q]) : "v"(rp + q * 256) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                       "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            float t[16];
+          for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-              t[e] = __hip_atomic_load(rp + ((mi * 2 + ni) * 16 + e) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] += t[e];
-          }
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] += t[(mi * 2 + ni) * 4 + (e >> 2)][e & 3];
       }
       __syncthreads();  // every thread is past its flag polls
       if (tid < lb - c0) __hip_atomic_store(g.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -447,32 +450,34 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
     }
   };
 
-  // DMA pieces of this wave: d = 6 * wave + i -> plane d / 8, row block d % 8 (32 rows: 4 x A, 4 x W)
+  // DMA pieces of this wave: i = 0..2 are A pieces a = 3 * wave + i (plane a / 4, row block a % 4), i = 3..5
+  // the W pieces of the same numbers.  Running per-lane pointers, bumped by one K block per slice.
   const int prow = lane >> 1;                       // row inside the piece
   const unsigned short* dsrc[6];
   int ddst[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const int d = 6 * wave + i;
-    ddst[i] = (d >> 3) * PLANE_B + (d & 7) * 1024;
+    const int a = 3 * wave + (i % 3);
+    ddst[i] = (a >> 2) * PLANE_B + ((i < 3 ? 0 : 4) + (a & 3)) * 1024;
   }
-  auto set_load_tile = [&](int id) {
+  const long long a_step = (long long)g.a_rows * 16, w_step = (long long)g.N * 16;  // elements per K block
+  auto set_load_tile = [&](int id, int j0) {
     const int rem2 = id % tiles_mn;
     const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
     const unsigned short* Asrc = (g.Ap2 != nullptr && n0 >= g.n_split) ? g.Ap2 : g.Ap;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const int d = 6 * wave + i, plane = d >> 3, rb = d & 7;
-      const int row = (rb & 3) * 32 + prow;                        // row inside the A or W half of the slot
+      const int a = 3 * wave + (i % 3), plane = a >> 2;
+      const int row = (a & 3) * 32 + prow;                         // row inside the A or W half of the slot
       const int chunk = (lane & 1) ^ ((row >> 4) & 1);             // logical 16-byte chunk this lane fetches
-      if (rb < 4) {
+      if (i < 3) {
         int r = m0 + row;
         r = r < g.M ? r : g.M - 1;
-        dsrc[i] = Asrc + plane * g.a_plane_stride + (size_t)r * 16 + chunk * 8;
+        dsrc[i] = Asrc + plane * g.a_plane_stride + j0 * a_step + (size_t)r * 16 + chunk * 8;
       } else {
         int n = n0 + row;
         n = n < g.N ? n : g.N - 1;
-        dsrc[i] = g.Wp + plane * g.plane_stride + (size_t)n * 16 + chunk * 8;
+        dsrc[i] = g.Wp + plane * g.plane_stride + j0 * w_step + (size_t)n * 16 + chunk * 8;
       }
     }
   };
@@ -480,26 +485,30 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
   {
     int tile, j0, n, kind;
     segment(0, tile, j0, n, kind);
-    set_load_tile(tile);
+    set_load_tile(tile, j0);
     ld_j = j0; ld_end = j0 + n;
   }
-  auto issue = [&](int slot) {
-    const size_t ka = (size_t)ld_j * g.a_rows * 16, kw = (size_t)ld_j * g.N * 16;  // k-block stride of A / W planes
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_global_load_lds(dsrc[i] + (((6 * wave + i) & 7) < 4 ? ka : kw),
-                                       (__attribute__((address_space(3))) void*)(lds + slot * BUF_B + ddst[i]), 16, 0, 0);
+  auto issue_piece = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds(dsrc[i], (__attribute__((address_space(3))) void*)(lds + slot * BUF_B + ddst[i]),
+                                     16, 0, 0);
   };
-  auto advance = [&]() {
+  auto issue = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_piece(slot, i);
+  };
+  auto advance = [&]() {  // block-uniform; past the last segment the cursor stays on its last slice
     if (++ld_j == ld_end) {
       if (ld_p + 1 < nseg) {
         int tile, j0, n, kind;
         segment(++ld_p, tile, j0, n, kind);
-        set_load_tile(tile);
+        set_load_tile(tile, j0);
         ld_j = j0; ld_end = j0 + n;
       } else {
         ld_j = ld_end - 1;
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dsrc[i] += (i < 3 ? a_step : w_step);
     }
   };
   // Fragment reads are inline asm: the compiler orders an LDS read it can see after ALL outstanding
@@ -539,16 +548,25 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][mi]),
                                                               __builtin_bit_cast(bf16x8, fb[pb][ni]), acc[mi][ni], 0, 0, 0);
   };
-  auto mfma_frags = [&]() {  // small terms first; the first products start while later fragments are in flight
+  // One slice: small terms first; the first products start while later fragments are still in flight, and
+  // each DMA piece of slice +2 (60-100 issue cycles) goes out behind a group of four MFMAs instead of in
+  // front of the slice.
+  auto mfma_frags = [&](int dma_slot) {
     FF_LGKM(8, fa[2][0], fa[2][1], fb[0][0], fb[0][1]);
     product(2, 0);
+    issue_piece(dma_slot, 0);
     FF_LGKM(4, fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
     product(1, 1);
+    issue_piece(dma_slot, 1);
     FF_LGKM(0, fa[0][0], fa[0][1], fb[2][0], fb[2][1]);
     product(0, 2);
+    issue_piece(dma_slot, 2);
     product(1, 0);
+    issue_piece(dma_slot, 3);
     product(0, 1);
+    issue_piece(dma_slot, 4);
     product(0, 0);
+    issue_piece(dma_slot, 5);
   };
 
   int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
@@ -573,9 +591,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
   const int total_slices = 2 * (u1 - u0);
   for (int s = 0; s < total_slices; ++s) {
     read_frags(b0);
-    issue(b2);
+    mfma_frags(b2);
     advance();
-    mfma_frags();
     if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
       x3_end_segment(g, acc, cp_kind, lb, k0, e_m0, e_n0);
       if (++cp_p < nseg) begin_segment(cp_p);
@@ -672,11 +689,18 @@ extern "C" int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream) {
   g.upt = K / 32;
   const long units = (long)g.tiles_m * g.tiles_n * g.upt;
   FF_CHECK_ARG(units < (1L << 30), "ff_gemm_x3: problem too large");
+  // Launch shape.  A cut tile costs its owner one memory round trip per contributing block (64 KB each),
+  // so small launches cut every tile in two (four below 32 tiles) rather than into many pieces; from 256
+  // tiles on, 512 blocks get equal unit ranges (a tile then spans at most three blocks).
+  const long tiles = (long)g.tiles_m * g.tiles_n;
   long grid;
-  if (units >= 1024) grid = X3_MAX_GRID;
+  if (tiles > X3_MAX_GRID / 2) grid = X3_MAX_GRID;
   else {
-    grid = ff_cdiv((int)units, 2);
-    if (grid > X3_MAX_GRID / 2) grid = X3_MAX_GRID / 2;
+    long sf = tiles <= 32 ? 4 : 2;
+    if (const char* e = getenv("FF_X3_SF")) sf = atoi(e);
+    if (sf > g.upt) sf = g.upt;
+    grid = tiles * sf;
+    if (grid > X3_MAX_GRID) grid = X3_MAX_GRID;
   }
   if (grid > units) grid = units;
   g.base = (int)(units / grid);
