@@ -99,6 +99,10 @@ __global__ void split_weight_kernel(const float* __restrict__ W, int ldw, int N,
   }
 }
 
+// Measured and dropped: one block of eight waves per CU on a 128x256 tile with a four-slot ring (three
+// slices of DMA lead, 25 % fewer operand bytes per MFMA): 132 / 125 / 124 TF/s where the four-wave kernel
+// below reaches 164 / 154 / 146 -- the eight-wave barrier domain costs more than the extra lead buys.
+//
 // End of a segment of the flat (tile, slice) sequence: hand the partial tile over (kind 1), or finish the
 // tile -- after adding the partials of the lower-numbered blocks (kind 2) -- with bias / activation /
 // residual and the store(s).  Shared by both kernels.
