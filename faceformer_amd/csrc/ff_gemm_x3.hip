@@ -29,7 +29,6 @@
 //     (slice +2), 5 global loads (slice +4), 24 MFMAs, one barrier;
 //   * equal ranges of 32-wide K units per block, partial tiles (64 KB) handed over through sc1 accesses
 //     and summed by the owning block in ascending block order (deterministic).
-#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -701,7 +700,6 @@ extern "C" int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream) {
   if (tiles > X3_MAX_GRID / 2) grid = X3_MAX_GRID;
   else {
     long sf = tiles <= 32 ? 4 : 2;
-    if (const char* e = getenv("FF_X3_SF")) sf = atoi(e);
     if (sf > g.upt) sf = g.upt;
     grid = tiles * sf;
     if (grid > X3_MAX_GRID) grid = X3_MAX_GRID;
