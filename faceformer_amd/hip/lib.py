@@ -100,6 +100,8 @@ SIGNATURES = {
     "ff_profile_bytes": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
                                fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "ff_layernorm_planes": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, fptr, C.c_int, C.c_longlong,
+                                      fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,
                              C.c_int, fptr]),
     "ff_gemm_f32": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,

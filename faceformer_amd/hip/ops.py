@@ -254,3 +254,23 @@ def linear_x3(x, planes, bias=None, act=0, residual=None, x2=None, n_split=0, ou
     d.M, d.N, d.K, d.act = M, N, K, act
     _L.check(_L.load().ff_gemm_x3_ex(C.byref(d), _stream()), "ff_gemm_x3")
     return out
+
+
+def layernorm_planes(x, gamma, beta, eps=1e-5, pos=None, pos_div=1, pos_mod=1, want_y=True):
+    """LayerNorm whose result is written as bf16 planes for linear_x3: returns (y_planes, ypos_planes),
+    each [3, E/16, rows, 16] bf16 or None."""
+    x, ldx = _rows(x, "x")
+    rows, E = x.shape
+    _dev(gamma, "gamma"), _dev(beta, "beta")
+    yp = torch.empty((3, E // 16, rows, 16), device=x.device, dtype=torch.bfloat16) if want_y else None
+    yqp, ldpos = None, 0
+    if pos is not None:
+        pos, ldpos = _rows(pos, "pos")
+        yqp = torch.empty((3, E // 16, rows, 16), device=x.device, dtype=torch.bfloat16)
+    stride = (E // 16) * rows * 16
+    _L.check(_L.load().ff_layernorm_planes(_p(x), ldx, _p(gamma), _p(beta), eps,
+                                           yp.data_ptr() if yp is not None else None,
+                                           yqp.data_ptr() if yqp is not None else None, rows, stride,
+                                           _p(pos), ldpos, pos_div, pos_mod, rows, E, _stream()),
+             "ff_layernorm_planes")
+    return yp, yqp

@@ -68,6 +68,14 @@ int ff_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
                  const float* pos, int ldpos, int pos_div, int pos_mod,
                  int rows, int E, ff_stream_t stream);
 
+/* Same LayerNorm, result written pre-split for ff_gemm_x3_ex: y_planes / ypos_planes receive the exact
+ * three-term bf16 split of LN(x) / LN(x)+pos in the K-blocked plane layout [3][E/16][plane_rows][16]
+ * (planes plane_stride elements apart).  E % 16 == 0.  Experimental, with ff_gemm_x3. */
+int ff_layernorm_planes(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                        void* y_planes, void* ypos_planes, int plane_rows, long long plane_stride,
+                        const float* pos, int ldpos, int pos_div, int pos_mod,
+                        int rows, int E, ff_stream_t stream);
+
 /* out[r,:] = x[r,:] + pos[((r / pos_div) % pos_mod), :]   (`memory + pos`, transformer.py:249) */
 int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div, int pos_mod,
                float* out, int ldout, int rows, int E, ff_stream_t stream);

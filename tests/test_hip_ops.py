@@ -185,6 +185,16 @@ def test_gemm_x3_presplit_activations_and_plane_output(ops, M, N, K):
     assert float((x - y).abs().max()) <= 2e-6 * float(ref.abs().max())  # same products, different split of A
 
 
+def test_layernorm_planes_equal_the_fp32_layernorm(ops):
+    """The plane-writing LayerNorm must reproduce the fp32 LayerNorm output bit for bit (exact split)."""
+    rows, E = 77, 512
+    x, g, b, pos = rnd(rows, E, seed=1), rnd(E, seed=2), rnd(E, seed=3), rnd(10, E, seed=4)
+    y, yq = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), pos=pos.cuda(), pos_div=7, pos_mod=10)
+    yp, yqp = ops.layernorm_planes(x.cuda(), g.cuda(), b.cuda(), pos=pos.cuda(), pos_div=7, pos_mod=10)
+    assert float((ops.planes_to_matrix(yp) - y.double()).abs().max()) == 0.0
+    assert float((ops.planes_to_matrix(yqp) - yq.double()).abs().max()) == 0.0
+
+
 def test_gemm_x3_split_a(ops):
     M, E = 300, 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
