@@ -186,8 +186,9 @@ __device__ __forceinline__ void ff_store_split4(f32x4 o, unsigned short* dst, lo
   unsigned h1[4], h2[4], h3[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const unsigned u1 = __builtin_bit_cast(unsigned, o[j]) & 0xffff0000u;
-    const float r1 = o[j] - __builtin_bit_cast(float, u1);
+    const float f = o[j];  // (bit_cast of the vector element itself reads element 0)
+    const unsigned u1 = __builtin_bit_cast(unsigned, f) & 0xffff0000u;
+    const float r1 = f - __builtin_bit_cast(float, u1);
     const unsigned u2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
     const float r2 = r1 - __builtin_bit_cast(float, u2);  // at most 8 significant bits left: exact in bf16
     h1[j] = u1; h2[j] = u2; h3[j] = __builtin_bit_cast(unsigned, r2);
