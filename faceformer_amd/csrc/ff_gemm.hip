@@ -23,7 +23,8 @@
 // not cover an L2 / Infinity-Cache round trip (loads must run >= 2 slices ahead); 64x64 block tiles beat
 // 128x64 / 128x128 at every M of the path because they are the only shape that keeps >= 2 blocks per
 // CU; wave-private tiles (no barrier, 2x the L2 traffic) and in-block split-K lost; barriers and the
-// phase of co-resident blocks do not matter.
+// phase of co-resident blocks do not matter; unpadded XOR-swizzled LDS rows (48 KB per block) with THREE
+// blocks per CU instead of two: 116.6 vs 115.4 TF/s at 8192x1536x512 -- occupancy is not the limit.
 #include <mutex>
 #include <vector>
 
