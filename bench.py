@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams for the micro-batches")
     ap.add_argument("--attn-algo", type=int, default=0, help="ff_attention kernel: 0 auto, 1 LDS-shared, 2 wave")
     ap.add_argument("--gemm-tuning", default="", help="min_units,two_per_cu_units,fix_tenths of ff_set_gemm_tuning")
+    ap.add_argument("--x3-min-rows", type=int, default=0,
+                    help="3 x bf16 projections (fp32-accurate, bf16 matrix cores) on steps with at least this many rows")
     ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")
     ap.add_argument("--cpu-anchors", type=int, default=32, help="anchor sequences in the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch threads for the CPU oracle")
@@ -102,6 +104,7 @@ def main():
     model.chunk_wireframes = args.chunk
     model.chunk_seqs, model.num_streams = args.chunk_seqs, args.streams
     model.sync_every = args.sync_every
+    model.x3_min_rows = args.x3_min_rows
     from faceformer_amd.hip import ops as _ops
     _ops.set_attention_algo(args.attn_algo)
     if args.gemm_tuning:

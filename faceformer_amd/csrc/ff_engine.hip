@@ -100,6 +100,19 @@ int gemm(const float* A, int lda, const float* A2, int n_split, const float* W, 
   return ff_gemm_f32(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, 0, st);
 }
 
+// The same product through the 3 x bf16 kernel when the weight's planes are bound and the launch is in the
+// range where it wins (measured on MI355X: N or K >= 1024 from ~4096 rows on; tools/bench_gemm.py).
+int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, int lda, const float* A2, int n_split,
+               const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M,
+               int N, int K, int act, hipStream_t st) {
+  // x3_min_rows is the threshold of the widest product (N >= 1536: 112 vs 104 TF/s at 4096 rows); the K = 1024
+  // product needs 1.5x and the N = 1024 one 2x as many rows before the larger tiles pay
+  const long need = (long)prm->x3_min_rows * (N >= 1536 ? 2 : (K >= 1024 ? 3 : 4)) / 2;
+  if (planes && prm->x3_min_rows > 0 && M >= need && (K % 32) == 0 && K >= 64 && (!A2 || (n_split % 128) == 0))
+    return ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
+  return gemm(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, st);
+}
+
 // Scratch of one in-flight micro-batch (one set per stream): R = t*Bc active rows, position-major.
 struct Scratch {
   float *x, *y, *yq, *qkv, *o, *h, *p, *logits;
@@ -196,8 +209,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     } else {
       FF_RETURN_IF(ff_layernorm(xin, E, w.norm1_w, w.norm1_b, m->ln_eps, buf.y, E, buf.yq, E, qpos, E, Bc, T,
                                 R, E, st));
-      FF_RETURN_IF(gemm(buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
-                        buf.qkv, 3 * E, R, 3 * E, E, 0, st));
+      FF_RETURN_IF(gemm_or_x3(prm, w.in_proj_planes, buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E,
+                              w.self_attn.in_proj_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, st));
       QKV = buf.qkv;
     }
     // rows that continue through the rest of this layer
@@ -251,10 +264,10 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     // ---- feed forward (transformer.py:253-255) ----
     FF_RETURN_IF(ff_layernorm(buf.x + roff * E, E, w.norm3_w, w.norm3_b, m->ln_eps, buf.y + roff * E, E, nullptr, 0,
                               nullptr, 0, 1, 1, Rl, E, st));
-    FF_RETURN_IF(gemm(buf.y + roff * E, E, nullptr, 0, w.lin1_w, E, w.lin1_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl,
-                      FFd, E, 1, st));
-    FF_RETURN_IF(gemm(buf.h + roff * FFd, FFd, nullptr, 0, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E,
-                      buf.x + roff * E, E, Rl, E, FFd, 0, st));
+    FF_RETURN_IF(gemm_or_x3(prm, w.lin1_planes, buf.y + roff * E, E, nullptr, 0, w.lin1_w, E, w.lin1_b, nullptr, 0,
+                            buf.h + roff * FFd, FFd, Rl, FFd, E, 1, st));
+    FF_RETURN_IF(gemm_or_x3(prm, w.lin2_planes, buf.h + roff * FFd, FFd, nullptr, 0, w.lin2_w, FFd, w.lin2_b,
+                            buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, FFd, 0, st));
   }
   // ---- decoder.norm + project (transformer.py:115-116, model_para.py:225) ----
   if (full_rows) {

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import lib as _L
-from .ops import _dev, _p, _stream
+from .ops import _dev, _p, _stream, split_weight
 
 DEFAULT_FLAGS = _L.FF_REUSE_LAYER0_QKV | _L.FF_LAST_LAYER_LAST_ROW
 
@@ -24,9 +24,10 @@ class PathEngine:
     (SURVEY.md Appendix B).  Tensors are referenced, not copied: in-place weight updates are seen.
     """
 
-    def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5):
+    def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5, bf16_split_planes=False):
         self._lib = _L.load()
         self._keep = {}
+        self._planes = {}
         m = _L.Model()
         get = self._get
         self.tensors = tensors
@@ -71,6 +72,15 @@ class PathEngine:
         m.enc_norm_w, m.enc_norm_b = get("encoder.norm.weight"), get("encoder.norm.bias")
         for i in range(n_dec):
             layer(m.dec[i], "decoder.layers.%d" % i, True)
+            if bf16_split_planes:
+                # three exact bf16 planes per weight (+1.5x their bytes), split once here: lets ff_decode run
+                # q|k|v, linear1 and linear2 of the large steps on the bf16 matrix cores (x3_min_rows);
+                # re-bind after in-place weight updates
+                for field, name in (("in_proj_planes", "self_attn.in_proj_weight"), ("lin1_planes", "linear1.weight"),
+                                    ("lin2_planes", "linear2.weight")):
+                    pl = split_weight(tensors["decoder.layers.%d.%s" % (i, name)])
+                    self._planes[(i, field)] = pl
+                    setattr(m.dec[i], field, pl.data_ptr())
         m.dec_norm_w, m.dec_norm_b = get("decoder.norm.weight"), get("decoder.norm.bias")
         m.proj_w, m.proj_b = get("project.weight"), get("project.bias")
         self.model = m
@@ -118,7 +128,7 @@ class PathEngine:
 
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
                chunk_wireframes=0, chunk_seqs=0, num_streams=1, sync_every=4, flags=DEFAULT_FLAGS,
-               tok_sos=1, tok_eos=3,
+               tok_sos=1, tok_eos=3, x3_min_rows=0,
                trace=False, return_pointer=False, no_stop=False):
         """Greedy decode. Returns dict(predict [N*F, T] int64, steps, [pointer], [trace tensors])."""
         _dev(memory, "memory")
@@ -130,6 +140,7 @@ class PathEngine:
         prm.chunk_seqs, prm.num_streams = chunk_seqs, num_streams
         prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0) | (_L.FF_NO_STOP if no_stop else 0)
         prm.tok_sos, prm.tok_eos = tok_sos, tok_eos
+        prm.x3_min_rows = int(x3_min_rows) if self._planes else 0
         B = N * F
         dev = self.device
         predict = torch.empty((B, T), device=dev, dtype=torch.int64)

@@ -60,6 +60,7 @@ class LayerWeights(C.Structure):
         ("lin1_w", fptr), ("lin1_b", fptr), ("lin2_w", fptr), ("lin2_b", fptr),
         ("norm1_w", fptr), ("norm1_b", fptr), ("norm2_w", fptr), ("norm2_b", fptr),
         ("norm3_w", fptr), ("norm3_b", fptr),
+        ("in_proj_planes", fptr), ("lin1_planes", fptr), ("lin2_planes", fptr),
     ]
 
 
@@ -87,6 +88,7 @@ class DecodeParams(C.Structure):
         ("chunk_wireframes", C.c_int), ("chunk_seqs", C.c_int), ("num_streams", C.c_int),
         ("sync_every", C.c_int), ("flags", C.c_int),
         ("tok_sos", C.c_int), ("tok_eos", C.c_int),
+        ("x3_min_rows", C.c_int),
     ]
 
 

@@ -49,6 +49,7 @@ class SurfaceFormerBase(nn.Module):
         self.chunk_seqs = 0            # >0: split every wireframe into groups of this many sequences
         self.num_streams = 1           # micro-batches are issued round-robin on this many HIP streams
         self.sync_every = 4            # host evaluation period of the stop rule
+        self.x3_min_rows = 0           # >0: q|k|v / FFN projections as 3 x bf16 products from this many rows on
         self._engine_obj = None
 
     def _reset_parameters(self):
@@ -105,7 +106,8 @@ class SurfaceFormerBase(nn.Module):
                     "model parameters are on %s: the faceformer_amd decode path runs only on a ROCm "
                     "device through libfaceformer_hip.so (no CPU fallback). Move the model with "
                     ".cuda()." % dev)
-            eng = PathEngine(tensors, self.num_head, self.num_token, self.encoder.norm.eps)
+            eng = PathEngine(tensors, self.num_head, self.num_token, self.encoder.norm.eps,
+                             bf16_split_planes=self.x3_min_rows > 0)
             self._engine_obj = eng
         return eng
 

@@ -46,6 +46,6 @@ class SurfaceFormer_Parallel(SurfaceFormerBase):
         out = eng.decode(memory, mask, kv_len, _L.FF_PARALLEL, T=T, F=F, num_input=num_input,
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
                          num_streams=self.num_streams, sync_every=self.sync_every,
-                         flags=self.decode_flags, extra_mask=self._extra_mask(inputs))
+                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, extra_mask=self._extra_mask(inputs))
         inputs["predict"] = out["predict"].view(-1, F, T)
         return inputs

@@ -242,6 +242,10 @@ typedef struct ff_layer_weights {
   const float *lin1_w, *lin1_b;        /* [FF, E], [FF] */
   const float *lin2_w, *lin2_b;        /* [E, FF], [E] */
   const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b; /* [E]; norm3: decoder */
+  /* optional (decoder layers): ff_split_weight_bf16x3 planes of self_attn.in_proj_w, lin1_w, lin2_w; when
+     given, ff_decode evaluates these projections with ff_gemm_x3 on steps that have at least
+     ff_decode_params.x3_min_rows prefix rows */
+  const void *in_proj_planes, *lin1_planes, *lin2_planes;
 } ff_layer_weights;
 
 typedef struct ff_model {
@@ -296,6 +300,9 @@ typedef struct ff_decode_params {
   int sync_every;       /* evaluate the stop rule on the host every k steps (<=0: only at the end) */
   int flags;            /* ff_decode_flags */
   int tok_sos, tok_eos; /* seq2seq start / stop tokens */
+  int x3_min_rows;      /* > 0: decoder projections whose weight planes are bound (q|k|v, linear1, linear2)
+                           run on the bf16 matrix cores (3 x bf16 split, fp32 accuracy) when the micro-batch
+                           has at least this many prefix rows (t * sequences); 0: never */
 } ff_decode_params;
 
 /* Greedy pointer decode (a5-a12 of SURVEY.md 8a).

@@ -41,11 +41,13 @@ def run_traced(model, case, batch):
         ni = [int(n) for n in batch["num_input"]]
         out = eng.decode(memory, mask, kv_len, L.FF_PARALLEL, T=T, F=max(ni), num_input=ni, trace=True,
                          extra_mask=extra, sync_every=model.sync_every, flags=model.decode_flags,
+                         x3_min_rows=model.x3_min_rows,
                          chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                          num_streams=model.num_streams)
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          extra_mask=extra, flags=model.decode_flags, return_pointer=True,
+                         x3_min_rows=model.x3_min_rows,
                          chunk_wireframes=model.chunk_wireframes)
     out["memory"] = memory
     return out
@@ -102,6 +104,20 @@ def test_golden_parity(hip_lib, name):
     out = run_traced(model, case, batch_to(batch, "cuda"))
     stats = compare_with_golden(case, z, out)
     print(name, stats)
+
+
+@pytest.mark.parametrize("min_rows", [1, 300])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
+    """The same bars with q|k|v, linear1 and linear2 of the decoder evaluated as 3 x bf16 split products on
+    the bf16 matrix cores (every step: min_rows=1; only the longer prefixes: 300)."""
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    model.x3_min_rows = min_rows
+    out = run_traced(model, case, batch_to(batch, "cuda"))
+    stats = compare_with_golden(case, z, out)
+    print(name, min_rows, stats)
 
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak",
