@@ -106,8 +106,8 @@ int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, 
                const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M,
                int N, int K, int act, hipStream_t st) {
   // x3_min_rows is the threshold of the widest product (N >= 1536: 112 vs 104 TF/s at 4096 rows); the K = 1024
-  // product needs 1.5x and the N = 1024 one 2x as many rows before the larger tiles pay
-  const long need = (long)prm->x3_min_rows * (N >= 1536 ? 2 : (K >= 1024 ? 3 : 4)) / 2;
+  // product needs 1.5x, the N = 1024 one 2x and the N = K = 512 ones 4x as many rows before the larger tiles pay
+  const long need = (long)prm->x3_min_rows * (N >= 1536 ? 2 : (K >= 1024 ? 3 : (N >= 1024 ? 4 : 8))) / 2;
   if (planes && prm->x3_min_rows > 0 && M >= need && (K % 32) == 0 && K >= 64 && (!A2 || (n_split % 128) == 0))
     return ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
   return gemm(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, st);
@@ -230,8 +230,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       d.scale = 0.125f;
       FF_RETURN_IF(ff_attention(&d, st));
     }
-    FF_RETURN_IF(gemm(buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
-                      buf.x + roff * E, E, Rl, E, E, 0, st));
+    FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
+                            w.self_attn.out_b, xin + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
     // ---- cross attention: q = LN2(x) + qpos, k = memory + pos, v = memory (transformer.py:247-252);
     //      K/V come from the per-batch cache ----
     if (last)
@@ -241,8 +241,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       FF_RETURN_IF(ff_layernorm(buf.x, E, w.norm2_w, w.norm2_b, m->ln_eps, nullptr, 0, buf.yq, E, qpos, E, Bc, T,
                                 Rl, E, st));
     float* qc = buf.qkv;  // [rows, E] view of the scratch
-    FF_RETURN_IF(gemm(buf.yq + roff * E, E, nullptr, 0, w.cross_attn.in_proj_w, E, w.cross_attn.in_proj_b, nullptr,
-                      0, qc + roff * E, E, Rl, E, E, 0, st));
+    FF_RETURN_IF(gemm_or_x3(prm, w.cross_q_planes, buf.yq + roff * E, E, nullptr, 0, w.cross_attn.in_proj_w, E,
+                            w.cross_attn.in_proj_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, st));
     {
       ff_attn_desc d;
       memset(&d, 0, sizeof(d));
@@ -259,8 +259,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       d.scale = 0.125f;
       FF_RETURN_IF(ff_attention(&d, st));
     }
-    FF_RETURN_IF(gemm(buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E, w.cross_attn.out_b, buf.x + roff * E, E,
-                      buf.x + roff * E, E, Rl, E, E, 0, st));
+    FF_RETURN_IF(gemm_or_x3(prm, w.cross_out_planes, buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E,
+                            w.cross_attn.out_b, buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
     // ---- feed forward (transformer.py:253-255) ----
     FF_RETURN_IF(ff_layernorm(buf.x + roff * E, E, w.norm3_w, w.norm3_b, m->ln_eps, buf.y + roff * E, E, nullptr, 0,
                               nullptr, 0, 1, 1, Rl, E, st));

@@ -76,9 +76,15 @@ class PathEngine:
                 # three exact bf16 planes per weight (+1.5x their bytes), split once here: lets ff_decode run
                 # q|k|v, linear1 and linear2 of the large steps on the bf16 matrix cores (x3_min_rows);
                 # re-bind after in-place weight updates
+                E_ = E
                 for field, name in (("in_proj_planes", "self_attn.in_proj_weight"), ("lin1_planes", "linear1.weight"),
-                                    ("lin2_planes", "linear2.weight")):
-                    pl = split_weight(tensors["decoder.layers.%d.%s" % (i, name)])
+                                    ("lin2_planes", "linear2.weight"), ("self_out_planes", "self_attn.out_proj.weight"),
+                                    ("cross_q_planes", "multihead_attn.in_proj_weight"),
+                                    ("cross_out_planes", "multihead_attn.out_proj.weight")):
+                    wt = tensors["decoder.layers.%d.%s" % (i, name)]
+                    if field == "cross_q_planes":
+                        wt = wt[:E_]  # q rows only: k|v of the cross attention are projected once per batch
+                    pl = split_weight(wt)
                     self._planes[(i, field)] = pl
                     setattr(m.dec[i], field, pl.data_ptr())
         m.dec_norm_w, m.dec_norm_b = get("decoder.norm.weight"), get("decoder.norm.bias")

@@ -61,6 +61,7 @@ class LayerWeights(C.Structure):
         ("norm1_w", fptr), ("norm1_b", fptr), ("norm2_w", fptr), ("norm2_b", fptr),
         ("norm3_w", fptr), ("norm3_b", fptr),
         ("in_proj_planes", fptr), ("lin1_planes", fptr), ("lin2_planes", fptr),
+        ("self_out_planes", fptr), ("cross_q_planes", fptr), ("cross_out_planes", fptr),
     ]
 
 

@@ -246,6 +246,8 @@ typedef struct ff_layer_weights {
      given, ff_decode evaluates these projections with ff_gemm_x3 on steps that have at least
      ff_decode_params.x3_min_rows prefix rows */
   const void *in_proj_planes, *lin1_planes, *lin2_planes;
+  /* the same for self_attn.out_w, the q rows of cross_attn.in_proj_w ([E, E]) and cross_attn.out_w */
+  const void *self_out_planes, *cross_q_planes, *cross_out_planes;
 } ff_layer_weights;
 
 typedef struct ff_model {
