@@ -245,8 +245,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
   // W (bf16 planes): thread (wr, wh) loads 8 bf16 of row wr in each of the three planes
   const int wr = tid >> 1, wh = tid & 1;
   const float* a_ptr[2];
-  const unsigned short* w_ptr;
-  auto set_load_tile = [&](int id) {
+  const unsigned short* w_ptr[3];  // per plane, advanced by one K block per slice
+  const long long w_step = (long long)g.N * 16;
+  auto set_load_tile = [&](int id, int j0) {
     const int rem2 = id % tiles_mn;
     const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
     const float* Asrc = (g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A;
@@ -258,13 +259,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
     }
     int n = n0 + wr;
     n = n < g.N ? n : g.N - 1;
-    w_ptr = g.Wp + (size_t)n * 16 + wh * 8;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) w_ptr[q] = g.Wp + q * g.plane_stride + j0 * w_step + (size_t)n * 16 + wh * 8;
   };
   int ld_p = 0, ld_j, ld_end;
   {
     int tile, j0, n, kind;
     segment(0, tile, j0, n, kind);
-    set_load_tile(tile);
+    set_load_tile(tile, j0);
     ld_j = j0; ld_end = j0 + n;
   }
   f32x4 sa[2][2];
@@ -274,19 +276,21 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) xa[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + kk0);
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-      xw[q] = *reinterpret_cast<const u32x4*>(w_ptr + q * g.plane_stride + (size_t)ld_j * g.N * 16);
+    for (int q = 0; q < 3; ++q) xw[q] = *reinterpret_cast<const u32x4*>(w_ptr[q]);
   };
   auto advance = [&]() {
     if (++ld_j == ld_end) {
       if (ld_p + 1 < nseg) {
         int tile, j0, n, kind;
         segment(++ld_p, tile, j0, n, kind);
-        set_load_tile(tile);
+        set_load_tile(tile, j0);
         ld_j = j0; ld_end = j0 + n;
       } else {
         ld_j = ld_end - 1;
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) w_ptr[q] += w_step;
     }
   };
   // LDS addresses (bytes inside a ring slot)
@@ -393,7 +397,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
       store_from(sa[u], sw[u], b2);
       load_next(sa[u], sw[u]);
       mfma_frags(fa, fb);
-      hints();
       advance();
       if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
         end_segment();
