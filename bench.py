@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--chunk-seqs", type=int, default=0, help="sequences per intra-wireframe group (0 = off)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams for the micro-batches")
     ap.add_argument("--attn-algo", type=int, default=0, help="ff_attention kernel: 0 auto, 1 LDS-shared, 2 wave")
-    ap.add_argument("--gemm-tuning", default="", help="min_units,two_per_cu_units,fix_tenths of ff_set_gemm_tuning")
+    ap.add_argument("--gemm-tuning", default="", help="min_units,two_per_cu_units,fix_tenths[,small_max_rows] of ff_set_gemm_tuning")
     ap.add_argument("--x3-min-rows", type=int, default=0,
                     help="3 x bf16 projections (fp32-accurate, bf16 matrix cores) on steps with at least this many rows")
     ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")

@@ -896,6 +896,7 @@ std::mutex g_sk_mu;
 std::vector<SkWorkspace> g_sk;
 int g_sk_min_units = 2;      // smallest range handed to a block (units of 64 k)
 int g_sk_two_per_cu = 2048;  // from this many units on, 512 blocks (2 per CU); below, at most 256
+int g_small_max_rows = 1024;  // tile 7 hands launches with at most this many rows to gemm_small_kernel
 double g_sk_fix_units = 2.5;  // what cutting tiles costs a launch, in units of per-CU work (policy only)
 
 int sk_acquire(hipStream_t st, StreamK* out) {
@@ -915,6 +916,89 @@ int sk_acquire(hipStream_t st, StreamK* out) {
   g_sk.push_back(w);
   out->ws = w.ws; out->flags = w.flags;
   return FF_OK;
+}
+
+// ---- small-M kernel: one 32x32 output tile per block, K split over the four waves ---------------------------
+// The first decode steps (and the whole seq2seq variant) launch products with a few hundred rows: every
+// kernel above spends its time in fill (LDS staging, barrier, fragment read), drain, and -- when stream-K cuts
+// the 64x64 tiles -- a cross-block exchange through memory (10-13 us per launch for < 2 us of MFMA work).
+// Here nothing is staged: with K-contiguous operands a lane can load its MFMA operands straight from
+// global memory (row = lane & 31, four consecutive k per 16-byte load; lane half h takes k = 8j + 4h .. +3 of
+// every 8-wide group, the same for A and W), each wave accumulates a quarter of K for the same 32x32 tile,
+// and the four partial tiles meet in 16 KB of LDS; every wave finishes four of the sixteen accumulator rows.
+template <int KQ>  // K / 4 (per-wave K range), a multiple of 8
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+  const int m0 = (blockIdx.x / g.tiles_n) * 32, n0 = (blockIdx.x % g.tiles_n) * 32;
+  const long long bz = blockIdx.y;
+  const float* Asrc = ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + bz * g.batch_stride_a;
+  int row = m0 + l32, col = n0 + l32;
+  row = row < g.M ? row : g.M - 1;
+  col = col < g.N ? col : g.N - 1;
+  const float* ap = Asrc + (size_t)row * g.lda + wave * KQ + half * 4;
+  const float* wp = g.W + bz * g.batch_stride_w + (size_t)col * g.ldw + wave * KQ + half * 4;
+  constexpr int NG = KQ / 8;  // 8-wide k groups per wave
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // groups of 8 loads in flight (64 VGPRs) before their MFMAs
+#pragma unroll
+  for (int g0 = 0; g0 < NG; g0 += 4) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = *reinterpret_cast<const f32x4*>(ap + (g0 + j) * 8);
+      b[j] = *reinterpret_cast<const f32x4*>(wp + (g0 + j) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][c], b[j][c], acc, 0, 0, 0);
+  }
+  // partial tiles -> LDS [wave][reg][lane]; wave w then owns registers 4w .. 4w+3 (rows 8w + 0..3 + 4*half)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
+  __syncthreads();
+  const int ocol = n0 + l32;
+  const bool colok = ocol < g.N;
+  const float bv = (g.bias && colok) ? g.bias[ocol] : 0.f;
+  float* Cout = g.C + bz * g.batch_stride_c;
+  float v[4], rv[4];
+  int orow[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = wave * 4 + q;
+    v[q] = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
+           (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
+    orow[q] = m0 + 8 * wave + q + 4 * half;
+    rv[q] = (g.res && colok && orow[q] < g.M) ? g.res[bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float o = v[q] + bv;
+    if (g.act == 1) o = fmaxf(o, 0.f);
+    o += rv[q];
+    if (colok && orow[q] < g.M) Cout[(size_t)orow[q] * g.ldc + ocol] = o;
+  }
+}
+
+int launch_small(GemmArgs g, int batch, hipStream_t st) {
+  g.tiles_m = ff_cdiv(g.M, 32);
+  g.tiles_n = ff_cdiv(g.N, 32);
+  const dim3 grid(g.tiles_m * g.tiles_n, batch);
+  switch (g.K) {
+    case 512: hipLaunchKernelGGL(gemm_small_kernel<128>, grid, dim3(256), 0, st, g); break;
+    case 1024: hipLaunchKernelGGL(gemm_small_kernel<256>, grid, dim3(256), 0, st, g); break;
+    case 128: hipLaunchKernelGGL(gemm_small_kernel<32>, grid, dim3(256), 0, st, g); break;
+    case 256: hipLaunchKernelGGL(gemm_small_kernel<64>, grid, dim3(256), 0, st, g); break;
+    default: ff_set_error("ff_gemm_f32: small-M kernel supports K in {128, 256, 512, 1024}"); return FF_ERR_ARG;
+  }
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+bool small_ok(const GemmArgs& g) {
+  return (g.K == 128 || g.K == 256 || g.K == 512 || g.K == 1024) && (!g.A2 || (g.n_split % 32) == 0);
 }
 
 // mode 0: whole tiles (persistent kernel) or equal unit ranges, whichever the cost model prefers; 2: unit ranges
@@ -953,12 +1037,14 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
 
 }  // namespace
 
-extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths) {
-  FF_CHECK_ARG(min_units >= 1 && two_per_cu_units >= 1 && fix_tenths >= 0, "ff_set_gemm_tuning: bad arguments");
+extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths, int small_max_rows) {
+  FF_CHECK_ARG(min_units >= 1 && two_per_cu_units >= 1 && fix_tenths >= 0 && small_max_rows >= 0,
+               "ff_set_gemm_tuning: bad arguments");
   std::lock_guard<std::mutex> lock(g_sk_mu);
   g_sk_min_units = min_units;
   g_sk_two_per_cu = two_per_cu_units;
   g_sk_fix_units = 0.1 * fix_tenths;
+  g_small_max_rows = small_max_rows;
   return FF_OK;
 }
 
@@ -976,7 +1062,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 8, "ff_gemm_f32: tile must be 0..8");
+  FF_CHECK_ARG(tile >= 0 && tile <= 9, "ff_gemm_f32: tile must be 0..9");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
@@ -995,7 +1081,12 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
     case 3: return launch_persist(g, batch, st);
     case 4: return launch_pipe<128, 64, 64, 32>(g, batch, st);
     case 6: return launch_streamk(g, batch, st, 2);
-    case 7: return launch_streamk(g, batch, st, 0);
+    case 7:
+      // few rows, the path's K (512 / 1024): the unstaged split-K kernel (its unshared operand loads cost more
+      // than the staging from ~1000 rows on; with K < 512 a wave's share of K is too short to be worth it)
+      if ((long)M * batch <= g_small_max_rows && K >= 512 && small_ok(g)) return launch_small(g, batch, st);
+      return launch_streamk(g, batch, st, 0);
+    case 9: FF_CHECK_ARG(small_ok(g), "ff_gemm_f32: tile 9 needs K in {128,256,512,1024}"); return launch_small(g, batch, st);
     case 8: return launch_pipe<128, 128, 64, 64, 16>(g, batch, st);
     default: return launch_pipe<128, 128, 64, 64>(g, batch, st);
   }

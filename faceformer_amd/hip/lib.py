@@ -119,7 +119,7 @@ SIGNATURES = {
     "ff_gemm_x3_ex": (C.c_int, [C.POINTER(GemmX3Desc), fptr]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),
-    "ff_set_gemm_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ff_set_gemm_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ff_pointer_argmax": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int,
                                     C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int,
                                     fptr, C.c_int, fptr, C.c_int, fptr]),

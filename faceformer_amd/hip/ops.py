@@ -171,11 +171,11 @@ def set_attention_algo(algo):
     return _L.load().ff_set_attention_algo(int(algo))
 
 
-def set_gemm_tuning(min_units=2, two_per_cu_units=2048, fix_tenths=25):
-    """Launch shape of the stream-K projection kernel (see include/faceformer_hip.h); no arguments =
-    the defaults."""
-    _L.check(_L.load().ff_set_gemm_tuning(int(min_units), int(two_per_cu_units), int(fix_tenths)),
-             "ff_set_gemm_tuning")
+def set_gemm_tuning(min_units=2, two_per_cu_units=2048, fix_tenths=25, small_max_rows=1024):
+    """Launch shape of the stream-K projection kernel and row limit of the small-M kernel (see
+    include/faceformer_hip.h); no arguments = the defaults."""
+    _L.check(_L.load().ff_set_gemm_tuning(int(min_units), int(two_per_cu_units), int(fix_tenths),
+                                          int(small_max_rows)), "ff_set_gemm_tuning")
 
 
 def split_weight(weight):

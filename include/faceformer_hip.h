@@ -93,8 +93,10 @@ int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div
  * (every block gets the same number of 64-wide K units; tiles cut between blocks are summed by the
  * owning block in a fixed order, so results are run-to-run deterministic), 7 = the stream-K kernel
  * with the launch shape (whole tiles or equal unit ranges) chosen per problem by a cost model: the
- * default on the path.  Kernels 6/7 keep an internal 8 MB workspace per (device, stream), allocated
- * at the first launch on that stream.
+ * default on the path; 9 = unstaged split-K kernel for launches with few rows (one 32x32 tile per block,
+ * K in {128, 256, 512, 1024} split over the four waves; 7 hands it every launch of at most 1024 rows).
+ * Kernels 6/7 keep an internal 8 MB workspace per (device, stream), allocated at the first launch on
+ * that stream.
  * ------------------------------------------------------------------------------------------- */
 int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split,
                 const float* W, int ldw, const float* bias,
@@ -146,8 +148,9 @@ int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream);
 /* Launch-shape tuning of the stream-K kernel (process-wide; tests and tools/): a block is never handed
  * fewer than `min_units` K units (of 64); launches with at least `two_per_cu_units` units use 512
  * blocks (two per CU), smaller ones at most 256; tile 7 cuts tiles only when that saves more than
- * `fix_tenths`/10 units of per-CU work. */
-int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths);
+ * `fix_tenths`/10 units of per-CU work; launches of at most `small_max_rows` rows (all problems of a
+ * batched call together) go to the unstaged split-K kernel (0: never). */
+int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths, int small_max_rows);
 
 /* ---------------------------------------------------------------------------------------------
  * G4/G5/G6  Multi-head attention core: softmax(q k^T * scale + mask) v for `num_groups` groups
