@@ -483,10 +483,12 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   FF_CHECK_ARG(blocks < 2147483647L, "ff_attention: grid too large");
   FFProfScope prof(FF_CAT_ATTN, 4.0 * FF_HEAD_DIM * (double)gh * d.nq * d.nk, st);
   // automatic: the wave-independent kernel (with key splitting) wins while the launch cannot fill the
-  // chip (measured crossover on MI355X: ~1500 units of 32 queries); above that the block-shared LDS
-  // staging moves 4x fewer bytes from L2 and is faster.
+  // chip (measured crossover on MI355X: ~1500 units of 32 queries) and for the per-sequence self-attention
+  // (at most two query tiles per group: the block-shared kernel then runs one- or two-wave blocks whose LDS
+  // chunk limits a CU to four of them); above that the block-shared LDS staging moves 4x fewer bytes from L2
+  // and is faster.
   const bool use_wave = g_attention_algo == 2 ||
-                        (g_attention_algo == 0 && gh * ff_cdiv(d.nq, 32) < 1536);
+                        (g_attention_algo == 0 && (gh * ff_cdiv(d.nq, 32) < 1536 || d.nq <= 64));
   if (use_wave) {
     // wave-independent kernel: units = (group, head, 32-query tile); split the key tiles over ks waves
     // when the launch would otherwise leave SIMDs idle (ks | 4, at most one key tile per wave).
