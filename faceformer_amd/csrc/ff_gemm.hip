@@ -1062,7 +1062,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 9, "ff_gemm_f32: tile must be 0..9");
+  FF_CHECK_ARG(tile >= 0 && tile <= 8, "ff_gemm_f32: tile must be 0..8");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
@@ -1071,7 +1071,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
              stride_a, stride_w, stride_c};
   const bool split128 = !A2 || (n_split % 128) == 0;
   if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
-  if ((tile == 5 || tile == 8) && !split128) tile = 4;
+  if (tile == 5 && !split128) tile = 4;
   hipStream_t st = (hipStream_t)stream;
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
   ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));
@@ -1086,8 +1086,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
       // than the staging from ~1000 rows on; with K < 512 a wave's share of K is too short to be worth it)
       if ((long)M * batch <= g_small_max_rows && K >= 512 && small_ok(g)) return launch_small(g, batch, st);
       return launch_streamk(g, batch, st, 0);
-    case 9: FF_CHECK_ARG(small_ok(g), "ff_gemm_f32: tile 9 needs K in {128,256,512,1024}"); return launch_small(g, batch, st);
-    case 8: return launch_pipe<128, 128, 64, 64, 16>(g, batch, st);
+    case 8: FF_CHECK_ARG(small_ok(g), "ff_gemm_f32: tile 8 needs K in {128,256,512,1024}"); return launch_small(g, batch, st);
     default: return launch_pipe<128, 128, 64, 64>(g, batch, st);
   }
 }

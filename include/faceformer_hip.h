@@ -93,7 +93,7 @@ int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div
  * (every block gets the same number of 64-wide K units; tiles cut between blocks are summed by the
  * owning block in a fixed order, so results are run-to-run deterministic), 7 = the stream-K kernel
  * with the launch shape (whole tiles or equal unit ranges) chosen per problem by a cost model: the
- * default on the path; 9 = unstaged split-K kernel for launches with few rows (one 32x32 tile per block,
+ * default on the path; 8 = unstaged split-K kernel for launches with few rows (one 32x32 tile per block,
  * K in {128, 256, 512, 1024} split over the four waves; 7 hands it every launch of at most 1024 rows).
  * Kernels 6/7 keep an internal 8 MB workspace per (device, stream), allocated at the first launch on
  * that stream.

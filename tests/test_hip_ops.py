@@ -139,10 +139,10 @@ def test_gemm_streamk_splits(ops, M, N, K, batch, min_units, two_per_cu):
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024), (64, 260, 512),
                                    (130, 96, 128), (1500, 1024, 512), (31, 33, 256)])
 def test_gemm_small_rows_kernel(ops, M, N, K):
-    """Unstaged split-K kernel for launches with few rows (tile 9; tile 0 picks it up to 1024 rows)."""
+    """Unstaged split-K kernel for launches with few rows (tile 8; tile 0 picks it up to 1024 rows)."""
     a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
     ref0 = a.double() @ w.double().t() + bias.double()
-    for tile in (9, 0):  # tile 0 takes the small kernel for K >= 512 and at most 1024 rows
+    for tile in (8, 0):  # tile 0 takes the small kernel for K >= 512 and at most 1024 rows
         out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), tile=tile)
         assert rel_err(out, ref0) < 3e-6
         x = res.cuda()
@@ -152,7 +152,7 @@ def test_gemm_small_rows_kernel(ops, M, N, K):
     if N % 96 == 0:
         a2 = rnd(M, K, seed=7)
         n_split = 2 * N // 3
-        out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), x2=a2.cuda(), n_split=n_split, tile=9)
+        out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), x2=a2.cuda(), n_split=n_split, tile=8)
         ref = torch.cat([a.double() @ w[:n_split].double().t(), a2.double() @ w[n_split:].double().t()], 1) + bias.double()
         assert rel_err(out, ref) < 3e-6
 
@@ -164,7 +164,7 @@ def test_gemm_small_rows_kernel_batched(ops):
     L = ops._L
     ac, wc = a.cuda(), w.cuda()
     L.check(L.load().ff_gemm_f32_batched(ac.data_ptr(), K, None, 0, wc.data_ptr(), K, None, None, 0,
-                                         out.data_ptr(), N, M, N, K, 0, 9, batch, M * K, N * K, M * N,
+                                         out.data_ptr(), N, M, N, K, 0, 8, batch, M * K, N * K, M * N,
                                          torch.cuda.current_stream().cuda_stream), "ff_gemm_f32_batched")
     assert rel_err(out, a.double() @ w.double().transpose(1, 2)) < 3e-6
 

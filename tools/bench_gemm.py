@@ -28,7 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ts", default="1,2,4,8,12,16,24,36")
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--tiles", default="3,7,9")
+    ap.add_argument("--tiles", default="3,7,8")
     args = ap.parse_args()
     dev = "cuda"
     shapes = [(512, 1536), (512, 512), (512, 1024), (1024, 512)]
