@@ -178,8 +178,9 @@ def test_struct_layouts_match_the_header(hip_lib):
 #include <stdio.h>
 #include "faceformer_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(ff_attn_desc), sizeof(ff_mha_weights), sizeof(ff_layer_weights),
-         sizeof(ff_model), sizeof(ff_decode_params), offsetof(ff_model, dec));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ff_attn_desc), sizeof(ff_mha_weights), sizeof(ff_layer_weights),
+         sizeof(ff_model), sizeof(ff_decode_params), offsetof(ff_model, dec), sizeof(ff_gemm_x3_desc),
+         offsetof(ff_gemm_x3_desc, M));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -188,5 +189,35 @@ int main(void) {
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     got = [ctypes.sizeof(lib.AttnDesc), ctypes.sizeof(lib.MhaWeights), ctypes.sizeof(lib.LayerWeights),
-           ctypes.sizeof(lib.Model), ctypes.sizeof(lib.DecodeParams), lib.Model.dec.offset]
+           ctypes.sizeof(lib.Model), ctypes.sizeof(lib.DecodeParams), lib.Model.dec.offset,
+           ctypes.sizeof(lib.GemmX3Desc), lib.GemmX3Desc.M.offset]
     assert [int(x) for x in out] == got
+
+
+def test_entry_points_reject_bad_arguments_without_touching_the_device(hip_lib):
+    """Argument validation happens before any HIP call: it works (and is tested) on a host without a GPU;
+    the error text names the offending argument."""
+    from faceformer_amd.hip import lib
+    FF_ERR_ARG = -1
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    p += (-p) % 16 or 0
+    # K not a multiple of 4 / null operand / bad tile id
+    assert hip_lib.ff_gemm_f32(p, 8, None, 0, p, 8, None, None, 0, p, 8, 2, 2, 6, 0, 0, None) == FF_ERR_ARG
+    assert b"K" in hip_lib.ff_last_error()
+    assert hip_lib.ff_gemm_f32(None, 8, None, 0, p, 8, None, None, 0, p, 8, 2, 2, 8, 0, 0, None) == FF_ERR_ARG
+    assert hip_lib.ff_gemm_f32(p, 8, None, 0, p, 8, None, None, 0, p, 8, 2, 2, 8, 0, 99, None) == FF_ERR_ARG
+    # empty problems are a no-op, not an error
+    assert hip_lib.ff_gemm_f32(p, 8, None, 0, p, 8, None, None, 0, p, 8, 0, 2, 8, 0, 0, None) == 0
+    # LayerNorm width must be a multiple of 4; attention needs its tensors
+    assert hip_lib.ff_layernorm(p, 8, p, p, 1e-5, p, 8, None, 0, None, 0, 1, 1, 2, 6, None) == FF_ERR_ARG
+    d = lib.AttnDesc()
+    d.num_groups, d.num_heads, d.nq, d.nk = 1, 1, 4, 4
+    assert hip_lib.ff_attention(ctypes.byref(d), None) == FF_ERR_ARG
+    assert hip_lib.ff_attention(None, None) == FF_ERR_ARG
+    # the bf16-split product: K must be a multiple of 32 and at least 64
+    x = lib.GemmX3Desc()
+    x.A, x.lda, x.w_planes, x.C, x.ldc, x.M, x.N, x.K = p, 48, p, p, 8, 2, 2, 48
+    assert hip_lib.ff_gemm_x3_ex(ctypes.byref(x), None) == FF_ERR_ARG
+    assert b"K" in hip_lib.ff_last_error()
+    assert hip_lib.ff_set_gemm_tuning(0, 1, 1, 1) == FF_ERR_ARG
