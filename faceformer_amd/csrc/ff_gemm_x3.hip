@@ -347,23 +347,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[t]][mi], xb[PB[t]][ni], acc[mi][ni], 0, 0, 0);
   };
-  auto hints = [&]() {
-#pragma unroll
-    for (int q = 0; q < 12; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read
-    }
-  };
 
   // ---- compute-side segment state ----
   int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
