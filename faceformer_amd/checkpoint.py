@@ -30,14 +30,51 @@ class _Inert(dict):
             self.update(state)
 
 
+_BUILTINS_OK = {"dict", "list", "set", "frozenset", "tuple", "int", "float", "complex", "str", "bytes", "bytearray",
+                "bool", "slice", "range", "object"}
+_GLOBALS_OK = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "deque"),
+               ("_codecs", "encode"), ("argparse", "Namespace"), ("copyreg", "_reconstructor")}
+
+
+def _torch_global_ok(obj):
+    """Only what torch's own tensor serialisation needs: storage / tensor / parameter classes, dtype, size and
+    device objects, and the `_rebuild_*` helpers -- never an arbitrary callable from the torch namespace."""
+    if isinstance(obj, (torch.dtype,)):
+        return True
+    if isinstance(obj, type):
+        ok = (torch.Tensor, torch.Size, torch.device, torch.dtype, torch.storage.TypedStorage,
+              torch.storage.UntypedStorage)
+        return issubclass(obj, ok) or obj.__name__.endswith("Storage")
+    return callable(obj) and getattr(obj, "__name__", "").startswith("_rebuild")
+
+
 class _Unpickler(pickle.Unpickler):
+    """Allow-list unpickler: a downloaded .ckpt is a pickle and must not be able to import and call arbitrary
+    code.  Config nodes map onto the local CfgNode; tensors / containers / numpy scalars are rebuilt; every
+    other global (Lightning callbacks, loggers, optimiser classes, ...) becomes an inert placeholder."""
+
     def find_class(self, module, name):
         if (module, name) in _CFG_CLASSES:
             return CfgNode
-        try:
+        if module == "builtins":
+            return super().find_class(module, name) if name in _BUILTINS_OK else _Inert
+        if (module, name) in _GLOBALS_OK:
             return super().find_class(module, name)
-        except (ImportError, AttributeError):
+        top = module.split(".")[0]
+        if top == "torch":
+            try:
+                obj = super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return _Inert
+            return obj if _torch_global_ok(obj) else _Inert
+        if top == "numpy":
+            if name in ("_reconstruct", "ndarray", "dtype", "scalar") or module.endswith("multiarray"):
+                try:
+                    return super().find_class(module, name)
+                except (ImportError, AttributeError):
+                    return _Inert
             return _Inert
+        return _Inert
 
 
 _pickle_module = types.ModuleType("faceformer_amd._ckpt_pickle")

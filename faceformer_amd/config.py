@@ -57,10 +57,18 @@ class CfgNode(dict):
         return {"items": dict(self), "frozen": self.is_frozen()}
 
     def __setstate__(self, state):
+        """Own pickles carry {'items', 'frozen'}.  A FOREIGN node (fvcore / yacs `CfgNode`, which
+        checkpoint.py maps onto this class) arrives through the dict-subclass protocol instead: its
+        entries were already stored by SETITEMS and `state` is the instance __dict__ of yacs
+        ({'__immutable__', '__deprecated_keys__', '__renamed_keys__', '__new_allowed__'}); only the
+        immutable flag means anything here."""
         object.__setattr__(self, CfgNode._FROZEN, False)
-        for k, v in state["items"].items():
-            dict.__setitem__(self, k, v)
-        object.__setattr__(self, CfgNode._FROZEN, state["frozen"])
+        if isinstance(state, dict) and "items" in state and "frozen" in state:
+            for k, v in state["items"].items():
+                dict.__setitem__(self, k, v)
+            object.__setattr__(self, CfgNode._FROZEN, bool(state["frozen"]))
+        elif isinstance(state, dict):
+            object.__setattr__(self, CfgNode._FROZEN, bool(state.get("__immutable__", False)))
 
     def __reduce__(self):
         return (CfgNode, (), self.__getstate__())

@@ -15,6 +15,7 @@
 // Sequences b of a micro-batch belong to wireframe w0 + b / F; nothing is replicated per sequence.
 #include <chrono>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "ff_common.h"
@@ -39,26 +40,26 @@ struct Bump {
 size_t bump_bytes(size_t count, size_t elem) { return ff_align_up(count * elem, 256); }
 
 // ---- small kernels -----------------------------------------------------------------------------
-__global__ void init_tokens_kernel(int* tok, int B, int F, const int* num_input, int variant,
-                                   int pad_tok, int sos, int b_off) {
+// Start tokens of one micro-batch: sequence i belongs to wireframe i / Fc of the chunk and is its compact
+// sequence f = f0 + i % Fc.
+__global__ void init_tokens_kernel(int* tok, int Bc, int Fc, int f0, const int* num_input, int variant,
+                                   int pad_tok, int sos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
+  if (i >= Bc) return;
   if (variant == FF_PARALLEL) {
     // anchors = arange(F) per wireframe, WITHOUT the +num_token offset (reference quirk C-3,
     // model_para.py:201); rows >= num_input[w] start from token num_token-1 (model_para.py:204-205)
-    const int b = b_off + i;
-    const int w = b / F, f = b % F;
-    tok[i] = f < num_input[w] ? f : pad_tok;
+    const int f = f0 + i % Fc;
+    tok[i] = f < num_input[i / Fc] ? f : pad_tok;
   } else {
     tok[i] = sos;
   }
 }
 
-// steps_done from the per-step counters, then predict[b, j] (int64) = token or 0 after the stop.
-__global__ void finalize_kernel(const int* __restrict__ tok_all, const int* __restrict__ cnt_ge,
-                                const int* __restrict__ cnt_eq, int variant, int N, int Btot, int T,
-                                int steps_enqueued, int no_stop, int64_t* __restrict__ predict,
-                                int* __restrict__ steps_done_out) {
+// steps_done from the per-step counters (the reference's stop rules, model_para.py:232 / model.py:207-210)
+__global__ void steps_kernel(const int* __restrict__ cnt_ge, const int* __restrict__ cnt_eq, int variant, int N,
+                             int steps_enqueued, int no_stop, int* __restrict__ steps_done_out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
   int steps = steps_enqueued;
   if (no_stop) {
   } else if (variant == FF_PARALLEL) {
@@ -71,12 +72,29 @@ __global__ void finalize_kernel(const int* __restrict__ tok_all, const int* __re
       if (cum == N) { steps = s + 1; break; }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *steps_done_out = steps;
-  const size_t total = (size_t)Btot * T;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / T), j = (int)(i % T);
-    predict[i] = (j <= steps) ? (int64_t)tok_all[(size_t)j * Btot + b] : (int64_t)0;
+  *steps_done_out = steps;
+}
+
+// predict[(w, fo), j] (int64) = token of the compact sequence that stands for output row fo of wireframe w,
+// or 0 after the stop step.  With padding-anchor de-duplication every row fo >= num_input[w] is the ONE
+// padding-anchor sequence stored at compact index num_input[w] (those rows are identical by construction:
+// same start token, same memory, same mask; reference model_para.py:204-205).  One launch per micro-batch:
+// it writes the rows whose compact sequence lives in [f0, f0 + Fc) of its wireframes.
+__global__ void finalize_chunk_kernel(const int* __restrict__ tok_all, int Btot, int T, const int* __restrict__ steps_p,
+                                      const int* __restrict__ num_input, int dedup, int F, int w0, int nw, int Fc,
+                                      int f0, int b0, int64_t* __restrict__ predict, int* __restrict__ seq_of_row) {
+  const int steps = *steps_p;
+  const size_t total = (size_t)nw * F * T;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % T);
+    const int fo = (int)((i / T) % F), wl = (int)(i / ((size_t)T * F));
+    int f = fo;
+    if (dedup) { const int n = num_input[w0 + wl]; f = fo < n ? fo : n; }
+    if (f < f0 || f >= f0 + Fc) continue;
+    const int seq = b0 + wl * Fc + (f - f0);
+    const size_t row = (size_t)(w0 + wl) * F + fo;
+    predict[row * T + j] = (j <= steps) ? (int64_t)tok_all[(size_t)j * Btot + seq] : (int64_t)0;
+    if (seq_of_row && j == 0) seq_of_row[row] = seq;
   }
 }
 
@@ -126,34 +144,72 @@ struct DecodeBuffers {
   int *cnt_ge, *cnt_eq, *steps_dev;
 };
 
-// A micro-batch is a contiguous range [b0, b0 + Bc) of the global sequence index b = w*F + f:
-// either whole wireframes (nw >= 1, Fc = F) or a group of Fc < F sequences of ONE wireframe.
+// A micro-batch is a contiguous range [b0, b0 + Bc) of the COMPACT sequence index: nw >= 1 consecutive
+// wireframes with Fc sequences each (compact sequences [f0, f0 + Fc) of every one of them).  Without
+// padding-anchor de-duplication the compact width of every wireframe is F and b = w*F + f as in the reference.
 struct Chunk {
-  int w0, nw, Fc, b0, Bc, sid;
+  int w0, nw, Fc, f0, b0, Bc, sid;
   float* x0;     // [T, Bc, E]
   float* qkv0;   // [T, Bc, 3E] or null
 };
 
-struct Plan {
-  int cw, cs, ns;       // wireframes per chunk, sequences per sub-wireframe chunk (0: none), streams
-  size_t max_bc;
-};
-
-Plan make_plan(const ff_decode_params* p) {
-  Plan pl;
-  pl.cw = (p->chunk_wireframes <= 0 || p->chunk_wireframes > p->N) ? p->N : p->chunk_wireframes;
-  pl.cs = (p->chunk_seqs > 0 && p->chunk_seqs < p->F) ? p->chunk_seqs : 0;
-  if (pl.cs) pl.cw = 1;
-  pl.ns = p->num_streams < 1 ? 1 : (p->num_streams > FF_MAX_STREAMS ? FF_MAX_STREAMS : p->num_streams);
-  pl.max_bc = pl.cs ? (size_t)pl.cs : (size_t)pl.cw * p->F;
-  return pl;
+// Compact width of wireframe w: its num_input real anchors plus ONE padding-anchor sequence when it has fewer
+// than F (the reference decodes F - num_input identical copies of it, model_para.py:204-205).
+inline int compact_width(const ff_decode_params* p, const int* num_input_host, int w) {
+  if (p->variant != FF_PARALLEL || !(p->flags & FF_DEDUP_PAD_ANCHORS) || !num_input_host) return p->F;
+  int n = num_input_host[w];
+  n = n < 0 ? 0 : n;
+  return n < p->F ? n + 1 : p->F;
 }
 
-size_t layout_decode(const ff_model* m, const ff_decode_params* p, Bump& bp, DecodeBuffers* out) {
+// Micro-batches: consecutive wireframes whose compact widths are within 25 % of the widest one share a chunk
+// (its Fc = the widest; the narrower ones carry a few surplus padding-anchor copies), at most
+// chunk_wireframes of them and at most chunk_max_seqs sequences; chunk_seqs > 0 additionally cuts every
+// wireframe into sequence groups.  Callers that want tight chunks pass the wireframes sorted by edge count
+// (the Python model does).
+void plan_chunks(const ff_decode_params* p, const int* num_input_host, int ns, std::vector<Chunk>* out, int* btot,
+                 int* max_bc) {
+  const int N = p->N;
+  const int cw_lim = (p->chunk_wireframes <= 0 || p->chunk_wireframes > N) ? N : p->chunk_wireframes;
+  int b0 = 0, mx = 0;
+  int w = 0;
+  while (w < N) {
+    int Fm = compact_width(p, num_input_host, w), Fmin = Fm, nw = 1;
+    const bool split = p->chunk_seqs > 0 && p->chunk_seqs < Fm;
+    while (!split && w + nw < N && nw < cw_lim) {
+      const int c = compact_width(p, num_input_host, w + nw);
+      const int nmax = c > Fm ? c : Fm, nmin = c < Fmin ? c : Fmin;
+      if (4 * nmin < 3 * nmax) break;
+      if (p->chunk_max_seqs > 0 && (long)(nw + 1) * nmax > (long)(p->chunk_max_seqs > nmax ? p->chunk_max_seqs : nmax)) break;
+      Fm = nmax; Fmin = nmin; ++nw;
+    }
+    const int fstep = split ? p->chunk_seqs : Fm;
+    for (int f0 = 0; f0 < Fm; f0 += fstep) {
+      Chunk c;
+      c.w0 = w; c.nw = nw; c.f0 = f0;
+      c.Fc = (Fm - f0) < fstep ? (Fm - f0) : fstep;
+      c.b0 = b0; c.Bc = nw * c.Fc;
+      c.sid = (int)(out ? out->size() % (size_t)ns : 0);
+      c.x0 = nullptr; c.qkv0 = nullptr;
+      b0 += c.Bc;
+      mx = c.Bc > mx ? c.Bc : mx;
+      if (out) out->push_back(c);
+    }
+    w += nw;
+  }
+  *btot = b0;
+  *max_bc = mx;
+}
+
+int plan_streams(const ff_decode_params* p) {
+  return p->num_streams < 1 ? 1 : (p->num_streams > FF_MAX_STREAMS ? FF_MAX_STREAMS : p->num_streams);
+}
+
+// Workspace layout for `btot` compact sequences in micro-batches of at most `max_bc`.
+size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, size_t Bch, Bump& bp,
+                     DecodeBuffers* out) {
   const int E = m->E, FFd = m->FF, S = p->L + m->num_token, T = p->T;
-  const size_t Btot = (size_t)p->N * p->F;
-  const Plan pl = make_plan(p);
-  const size_t Bch = pl.max_bc;
+  const int ns = plan_streams(p);
   const size_t Rmax = (size_t)(T - 1 > 0 ? T - 1 : 1) * Bch;
   DecodeBuffers b;
   memset(&b, 0, sizeof(b));
@@ -162,7 +218,7 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, Bump& bp, Dec
   b.x0_all = bp.take<float>((size_t)T * Btot * E);
   b.tok_all = bp.take<int>((size_t)T * Btot);
   b.qkv0_all = (p->flags & FF_REUSE_LAYER0_QKV) ? bp.take<float>((size_t)T * Btot * 3 * E) : nullptr;
-  for (int s = 0; s < pl.ns; ++s) {
+  for (int s = 0; s < ns; ++s) {
     Scratch& c = b.scr[s];
     c.x = bp.take<float>(Rmax * E);
     c.y = bp.take<float>(Rmax * E);
@@ -282,26 +338,35 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   return FF_OK;
 }
 
-// Internal side streams + fork/join events (created once per process).
+// Internal side streams + fork/join events: one pool per device, created on first use.
 struct StreamPool {
   hipStream_t side[FF_MAX_STREAMS];
   hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];
   int created;
   bool events;
 };
-StreamPool g_pool = {{}, nullptr, {}, 0, false};
+constexpr int FF_MAX_DEVICES = 16;
+StreamPool g_pools[FF_MAX_DEVICES];
+std::mutex g_pool_mu;
 
-int pool_get(int n) {
-  if (!g_pool.events) {
-    FF_CHECK_HIP(hipEventCreateWithFlags(&g_pool.fork_ev, hipEventDisableTiming));
+int pool_get(int n, StreamPool** out) {
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  FF_CHECK_ARG(dev >= 0 && dev < FF_MAX_DEVICES, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  StreamPool& pool = g_pools[dev];
+  if (!pool.events) {
+    FF_CHECK_HIP(hipEventCreateWithFlags(&pool.fork_ev, hipEventDisableTiming));
     for (int i = 0; i < FF_MAX_STREAMS; ++i)
-      FF_CHECK_HIP(hipEventCreateWithFlags(&g_pool.join_ev[i], hipEventDisableTiming));
-    g_pool.events = true;
+      FF_CHECK_HIP(hipEventCreateWithFlags(&pool.join_ev[i], hipEventDisableTiming));
+    pool.events = true;
   }
-  while (g_pool.created < n) {
-    FF_CHECK_HIP(hipStreamCreateWithFlags(&g_pool.side[g_pool.created], hipStreamNonBlocking));
-    g_pool.created++;
+  while (pool.created < n) {
+    FF_CHECK_HIP(hipStreamCreateWithFlags(&pool.side[pool.created], hipStreamNonBlocking));
+    FF_RETURN_IF(ff_gemm_prepare_stream(pool.side[pool.created]));
+    pool.created++;
   }
+  *out = &pool;
   return FF_OK;
 }
 
@@ -327,6 +392,7 @@ extern "C" int ff_encode(const ff_model* m, const float* input, const unsigned c
   const int E = m->E, FFd = m->FF, H = m->H, S = L + m->num_token;
   FF_CHECK_ARG(S <= m->pos_len, "ff_encode: S=%d exceeds the position table (%d rows)", S, m->pos_len);
   hipStream_t st = (hipStream_t)stream;
+  FF_RETURN_IF(ff_gemm_prepare_stream(st));
   Bump bp(workspace, workspace_bytes);
   float* h1 = bp.take<float>((size_t)N * L * E);
   float* h2 = bp.take<float>((size_t)N * L * E);
@@ -371,18 +437,20 @@ extern "C" int ff_encode(const ff_model* m, const float* input, const unsigned c
   return FF_OK;
 }
 
-extern "C" size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p) {
+extern "C" size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p, const int* num_input_host) {
   if (!m || !p || p->N <= 0 || p->F <= 0 || p->T <= 0) return 0;
+  int btot = 0, max_bc = 0;
+  plan_chunks(p, num_input_host, 1, nullptr, &btot, &max_bc);
   Bump bp(nullptr, 0);
-  return layout_decode(m, p, bp, nullptr) + 256;
+  return layout_decode(m, p, (size_t)btot, (size_t)max_bc, bp, nullptr) + 256;
 }
 
 extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const float* memory,
                          const unsigned char* mask, const int* kv_len, const int* num_input,
-                         const unsigned char* extra_mask, int64_t* predict, int* steps_done,
-                         int* step_counts, float* pointer_out, float* trace_logits, float* trace_best,
-                         float* trace_second, void* workspace, size_t workspace_bytes,
-                         ff_stream_t stream) {
+                         const int* num_input_host, const unsigned char* extra_mask, int64_t* predict,
+                         int* steps_done, int* step_counts, float* pointer_out, float* trace_logits,
+                         float* trace_best, float* trace_second, int* seq_of_row, void* workspace,
+                         size_t workspace_bytes, ff_stream_t stream) {
   FF_RETURN_IF(check_model(m));
   FF_CHECK_ARG(p != nullptr, "ff_decode: null params");
   FF_CHECK_ARG(p->variant == FF_PARALLEL || p->variant == FF_SEQ2SEQ, "ff_decode: bad variant");
@@ -395,122 +463,137 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_CHECK_ARG(T - 1 <= m->qpos_len, "ff_decode: T-1=%d exceeds the query position table (%d rows)", T - 1, m->qpos_len);
   FF_CHECK_ARG(p->variant != FF_PARALLEL || F <= S, "ff_decode: F=%d anchors exceed S=%d", F, S);
   FF_CHECK_ARG(!(p->flags & FF_RETURN_POINTER) || pointer_out, "ff_decode: pointer_out required");
+  // every padding-anchor sequence has its own row of an extra mask: no de-duplication then
+  ff_decode_params prm_local = *p;
+  if (extra_mask) prm_local.flags &= ~FF_DEDUP_PAD_ANCHORS;
+  p = &prm_local;
+  const bool dedup = p->variant == FF_PARALLEL && (p->flags & FF_DEDUP_PAD_ANCHORS) && num_input_host;
   hipStream_t main_st = (hipStream_t)stream;
 
+  const int ns_req = plan_streams(p);
+  std::vector<Chunk> chunks;
+  int Btot = 0, max_bc = 0;
+  plan_chunks(p, num_input_host, ns_req, &chunks, &Btot, &max_bc);
   Bump bp(workspace, workspace_bytes);
   DecodeBuffers buf;
-  layout_decode(m, p, bp, &buf);
+  layout_decode(m, p, (size_t)Btot, (size_t)max_bc, bp, &buf);
   if (!bp.ok) { ff_set_error("ff_decode: workspace too small (%zu needed, %zu given)", bp.off, workspace_bytes); return FF_ERR_WORKSPACE; }
-
-  const int Btot = N * F;
-  const Plan pl = make_plan(p);
-  std::vector<Chunk> chunks;
-  for (int w0 = 0; w0 < N; w0 += pl.cw) {
-    const int nw = (N - w0) < pl.cw ? (N - w0) : pl.cw;
-    const int fstep = pl.cs ? pl.cs : F;
-    for (int f0 = 0; f0 < F; f0 += fstep) {
-      Chunk c;
-      c.w0 = w0; c.nw = nw;
-      c.Fc = (F - f0) < fstep ? (F - f0) : fstep;
-      c.b0 = w0 * F + f0;
-      c.Bc = nw * c.Fc;
-      c.sid = (int)(chunks.size() % pl.ns);
-      c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
-      c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
-      chunks.push_back(c);
-    }
+  for (Chunk& c : chunks) {
+    c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
+    c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
   }
-  const int ns = pl.ns < (int)chunks.size() ? pl.ns : (int)chunks.size();
+  const int ns = ns_req < (int)chunks.size() ? ns_req : (int)chunks.size();
   // With more than one stream ALL micro-batch work runs on the internal pool (the caller's stream is
   // often the legacy default stream, whose implicit synchronisation would serialise the others).
   hipStream_t sts[FF_MAX_STREAMS];
   sts[0] = main_st;
+  StreamPool* pool = nullptr;
+  FF_RETURN_IF(ff_gemm_prepare_stream(main_st));
   if (ns > 1) {
-    FF_RETURN_IF(pool_get(ns));
-    for (int s = 0; s < ns; ++s) sts[s] = g_pool.side[s];
+    FF_RETURN_IF(pool_get(ns, &pool));
+    for (int s = 0; s < ns; ++s) sts[s] = pool->side[s];
   }
-
-  // ---- per-batch invariants (main stream): memory + pos, cross-attention K|V of every layer ----
-  const int RS = N * S;
-  FF_RETURN_IF(ff_add_pos(memory, E, m->pos_table, E, 1, S, buf.mem_pos, E, RS, E, main_st));
-  for (int l = 0; l < m->num_dec_layers; ++l) {
-    const ff_mha_weights& c = m->dec[l].cross_attn;
-    FF_RETURN_IF(gemm(buf.mem_pos, E, memory, E, c.in_proj_w + (size_t)E * E, E, c.in_proj_b + E, nullptr, 0,
-                      buf.kvc[l], 2 * E, RS, 2 * E, E, 0, main_st));
-  }
-  FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * T, main_st));
-  FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * T, main_st));
-  // start tokens (anchors / SOS) for every sequence
-  hipLaunchKernelGGL(init_tokens_kernel, dim3(ff_cdiv(Btot, 256)), dim3(256), 0, main_st, buf.tok_all, Btot, F,
-                     num_input, p->variant, m->num_token - 1, p->tok_sos, 0);
-  FF_CHECK_LAUNCH();
-  if (ns > 1) {  // fork
-    FF_CHECK_HIP(hipEventRecord(g_pool.fork_ev, main_st));
-    for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], g_pool.fork_ev, 0));
-  }
-  // first decoder input rows
-  for (const Chunk& c : chunks)
-    FF_RETURN_IF(ff_gather_rows(memory + (size_t)c.w0 * S * E, S, E, buf.tok_all + c.b0, c.Bc, c.Fc, c.x0, E,
-                                sts[c.sid]));
-
   auto sync_all = [&]() -> int {
     for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamSynchronize(sts[s]));
     return FF_OK;
   };
 
-  // ---- greedy loop -----------------------------------------------------------------------------------
-  const int max_steps = T - 1;
-  const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
-  const auto host_t0 = std::chrono::steady_clock::now();
   int enq = 0;
-  std::vector<int> hcnt(T > 0 ? T : 1);
-  bool stopped = false;
-  for (int step = 0; step < max_steps && !stopped; ++step) {
-    const int t = step + 1;
-    for (const Chunk& c : chunks) {
-      hipStream_t st = sts[c.sid];
-      const Scratch& sc = buf.scr[c.sid];
-      FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
-      const size_t trow = (size_t)step * Btot + c.b0;
-      FF_RETURN_IF(ff_pointer_argmax(
-          sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
-          extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,
-          buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
-          trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
-          c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st));
+  // Everything that enqueues work on the side streams sits in this lambda: on ANY failure the streams are
+  // drained before the error is returned (the caller frees the workspace the queued kernels use).
+  auto run = [&]() -> int {
+    // ---- per-batch invariants (main stream): memory + pos, cross-attention K|V of every layer ----
+    const int RS = N * S;
+    FF_RETURN_IF(ff_add_pos(memory, E, m->pos_table, E, 1, S, buf.mem_pos, E, RS, E, main_st));
+    for (int l = 0; l < m->num_dec_layers; ++l) {
+      const ff_mha_weights& c = m->dec[l].cross_attn;
+      FF_RETURN_IF(gemm(buf.mem_pos, E, memory, E, c.in_proj_w + (size_t)E * E, E, c.in_proj_b + E, nullptr, 0,
+                        buf.kvc[l], 2 * E, RS, 2 * E, E, 0, main_st));
     }
-    enq = step + 1;
-    if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
-      FF_RETURN_IF(sync_all());
-      const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
-      FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
-      FF_CHECK_HIP(hipStreamSynchronize(main_st));
-      if (p->variant == FF_PARALLEL) {
-        for (int s = 0; s < enq; ++s) if (hcnt[s] == 0) { stopped = true; break; }
-      } else {
-        int cum = 0;
-        for (int s = 0; s < enq; ++s) { cum += hcnt[s]; if (cum == N) { stopped = true; break; } }
+    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * T, main_st));
+    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * T, main_st));
+    if (ns > 1) {  // fork
+      FF_CHECK_HIP(hipEventRecord(pool->fork_ev, main_st));
+      for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], pool->fork_ev, 0));
+    }
+    // start tokens (anchors / SOS) and first decoder input rows of every micro-batch
+    for (const Chunk& c : chunks) {
+      hipLaunchKernelGGL(init_tokens_kernel, dim3(ff_cdiv(c.Bc, 256)), dim3(256), 0, sts[c.sid], buf.tok_all + c.b0,
+                         c.Bc, c.Fc, c.f0, num_input ? num_input + c.w0 : nullptr, p->variant, m->num_token - 1,
+                         p->tok_sos);
+      FF_CHECK_LAUNCH();
+      FF_RETURN_IF(ff_gather_rows(memory + (size_t)c.w0 * S * E, S, E, buf.tok_all + c.b0, c.Bc, c.Fc, c.x0, E,
+                                  sts[c.sid]));
+    }
+
+    // ---- greedy loop -----------------------------------------------------------------------------------
+    const int max_steps = T - 1;
+    const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
+    const auto host_t0 = std::chrono::steady_clock::now();
+    std::vector<int> hcnt(T > 0 ? T : 1);
+    bool stopped = false;
+    for (int step = 0; step < max_steps && !stopped; ++step) {
+      const int t = step + 1;
+      for (const Chunk& c : chunks) {
+        hipStream_t st = sts[c.sid];
+        const Scratch& sc = buf.scr[c.sid];
+        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
+        const size_t trow = (size_t)step * Btot + c.b0;
+        FF_RETURN_IF(ff_pointer_argmax(
+            sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
+            extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,
+            buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
+            trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
+            c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st));
+      }
+      enq = step + 1;
+      if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
+        FF_RETURN_IF(sync_all());
+        const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
+        FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+        FF_CHECK_HIP(hipStreamSynchronize(main_st));
+        if (p->variant == FF_PARALLEL) {
+          for (int s = 0; s < enq; ++s) if (hcnt[s] == 0) { stopped = true; break; }
+        } else {
+          int cum = 0;
+          for (int s = 0; s < enq; ++s) { cum += hcnt[s]; if (cum == N) { stopped = true; break; } }
+        }
       }
     }
-  }
-  if (dbg_timing) {
-    const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-    FF_CHECK_HIP(hipStreamSynchronize(main_st));
-    const double tot_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-    fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks: %.2f ms; until GPU idle: %.2f ms\n", enq,
-            chunks.size(), host_ms, tot_ms);
-  }
-  if (ns > 1) {  // join
-    for (int s = 0; s < ns; ++s) {
-      FF_CHECK_HIP(hipEventRecord(g_pool.join_ev[s], sts[s]));
-      FF_CHECK_HIP(hipStreamWaitEvent(main_st, g_pool.join_ev[s], 0));
+    if (dbg_timing) {
+      const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+      FF_RETURN_IF(sync_all());
+      const double tot_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+      fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks (%d of %d sequences decoded): %.2f ms; "
+                      "until GPU idle: %.2f ms\n", enq, chunks.size(), Btot, N * F, host_ms, tot_ms);
+    }
+    if (ns > 1) {  // join
+      for (int s = 0; s < ns; ++s) {
+        FF_CHECK_HIP(hipEventRecord(pool->join_ev[s], sts[s]));
+        FF_CHECK_HIP(hipStreamWaitEvent(main_st, pool->join_ev[s], 0));
+      }
+    }
+    return FF_OK;
+  };
+  {
+    const int rc = run();
+    if (rc != FF_OK) {
+      for (int s = 0; s < ns; ++s) (void)hipStreamSynchronize(sts[s]);
+      (void)hipStreamSynchronize(main_st);
+      return rc;
     }
   }
 
-  hipLaunchKernelGGL(finalize_kernel, dim3(ff_cdiv(Btot * T, 256) < 1024 ? ff_cdiv(Btot * T, 256) : 1024),
-                     dim3(256), 0, main_st, buf.tok_all, buf.cnt_ge, buf.cnt_eq, p->variant, N, Btot, T, enq,
-                     (p->flags & FF_NO_STOP) ? 1 : 0, predict, buf.steps_dev);
+  hipLaunchKernelGGL(steps_kernel, dim3(1), dim3(64), 0, main_st, buf.cnt_ge, buf.cnt_eq, p->variant, N, enq,
+                     (p->flags & FF_NO_STOP) ? 1 : 0, buf.steps_dev);
   FF_CHECK_LAUNCH();
+  for (const Chunk& c : chunks) {
+    const long total = (long)c.nw * F * T;
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(finalize_chunk_kernel, dim3(grid), dim3(256), 0, main_st, buf.tok_all, Btot, T, buf.steps_dev,
+                       num_input, dedup ? 1 : 0, F, c.w0, c.nw, c.Fc, c.f0, c.b0, predict, seq_of_row);
+    FF_CHECK_LAUNCH();
+  }
   int steps = 0;
   FF_CHECK_HIP(hipMemcpyAsync(&steps, buf.steps_dev, sizeof(int), hipMemcpyDeviceToHost, main_st));
   if (step_counts && enq > 0)
@@ -523,6 +606,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   //      (SurfaceFormer returns it as inputs['pointer'], reference model.py:217) --------------------
   if ((p->flags & FF_RETURN_POINTER) && steps > 0) {
     FF_CHECK_ARG(m->FF >= m->E, "ff_decode: FF_RETURN_POINTER needs FF >= E");
+    FF_CHECK_ARG(Btot == N * F, "ff_decode: FF_RETURN_POINTER is not available with de-duplicated sequences");
     for (const Chunk& c : chunks) {
       const Scratch& sc = buf.scr[0];
       float* proj_all = sc.h;  // [steps*Bc, E] fits in the FF-wide scratch

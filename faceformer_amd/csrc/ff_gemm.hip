@@ -831,19 +831,25 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   }
 }
 
+// hipFuncSetAttribute is per device: one flag per (kernel, device)
+constexpr int FF_MAX_DEV = 16;
+struct AttrFlags { bool done[FF_MAX_DEV]; };
 template <typename K>
-int set_lds_limit(K kernel, int bytes, bool* done) {
-  if (!*done) {
+int set_lds_limit(K kernel, int bytes, AttrFlags* fl) {
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  const bool track = dev >= 0 && dev < FF_MAX_DEV;
+  if (!track || !fl->done[dev]) {
     FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    *done = true;
+    if (track) fl->done[dev] = true;
   }
   return FF_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_generic(GemmArgs g, int batch, hipStream_t st) {
-  static bool attr_set = false;
+  static AttrFlags attr_set = {};
   constexpr int bytes = 2 * (BM + BN) * 36 * (int)sizeof(float);
   FF_RETURN_IF(set_lds_limit(&gemm_generic_kernel<BM, BN, WM, WN>, bytes, &attr_set));
   g.tiles_m = ff_cdiv(g.M, BM);
@@ -857,7 +863,7 @@ int launch_generic(GemmArgs g, int batch, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch_pipe(GemmArgs g, int batch, hipStream_t st) {
   if (g.K % BK != 0) return launch_generic<BM, BN, WM, WN>(g, batch, st);
-  static bool attr_set = false;
+  static AttrFlags attr_set = {};
   constexpr int bytes = 3 * (BM + BN) * (BK + 4) * (int)sizeof(float);
   FF_RETURN_IF(set_lds_limit(&gemm_pipe_kernel<BM, BN, WM, WN, BK>, bytes, &attr_set));
   g.tiles_m = ff_cdiv(g.M, BM);
@@ -870,7 +876,7 @@ int launch_pipe(GemmArgs g, int batch, hipStream_t st) {
 
 int launch_persist(GemmArgs g, int batch, hipStream_t st) {
   if (g.K % 64 != 0 || g.K < 128) return launch_pipe<64, 64, 32, 32>(g, batch, st);
-  static bool attr_set = false;
+  static AttrFlags attr_set = {};
   constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float);
   FF_RETURN_IF(set_lds_limit(&gemm_persist_kernel, bytes, &attr_set));
   g.tiles_m = ff_cdiv(g.M, 64);
@@ -1004,7 +1010,7 @@ bool small_ok(const GemmArgs& g) {
 // mode 0: whole tiles (persistent kernel) or equal unit ranges, whichever the cost model prefers; 2: unit ranges
 int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   if (g.K % 64 != 0 || g.K < 128) return launch_pipe<64, 64, 32, 32>(g, batch, st);
-  static bool attr_set = false;
+  static AttrFlags attr_set = {};
   constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float);
   FF_RETURN_IF(set_lds_limit(&gemm_streamk_kernel, bytes, &attr_set));
   g.tiles_m = ff_cdiv(g.M, 64);
@@ -1036,6 +1042,11 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
 }
 
 }  // namespace
+
+extern "C" int ff_gemm_prepare_stream(ff_stream_t stream) {
+  StreamK sk;
+  return sk_acquire((hipStream_t)stream, &sk);
+}
 
 extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths, int small_max_rows) {
   FF_CHECK_ARG(min_units >= 1 && two_per_cu_units >= 1 && fix_tenths >= 0 && small_max_rows >= 0,

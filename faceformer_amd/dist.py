@@ -1,6 +1,6 @@
-"""Multi-GPU decode: wireframes are independent, so the batch is sharded by wireframe index (one
-process per GPU) and only RESULTS travel: one `all_gather_into_tensor` of the fixed-shape int32
-token tensor over RCCL/xGMI.  No collective sits on the data path of the kernels.
+"""Multi-GPU decode: wireframes are independent, so the batch is sharded by wireframe (one process per
+GPU) and only RESULTS travel: one `all_gather_into_tensor` of the fixed-shape int32 token tensor over
+RCCL/xGMI.  No collective sits on the data path of the kernels.
 
 The reference has no distributed code; what it fixes is the meaning of the raw
 `predict` tensor, which couples the wireframes of a batch in two places: the padded sequence count
@@ -9,6 +9,15 @@ over ALL sequences of the batch (model_para.py:232).  `decode_sharded` therefore
 shard with the global F, (b) runs all T-1 steps locally without applying a stop rule, (c) sums the
 per-step special-token counters over ranks (tiny all_reduce) and applies the GLOBAL rule, and
 (d) gathers.  The result is identical to the single-GPU tensor for any world size.
+
+Which rank decodes which wireframe (`shard_plan`): equal-sized wireframes are dealt out in contiguous
+blocks; a ragged batch (BASELINE config E: 64..1024 edges) is balanced by decode COST, which grows like
+n^2 (n anchor sequences, each attending to n keys and paying n-independent projections per token):
+longest-processing-time-first over the wireframes sorted by edge count.  Every rank computes the same
+plan from `num_input`, so no extra communication is needed to reassemble the batch order.
+
+A rank may also hold ONLY its own wireframes (`local_shard=True`): then F, the stop-rule counters and the
+wireframe counts are agreed by collectives and the result is the concatenation in rank order.
 """
 import torch
 
@@ -21,6 +30,32 @@ def shard_range(n_items, rank, world):
     per = (n_items + world - 1) // world
     lo = min(n_items, rank * per)
     return lo, min(n_items, lo + per), per
+
+
+def wireframe_cost(n, F=None):
+    """Relative decode cost of a wireframe with n real edges: its decoded sequences (n, plus one shared
+    padding-anchor sequence when n < F) times a per-sequence cost with a fixed part (projections) and a
+    part linear in the key count n + 4 (cross attention, pointer).  The constants come from the FLOP
+    split of SURVEY.md Appendix E (per token-layer: 5.24 MFLOP of projections vs 4*S*E = 2048*S)."""
+    seqs = n + (1 if (F is not None and n < F) else 0)
+    return seqs * (5.24e6 + 2048.0 * (n + 4))
+
+
+def shard_plan(num_input, world, F=None):
+    """Assignment of wireframe indices to ranks: list (one entry per rank) of index lists, each sorted by
+    descending edge count (the order the engine likes: tight micro-batches).  Uniform batches get the
+    contiguous blocks of `shard_range`; ragged ones are balanced by `wireframe_cost` (LPT greedy)."""
+    n_items = len(num_input)
+    if len(set(int(n) for n in num_input)) <= 1:
+        return [list(range(*shard_range(n_items, r, world)[:2])) for r in range(world)]
+    order = sorted(range(n_items), key=lambda i: (-int(num_input[i]), i))
+    load = [0.0] * world
+    plan = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        plan[r].append(i)
+        load[r] += wireframe_cost(int(num_input[i]), F)
+    return plan
 
 
 def gather_predictions(pred, dist_mod, group=None):
@@ -55,36 +90,100 @@ def apply_global_stop(predict, counts, num_wireframes, variant):
     return predict, stop
 
 
-def decode_sharded(model, inputs, dist_mod, group=None):
-    """Decode the FULL batch `inputs` (same dict on every rank) across the ranks of `group`.
-    Returns the dict with 'predict' [N, F, T] (parallel) / [N, T] (seq2seq) for the whole batch on
-    every rank, identical to a single-process `model(inputs)['predict']`."""
+def _decode_local(model, sub, variant, T, F, num_input, extra_rows):
+    """No-stop decode of the wireframes in `sub` with the batch-global F -> (predict [n, F, T], counts)."""
+    parallel = variant == _L.FF_PARALLEL
+    n = sub["input"].size(0)
+    order = list(range(n))
+    if parallel and getattr(model, "sort_by_edges", True) and extra_rows is None and len(set(num_input)) > 1:
+        order = sorted(range(n), key=lambda i: -num_input[i])
+        idx = torch.tensor(order, device=sub["input"].device)
+        sub = {"input": sub["input"].index_select(0, idx), "input_mask": sub["input_mask"].index_select(0, idx)}
+    eng, memory, mask, kv_len = model._encode(sub)
+    out = eng.decode(memory, mask, kv_len, variant, T=T, F=F,
+                     num_input=[num_input[i] for i in order] if parallel else None,
+                     chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
+                     chunk_max_seqs=getattr(model, "chunk_max_seqs", 0),
+                     num_streams=model.num_streams, sync_every=0, flags=model.decode_flags,
+                     x3_min_rows=model.x3_min_rows, extra_mask=extra_rows,
+                     tok_sos=model.token.SOS if not parallel else 1,
+                     tok_eos=model.token.EOS if not parallel else 3, no_stop=True)
+    pred = out["predict"].view(n, F, T)
+    if order != list(range(n)):
+        inv = torch.empty(n, dtype=torch.long, device=pred.device)
+        inv[torch.tensor(order, device=pred.device)] = torch.arange(n, device=pred.device)
+        pred = pred.index_select(0, inv)
+    return pred, out["step_counts"]
+
+
+def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
+    """Decode a batch across the ranks of `group`; returns `inputs` with 'predict' [N, F, T] (parallel) /
+    [N, T] (seq2seq) for the WHOLE batch on every rank, identical to a single-process
+    `model(inputs)['predict']` of that batch.
+
+    local_shard=False: `inputs` is the full batch (same dict on every rank); every rank decodes the
+        wireframes `shard_plan` gives it and only those slices are touched on the device.
+    local_shard=True : `inputs` holds only this rank's wireframes (any number, also zero rows); the batch is
+        their concatenation in rank order.  Also returns inputs['shard_sizes'] (wireframes per rank)."""
     from .models import SurfaceFormer_Parallel
     rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
-    N = inputs["input"].size(0)
-    lo, hi, per = shard_range(N, rank, world)
     parallel = isinstance(model, SurfaceFormer_Parallel)
     variant = _L.FF_PARALLEL if parallel else _L.FF_SEQ2SEQ
     T = model.max_face_length if parallel else model.num_labels
-    num_input = [int(n) for n in inputs["num_input"]] if parallel else None
-    F = max(num_input) if parallel else 1
     dev = next(model.parameters()).device
+    n_here = inputs["input"].size(0)
+    num_input = [int(n) for n in inputs["num_input"]] if parallel else [0] * n_here
+    extra = model._extra_mask(inputs) if hasattr(model, "_extra_mask") else None   # [n*F or n, S] uint8
+
+    if local_shard:
+        meta = torch.tensor([max(num_input) if (parallel and num_input) else 1, n_here], dtype=torch.int64, device=dev)
+        allmeta = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        dist_mod.all_gather_into_tensor(allmeta, meta, group=group)
+        allmeta = allmeta.view(world, 2).tolist()
+        F = max(m[0] for m in allmeta) if parallel else 1
+        sizes = [int(m[1]) for m in allmeta]
+        mine = list(range(n_here))
+        N = sum(sizes)
+        if extra is not None and parallel and extra.size(0) != n_here * F:
+            raise ValueError("extra_mask must have one row per (wireframe, anchor) of the GLOBAL width F=%d" % F)
+    else:
+        N = n_here
+        F = max(num_input) if parallel else 1
+        plan = shard_plan(num_input, world, F) if parallel else \
+            [list(range(*shard_range(N, r, world)[:2])) for r in range(world)]
+        mine = plan[rank]
+        sizes = [len(p) for p in plan]
+    per = max(max(sizes), 1)
+
     local = torch.zeros((per, F, T), dtype=torch.int64, device=dev)
     counts = torch.zeros(max(T - 1, 1), dtype=torch.int64, device=dev)
-    if hi > lo:
-        sub = {"input": inputs["input"][lo:hi], "input_mask": inputs["input_mask"][lo:hi]}
-        eng, memory, mask, kv_len = model._encode(sub)
-        out = eng.decode(memory, mask, kv_len, variant, T=T, F=F,
-                         num_input=num_input[lo:hi] if parallel else None,
-                         chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
-                         num_streams=model.num_streams, sync_every=0, flags=model.decode_flags,
-                         tok_sos=model.token.SOS if not parallel else 1,
-                         tok_eos=model.token.EOS if not parallel else 3, no_stop=True)
-        local[: hi - lo] = out["predict"].view(hi - lo, F, T)
-        c = out["step_counts"]
+    if mine:
+        if local_shard:
+            sub, ni, ex = inputs, num_input, extra
+        else:
+            idx = torch.tensor(mine, device=inputs["input"].device)
+            sub = {"input": inputs["input"].index_select(0, idx), "input_mask": inputs["input_mask"].index_select(0, idx)}
+            ni = [num_input[i] for i in mine]
+            ex = None
+            if extra is not None:
+                rows = extra.view(N, F if parallel else 1, -1).index_select(0, idx.to(extra.device))
+                ex = rows.reshape(-1, extra.size(-1)).contiguous()
+        pred, c = _decode_local(model, sub, variant, T, F, ni, ex)
+        local[: len(mine)] = pred
         counts[: len(c)] = torch.tensor(c, dtype=torch.int64, device=dev)
     dist_mod.all_reduce(counts, group=group)
-    full = gather_predictions(local, dist_mod, group)[:N]
+    gathered = gather_predictions(local, dist_mod, group)          # [world * per, F, T]
+    if local_shard:
+        keep = [r * per + k for r in range(world) for k in range(sizes[r])]
+        full = gathered[torch.tensor(keep, dtype=torch.long, device=gathered.device)] if keep else gathered[:0]
+        inputs["shard_sizes"] = sizes
+    else:
+        full = torch.empty((N, F, T), dtype=torch.int64, device=gathered.device)
+        src = [r * per + k for r in range(world) for k in range(sizes[r])]
+        dst = [i for r in range(world) for i in plan[r]]
+        if dst:
+            full[torch.tensor(dst, dtype=torch.long, device=gathered.device)] = \
+                gathered[torch.tensor(src, dtype=torch.long, device=gathered.device)]
     full, _ = apply_global_stop(full, counts[: T - 1].tolist(), N, variant)
     inputs["predict"] = full if parallel else full.view(N, T)
     return inputs
@@ -92,10 +191,10 @@ def decode_sharded(model, inputs, dist_mod, group=None):
 
 # ---- predicted face-loop JSON over the wire ---------------------------------------------------------
 def gather_json_records(records, dist_mod, group=None, device=None):
-    """All-gather variable-length JSON strings: every rank passes the list of records it owns (in
-    wireframe order) and receives the concatenation over ranks in rank order.  Wire format: per rank a
-    uint8 buffer of [u32 little-endian length | utf-8 bytes]* padded to the longest rank (two
-    collectives: sizes, then one `all_gather_into_tensor` of the padded payload over RCCL/gloo)."""
+    """All-gather variable-length JSON strings: every rank passes the list of records it owns and receives
+    the concatenation over ranks in rank order.  Wire format: per rank a uint8 buffer of
+    [u32 little-endian length | utf-8 bytes]* padded to the longest rank (two collectives: sizes, then one
+    `all_gather_into_tensor` of the padded payload over RCCL/gloo)."""
     import struct
     world = dist_mod.get_world_size(group)
     blob = b"".join(struct.pack("<I", len(b)) + b for b in (r.encode("utf-8") for r in records))
@@ -124,7 +223,7 @@ def gather_json_records(records, dist_mod, group=None, device=None):
 def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominant_directions=None,
                         pairings=None, is_coedge=False, tol=2e-4):
     """decode_sharded + face parsing of the rank's own wireframes + JSON all-gather: every rank returns
-    the list of N per-wireframe JSON records (`edges`, `dominant_directions`, `pred_faces`,
+    the list of N per-wireframe JSON records in batch order (`edges`, `dominant_directions`, `pred_faces`,
     `label_faces`; reference trainer.py:118-136).  `edges[i]` / `dominant_directions[i]` / `pairings[i]`
     are the raw-data entries of wireframe i when available (else the record carries empty lists)."""
     from . import faces as FZ
@@ -132,12 +231,18 @@ def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominan
     out = decode_sharded(model, inputs, dist_mod, group)
     rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
     N = inputs["input"].size(0)
-    lo, hi, _ = shard_range(N, rank, world)
     parallel = isinstance(model, SurfaceFormer_Parallel)
-    pred = out["predict"][lo:hi].cpu().numpy()
-    labels = inputs["label"][lo:hi].cpu().numpy()
+    if parallel:
+        ni = [int(n) for n in inputs["num_input"]]
+        plan = shard_plan(ni, world, max(ni))
+    else:
+        plan = [list(range(*shard_range(N, r, world)[:2])) for r in range(world)]
+    mine = plan[rank]
+    sel = torch.tensor(mine, dtype=torch.long)
+    pred = out["predict"].cpu()[sel].numpy() if mine else []
+    labels = inputs["label"].cpu()[sel].numpy() if mine else []
     recs = []
-    for k, i in enumerate(range(lo, hi)):
+    for k, i in enumerate(mine):
         n = int(inputs["num_input"][i]) if "num_input" in inputs else int((~inputs["input_mask"][i]).sum())
         fn = FZ.parse_parallel_faces if parallel else FZ.parse_faces
         pf, lf = fn(pred[k], labels[k], n, model.token)
@@ -149,4 +254,9 @@ def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominan
             edges[i] if edges is not None else [], dominant_directions[i] if dominant_directions is not None else [],
             m["predictions"], m["labels"])))
     dev = out["predict"].device if dist_mod.get_backend(group) == "nccl" else torch.device("cpu")
-    return gather_json_records(recs, dist_mod, group, device=dev)
+    flat = gather_json_records(recs, dist_mod, group, device=dev)        # rank order
+    order = [i for r in range(world) for i in plan[r]]
+    res = [None] * N
+    for rec, i in zip(flat, order):
+        res[i] = rec
+    return res

@@ -7,7 +7,7 @@ import torch
 from . import lib as _L
 from .ops import _dev, _p, _stream, split_weight
 
-DEFAULT_FLAGS = _L.FF_REUSE_LAYER0_QKV | _L.FF_LAST_LAYER_LAST_ROW
+DEFAULT_FLAGS = _L.FF_REUSE_LAYER0_QKV | _L.FF_LAST_LAYER_LAST_ROW | _L.FF_DEDUP_PAD_ANCHORS
 
 
 def _kv_len_from_mask(mask_u8):
@@ -93,6 +93,10 @@ class PathEngine:
         self.E, self.H, self.num_token = E, num_head, num_token
         self.device = tensors["project.weight"].device
         self._ws = None
+        self._versions = {k: v._version for k, v in self._keep.items()} if self._planes else {}
+        # the stream-K exchange buffer of the launch stream is allocated here, not inside the first decode
+        with torch.cuda.device(self.device):
+            _L.check(self._lib.ff_gemm_prepare_stream(_stream()), "ff_gemm_prepare_stream")
 
     def _get(self, name):
         t = self.tensors[name]
@@ -105,8 +109,16 @@ class PathEngine:
         return t.data_ptr()
 
     def pointers_current(self):
-        """True while every bound tensor still lives at the address captured in the struct."""
-        return all(self.tensors[k].data_ptr() == v.data_ptr() for k, v in self._keep.items())
+        """True while every bound tensor still lives at the address captured in the struct -- and, when
+        derived copies of the weights exist (the bf16 planes), while no bound tensor was updated in place
+        since they were made (load_state_dict / optimizer.step bump `_version`)."""
+        if not all(self.tensors[k].data_ptr() == v.data_ptr() for k, v in self._keep.items()):
+            return False
+        return all(self.tensors[k]._version == ver for k, ver in self._versions.items())
+
+    @property
+    def has_planes(self):
+        return bool(self._planes)
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
@@ -126,53 +138,76 @@ class PathEngine:
         mask_u8 = mask_u8.contiguous()
         kv_len = _kv_len_from_mask(mask_u8)
         memory = torch.empty((N, S, self.E), device=self.device, dtype=torch.float32)
+        self._same_device(inp, "input"), self._same_device(mask_u8, "mask")
         nbytes = self._lib.ff_encode_workspace_bytes(C.byref(self.model), N, L)
         ws = self._workspace(nbytes)
-        _L.check(self._lib.ff_encode(C.byref(self.model), _p(inp), _p(mask_u8), _p(kv_len), N, L,
-                                     _p(memory), _p(ws), ws.numel(), _stream()), "ff_encode")
+        with torch.cuda.device(self.device):   # the C side launches on the CURRENT device / stream
+            _L.check(self._lib.ff_encode(C.byref(self.model), _p(inp), _p(mask_u8), _p(kv_len), N, L,
+                                         _p(memory), _p(ws), ws.numel(), _stream()), "ff_encode")
         return memory, kv_len
+
+    def _same_device(self, t, name):
+        if t is not None and t.device != self.device:
+            raise _L.HipExtensionError("%s is on %s but the engine's weights are on %s" % (name, t.device, self.device))
 
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
                chunk_wireframes=0, chunk_seqs=0, num_streams=1, sync_every=4, flags=DEFAULT_FLAGS,
-               tok_sos=1, tok_eos=3, x3_min_rows=0,
+               tok_sos=1, tok_eos=3, x3_min_rows=0, chunk_max_seqs=0,
                trace=False, return_pointer=False, no_stop=False):
-        """Greedy decode. Returns dict(predict [N*F, T] int64, steps, [pointer], [trace tensors])."""
+        """Greedy decode. Returns dict(predict [N*F, T] int64, steps, decoded_seqs, [pointer], [trace
+        tensors indexed like predict's rows])."""
         _dev(memory, "memory")
+        self._same_device(memory, "memory"), self._same_device(mask_u8, "mask"), self._same_device(kv_len, "kv_len")
         N, S, E = memory.shape
         L = S - self.num_token
         prm = _L.DecodeParams()
         prm.variant, prm.N, prm.L, prm.F, prm.T = variant, N, L, F, T
         prm.chunk_wireframes, prm.sync_every = chunk_wireframes, sync_every
         prm.chunk_seqs, prm.num_streams = chunk_seqs, num_streams
+        prm.chunk_max_seqs = int(chunk_max_seqs)
         prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0) | (_L.FF_NO_STOP if no_stop else 0)
+        if return_pointer:
+            prm.flags &= ~_L.FF_DEDUP_PAD_ANCHORS
         prm.tok_sos, prm.tok_eos = tok_sos, tok_eos
         prm.x3_min_rows = int(x3_min_rows) if self._planes else 0
         B = N * F
         dev = self.device
         predict = torch.empty((B, T), device=dev, dtype=torch.int64)
-        ni = None
+        ni = ni_host = None
         if num_input is not None:
-            ni = torch.as_tensor([int(x) for x in num_input], dtype=torch.int32).to(dev)
+            vals = [int(x) for x in num_input]
+            if len(vals) != N:
+                raise ValueError("num_input has %d entries for %d wireframes" % (len(vals), N))
+            ni_host = (C.c_int * N)(*vals)
+            ni = torch.tensor(vals, dtype=torch.int32).to(dev)
         pointer = torch.zeros((max(T - 1, 1), B, E), device=dev, dtype=torch.float32) if return_pointer else None
-        tl = tb = ts = None
+        tl = tb = ts = rows = None
         if trace:
             tl = torch.full((max(T - 1, 1), B, S), float("nan"), device=dev, dtype=torch.float32)
             tb = torch.full((max(T - 1, 1), B), float("nan"), device=dev, dtype=torch.float32)
             ts = torch.full((max(T - 1, 1), B), float("nan"), device=dev, dtype=torch.float32)
+        rows = torch.empty(B, device=dev, dtype=torch.int32)
         if extra_mask is not None:
             _dev(extra_mask, "extra_mask", torch.uint8)
+            self._same_device(extra_mask, "extra_mask")
             extra_mask = extra_mask.contiguous()
-        nbytes = self._lib.ff_decode_workspace_bytes(C.byref(self.model), C.byref(prm))
+        nbytes = self._lib.ff_decode_workspace_bytes(C.byref(self.model), C.byref(prm), ni_host)
         ws = self._workspace(nbytes)
         steps = C.c_int(0)
         counts = (C.c_int * max(T - 1, 1))()
-        _L.check(self._lib.ff_decode(
-            C.byref(self.model), C.byref(prm), _p(memory), _p(mask_u8), _p(kv_len), _p(ni),
-            _p(extra_mask), _p(predict), C.byref(steps), counts, _p(pointer), _p(tl), _p(tb), _p(ts),
-            _p(ws), ws.numel(), _stream()), "ff_decode")
-        out = {"predict": predict, "steps": steps.value, "step_counts": list(counts)[: steps.value]}
+        with torch.cuda.device(dev):
+            _L.check(self._lib.ff_decode(
+                C.byref(self.model), C.byref(prm), _p(memory), _p(mask_u8), _p(kv_len), _p(ni), ni_host,
+                _p(extra_mask), _p(predict), C.byref(steps), counts, _p(pointer), _p(tl), _p(tb), _p(ts),
+                _p(rows), _p(ws), ws.numel(), _stream()), "ff_decode")
+        out = {"predict": predict, "steps": steps.value, "step_counts": list(counts)[: steps.value],
+               "seq_of_row": rows}
         if return_pointer:
             out["pointer"] = pointer[: steps.value]
         if trace:
-            out["logits"], out["best"], out["second"] = tl, tb, ts
+            # the C side indexes its traces by DECODED sequence (padding-anchor rows share one); expand to
+            # one entry per row of `predict`
+            idx = rows.long()
+            out["decoded_seqs"] = int(idx.max().item()) + 1 if B else 0
+            out["logits"], out["best"], out["second"] = tl[:, idx], tb[:, idx], ts[:, idx]
         return out

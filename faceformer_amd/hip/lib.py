@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libfaceformer_hip.so")
 FF_MAX_LAYERS = 16
 FF_HEAD_DIM = 64
 FF_PARALLEL, FF_SEQ2SEQ = 0, 1
-FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP = 1, 2, 4, 8
+FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP, FF_DEDUP_PAD_ANCHORS = 1, 2, 4, 8, 16
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -89,7 +89,7 @@ class DecodeParams(C.Structure):
         ("chunk_wireframes", C.c_int), ("chunk_seqs", C.c_int), ("num_streams", C.c_int),
         ("sync_every", C.c_int), ("flags", C.c_int),
         ("tok_sos", C.c_int), ("tok_eos", C.c_int),
-        ("x3_min_rows", C.c_int),
+        ("x3_min_rows", C.c_int), ("chunk_max_seqs", C.c_int),
     ]
 
 
@@ -129,10 +129,12 @@ SIGNATURES = {
     "ff_encode_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int, C.c_int]),
     "ff_encode": (C.c_int, [C.POINTER(Model), fptr, fptr, fptr, C.c_int, C.c_int, fptr, fptr,
                             C.c_size_t, fptr]),
-    "ff_decode_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(DecodeParams)]),
-    "ff_decode": (C.c_int, [C.POINTER(Model), C.POINTER(DecodeParams), fptr, fptr, fptr, fptr, fptr,
-                            fptr, C.POINTER(C.c_int), C.POINTER(C.c_int), fptr, fptr, fptr, fptr, fptr,
+    "ff_decode_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(DecodeParams), C.POINTER(C.c_int)]),
+    "ff_decode": (C.c_int, [C.POINTER(Model), C.POINTER(DecodeParams), fptr, fptr, fptr, fptr,
+                            C.POINTER(C.c_int), fptr,
+                            fptr, C.POINTER(C.c_int), C.POINTER(C.c_int), fptr, fptr, fptr, fptr, fptr, fptr,
                             C.c_size_t, fptr]),
+    "ff_gemm_prepare_stream": (C.c_int, [fptr]),
 }
 
 _lib = None

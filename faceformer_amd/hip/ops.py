@@ -10,8 +10,27 @@ import torch
 from . import lib as _L
 
 
+import functools
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def _on_tensor_device(fn):
+    """Run `fn` with the CUDA device of its first device tensor argument made current: the C side launches
+    on the current HIP device and on torch's current stream OF THAT DEVICE, so a tensor on cuda:1 must
+    never be handed over while cuda:0 is current.  Tensors on different devices are rejected."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        devs = {a.device for a in list(args) + list(kwargs.values()) if torch.is_tensor(a) and a.is_cuda}
+        if len(devs) > 1:
+            raise _L.HipExtensionError("%s: tensors on different devices %s" % (fn.__name__, sorted(map(str, devs))))
+        if not devs:
+            return fn(*args, **kwargs)   # the op's own checks reject CPU tensors
+        with torch.cuda.device(next(iter(devs))):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _dev(t, name, dtype=torch.float32):
@@ -40,6 +59,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+@_on_tensor_device
 def layernorm(x, gamma, beta, eps=1e-5, pos=None, pos_div=1, pos_mod=1, want_y=True):
     """(y, ypos): y = LN(x); ypos = y + pos[(row // pos_div) % pos_mod] (None when pos is None)."""
     x, ldx = _rows(x, "x")
@@ -57,6 +77,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pos=None, pos_div=1, pos_mod=1, want_y=T
     return y, ypos
 
 
+@_on_tensor_device
 def add_pos(x, pos, pos_div=1, pos_mod=1):
     x, ldx = _rows(x, "x")
     pos, ldpos = _rows(pos, "pos")
@@ -66,6 +87,7 @@ def add_pos(x, pos, pos_div=1, pos_mod=1):
     return out
 
 
+@_on_tensor_device
 def linear(x, weight, bias=None, act=0, residual=None, x2=None, n_split=0, tile=0, out=None):
     """out = act(xsel @ weight.T + bias) + residual on the f32 matrix cores (F.linear layout)."""
     x, lda = _rows(x, "x")
@@ -92,6 +114,7 @@ def linear(x, weight, bias=None, act=0, residual=None, x2=None, n_split=0, tile=
     return out
 
 
+@_on_tensor_device
 def attention(q, k, v, num_groups, num_heads, nq, nk, q_group_stride, q_inner, q_outer_stride,
               k_group_stride, k_stride, kv_len=None, key_mask=None, causal=False, scale=0.125,
               out=None):
@@ -118,6 +141,7 @@ def attention(q, k, v, num_groups, num_heads, nq, nk, q_group_stride, q_inner, q
     return out
 
 
+@_on_tensor_device
 def pointer_argmax(p, memory, mask=None, kv_len=None, extra_mask=None, seqs_per_group=1,
                    want_logits=False, want_rows=False, counters=None, ge_bound=0, eq_value=0):
     """select_next: returns dict(next, best, second, [logits], [rows])."""
@@ -157,6 +181,7 @@ def pointer_argmax(p, memory, mask=None, kv_len=None, extra_mask=None, seqs_per_
     return out
 
 
+@_on_tensor_device
 def gather_rows(memory, tok, seqs_per_group=1):
     _dev(memory, "memory"), _dev(tok, "tok", torch.int32)
     N, S, E = memory.shape
@@ -178,6 +203,7 @@ def set_gemm_tuning(min_units=2, two_per_cu_units=2048, fix_tenths=25, small_max
                                           int(small_max_rows)), "ff_set_gemm_tuning")
 
 
+@_on_tensor_device
 def split_weight(weight):
     """[N, K] fp32 matrix -> its three bf16 planes in the K-blocked layout [3, K/16, N, 16]
     (planes_to_matrix(planes) == weight up to 2^-25 relative)."""
@@ -202,6 +228,7 @@ def _check_planes(p, what):
         raise ValueError("linear_x3: %s must be a contiguous [3, K/16, rows, 16] bf16 tensor (split_weight)" % what)
 
 
+@_on_tensor_device
 def linear_x3(x, planes, bias=None, act=0, residual=None, x2=None, n_split=0, out=None, x_planes=None,
               x2_planes=None, out_planes=None, want_fp32=True):
     """linear() on the bf16 matrix cores with fp32 accuracy; `planes` comes from split_weight().
@@ -256,6 +283,7 @@ def linear_x3(x, planes, bias=None, act=0, residual=None, x2=None, n_split=0, ou
     return out
 
 
+@_on_tensor_device
 def layernorm_planes(x, gamma, beta, eps=1e-5, pos=None, pos_div=1, pos_mod=1, want_y=True):
     """LayerNorm whose result is written as bf16 planes for linear_x3: returns (y_planes, ypos_planes),
     each [3, E/16, rows, 16] bf16 or None."""

@@ -48,6 +48,8 @@ class SurfaceFormerBase(nn.Module):
         self.chunk_wireframes = 16     # micro-batch size in wireframes (0 = whole batch); 8-32 measured best
         self.chunk_seqs = 0            # >0: split every wireframe into groups of this many sequences
         self.num_streams = 1           # micro-batches are issued round-robin on this many HIP streams
+        self.chunk_max_seqs = 8192     # ... and at most this many sequences per micro-batch of several wireframes
+        self.sort_by_edges = True      # ragged batches: decode the wireframes sorted by edge count (tight micro-batches)
         self.sync_every = 4            # host evaluation period of the stop rule
         self.x3_min_rows = 0           # >0: q|k|v / FFN projections as 3 x bf16 products from this many rows on
         self._engine_obj = None
@@ -98,7 +100,7 @@ class SurfaceFormerBase(nn.Module):
         """PathEngine bound to this module's parameters (rebuilt when they moved, e.g. after .to())."""
         self._check_supported()
         eng = self._engine_obj
-        if eng is None or not eng.pointers_current():
+        if eng is None or not eng.pointers_current() or eng.has_planes != (self.x3_min_rows > 0):
             tensors = {k: v for k, v in self.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             dev = tensors["project.weight"].device
             if dev.type != "cuda":

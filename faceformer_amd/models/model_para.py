@@ -40,12 +40,32 @@ class SurfaceFormer_Parallel(SurfaceFormerBase):
                              "needed" % (label.size(2), T - 1))
         num_input = [int(n) for n in inputs["num_input"]]
         F = max(num_input)
-        eng, memory, mask, kv_len = self._encode(inputs)
-        if len(num_input) != memory.size(0):
-            raise ValueError("num_input has %d entries for a batch of %d" % (len(num_input), memory.size(0)))
-        out = eng.decode(memory, mask, kv_len, _L.FF_PARALLEL, T=T, F=F, num_input=num_input,
+        N = len(num_input)
+        if N != inputs["input"].size(0):
+            raise ValueError("num_input has %d entries for a batch of %d" % (N, inputs["input"].size(0)))
+        extra = self._extra_mask(inputs)
+        # Ragged batch: decode the wireframes sorted by edge count so that a micro-batch holds wireframes of
+        # (nearly) the same width; wireframes are independent, the result rows are put back in batch order.
+        order = None
+        if self.sort_by_edges and extra is None and len(set(num_input)) > 1:
+            order = sorted(range(N), key=lambda i: -num_input[i])
+            idx = torch.tensor(order, device=inputs["input"].device)
+            sub = {"input": inputs["input"].index_select(0, idx), "input_mask": inputs["input_mask"].index_select(0, idx)}
+            eng, memory, mask, kv_len = self._encode(sub)
+            ni = [num_input[i] for i in order]
+        else:
+            eng, memory, mask, kv_len = self._encode(inputs)
+            ni = num_input
+        out = eng.decode(memory, mask, kv_len, _L.FF_PARALLEL, T=T, F=F, num_input=ni,
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
+                         chunk_max_seqs=self.chunk_max_seqs,
                          num_streams=self.num_streams, sync_every=self.sync_every,
-                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, extra_mask=self._extra_mask(inputs))
-        inputs["predict"] = out["predict"].view(-1, F, T)
+                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, extra_mask=extra)
+        pred = out["predict"].view(N, F, T)
+        if order is not None:
+            inv = torch.empty(N, dtype=torch.long, device=pred.device)
+            inv[torch.tensor(order, device=pred.device)] = torch.arange(N, device=pred.device)
+            pred = pred.index_select(0, inv)
+        inputs["predict"] = pred
+        self.last_decode_stats = {"decoded_seqs": sum(min(F, n + 1) for n in num_input), "rows": N * F}
         return inputs

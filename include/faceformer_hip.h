@@ -152,6 +152,11 @@ int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream);
  * batched call together) go to the unstaged split-K kernel (0: never). */
 int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths, int small_max_rows);
 
+/* Allocate the partial-tile exchange buffer of the stream-K kernels for (current device, stream) now
+ * instead of at the first launch (hipMalloc + device synchronisation: keep it out of timed or captured
+ * regions).  ff_decode calls it for the caller's stream and its internal streams before enqueuing. */
+int ff_gemm_prepare_stream(ff_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * G4/G5/G6  Multi-head attention core: softmax(q k^T * scale + mask) v for `num_groups` groups
  * that each share one key/value set, `num_heads` heads of FF_HEAD_DIM columns.  Replaces the
@@ -287,8 +292,12 @@ enum ff_decode_flags {
   FF_REUSE_LAYER0_QKV = 1,   /* layer-0 self-attention q,k,v computed once per filled position */
   FF_LAST_LAYER_LAST_ROW = 2,/* last decoder layer evaluated for the newest position only */
   FF_RETURN_POINTER = 4,     /* also produce project(decoder(...)) for ALL prefix rows of the last step */
-  FF_NO_STOP = 8             /* run all T-1 steps and do not apply the stop rule (multi-GPU: the caller
+  FF_NO_STOP = 8,            /* run all T-1 steps and do not apply the stop rule (multi-GPU: the caller
                                 all-reduces step_counts and applies the GLOBAL rule) */
+  FF_DEDUP_PAD_ANCHORS = 16  /* parallel variant: the F - num_input[w] padding-anchor sequences of a wireframe
+                                (start token num_token-1, reference model_para.py:204-205) are identical by
+                                construction; decode ONE of them and copy its tokens into all those rows of
+                                `predict`.  Needs num_input_host; ignored when an extra mask is given */
 };
 
 typedef struct ff_decode_params {
@@ -308,27 +317,35 @@ typedef struct ff_decode_params {
   int x3_min_rows;      /* > 0: decoder projections whose weight planes are bound (q|k|v, linear1, linear2)
                            run on the bf16 matrix cores (3 x bf16 split, fp32 accuracy) when the micro-batch
                            has at least this many prefix rows (t * sequences); 0: never */
+  int chunk_max_seqs;   /* > 0: a micro-batch of several wireframes holds at most this many sequences
+                           (a single wireframe is never cut by it); 0: no limit */
 } ff_decode_params;
 
 /* Greedy pointer decode (a5-a12 of SURVEY.md 8a).
  *   memory, mask, kv_len : as produced by / given to ff_encode
- *   num_input [N] int32   : real edge count per wireframe (parallel anchors, model_para.py:201-207)
+ *   num_input [N] int32   : DEVICE, real edge count per wireframe (parallel anchors, model_para.py:201-207)
+ *   num_input_host [N]    : the same values on the HOST (plans the micro-batches and the padding-anchor
+ *                           de-duplication); NULL: every wireframe decodes all F sequences
  *   extra_mask            : optional [B, S] uint8 additional pointer mask (co-edge style), or NULL
  *   predict [N*F, T] int64: output tokens incl. the start token, zero padded after the stop step
  *   steps_done            : host int, number of decode steps the reference semantics executed
  *   step_counts           : optional host int[T-1]: per executed step, #{tokens >= num_token} (parallel)
- *                           or #{tokens == EOS} (seq2seq) -- the inputs of the stop rules
+ *                           or #{tokens == EOS} (seq2seq) over the DECODED sequences -- the inputs of the
+ *                           stop rules (with de-duplication a padding-anchor sequence counts once: the
+ *                           parallel rule only tests the count against zero)
  *   pointer_out           : optional [steps_done, N*F, E] (FF_RETURN_POINTER), position-major
- *   trace_logits          : optional [T-1, N*F, S] masked logits of every step (tests), or NULL
- *   trace_best/second     : optional [T-1, N*F] top-2 logits, or NULL
+ *   trace_logits          : optional [T-1, Bd, S] masked logits of every step (tests), or NULL; Bd = number
+ *                           of decoded sequences <= N*F, indexed by the compact sequence id
+ *   trace_best/second     : optional [T-1, Bd] top-2 logits, or NULL (size them for N*F)
+ *   seq_of_row            : optional DEVICE int[N*F]: compact sequence id behind every row of `predict`
  * Stop rules reproduced exactly: parallel = first step whose tokens are all < num_token
  * (model_para.py:232); seq2seq = cumulative EOS count == N (model.py:207-210). */
-size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p);
+size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p, const int* num_input_host);
 int ff_decode(const ff_model* m, const ff_decode_params* p,
               const float* memory, const unsigned char* mask, const int* kv_len,
-              const int* num_input, const unsigned char* extra_mask,
+              const int* num_input, const int* num_input_host, const unsigned char* extra_mask,
               int64_t* predict, int* steps_done, int* step_counts, float* pointer_out,
-              float* trace_logits, float* trace_best, float* trace_second,
+              float* trace_logits, float* trace_best, float* trace_second, int* seq_of_row,
               void* workspace, size_t workspace_bytes, ff_stream_t stream);
 
 #ifdef __cplusplus

@@ -61,4 +61,20 @@ CASES = [
     # configs/seq2seq.yml sizes (config A): L=110, T=259, one 64-edge wireframe
     dict(name="seq_full_A64_gain4", kind="seq2seq", model=_m(FULL, 110, 259), recipe="gain4",
          wseed=0, n_edges=[64], seeds=[3], slow=True),
+    # --- round 2: BASELINE configs C, D, E at the FULL model size ---------------------------------------
+    # config C (per-GPU batch of 256-edge wireframes, ours.yml sizes): four distinct wireframes in ONE
+    # reference batch; the GPU property test decodes a 16-wireframe batch whose first four must
+    # reproduce these rows under every micro-batching
+    dict(name="par_full_C4x256_gain4", kind="parallel", model=_m(FULL, 256, 37), recipe="gain4",
+         wseed=0, n_edges=[256, 256, 256, 256], seeds=[0, 1, 2, 3],
+         keep_logit_rows=[0, 1, 255, 256, 300, 511, 512, 700, 1000, 1023], slow=True),
+    # config D (seq2seq+coedge.yml sizes: L=216, T=259) with the extra pointer mask operand
+    dict(name="seq_full_D216_extramask", kind="seq2seq", model=_m(FULL, 216, 259), recipe="gain4",
+         wseed=1, n_edges=[216], seeds=[5], extra_mask_seed=11, slow=True),
+    # config E (ours-perspective.yml with num_lines=1024, ragged 64..1024 edges): S = 1028 keys, F = 1024
+    # anchor sequences per wireframe of which 960 / 724 are padding anchors in the short wireframes;
+    # max_face_length 4 keeps the imported reference (which replicates memory F times) within minutes
+    dict(name="par_full_E1024_gain4", kind="parallel", model=_m(FULL, 1024, 4), recipe="gain4",
+         wseed=0, n_edges=[1024, 64, 300], seeds=[31, 32, 33],
+         keep_logit_rows=[0, 1, 500, 1023, 1024, 1060, 1087, 1088, 2047, 2048, 2200, 2347, 2348, 3071], slow=True),
 ]

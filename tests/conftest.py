@@ -22,6 +22,17 @@ def has_gpu():
     return torch.cuda.is_available()
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu`-marked tests need a ROCm device: on a host without one a plain `pytest tests` skips them (with the
+    reason) instead of failing in torch._C._cuda_init; `-m gpu` on a GPU box runs them all."""
+    if has_gpu():
+        return
+    skip = pytest.mark.skip(reason="needs a ROCm GPU (torch.cuda.is_available() is False)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     """The built C-ABI library (built on demand: hipcc cross-compiles without a GPU)."""

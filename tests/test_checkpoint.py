@@ -13,7 +13,21 @@ def _write_fake_ckpt(path, model, cfg_dict):
     mod_a, mod_b, mod_c = types.ModuleType("fvcore"), types.ModuleType("fvcore.common"), types.ModuleType("fvcore.common.config")
 
     class CfgNode(dict):
-        pass
+        """Shaped like yacs.config.CfgNode: a dict subclass whose instance __dict__ holds the bookkeeping
+        keys, so pickling emits a BUILD with that state after the items (what real reference .ckpt files do)."""
+
+        def __init__(self, init=None):
+            super().__init__(init or {})
+            self.__dict__["__immutable__"] = False
+            self.__dict__["__deprecated_keys__"] = set()
+            self.__dict__["__renamed_keys__"] = {}
+            self.__dict__["__new_allowed__"] = False
+
+        def freeze(self):
+            self.__dict__["__immutable__"] = True
+            for v in self.values():
+                if isinstance(v, CfgNode):
+                    v.freeze()
     CfgNode.__module__, CfgNode.__qualname__ = "fvcore.common.config", "CfgNode"
     mod_c.CfgNode = CfgNode
     pl_mod = types.ModuleType("pytorch_lightning_fake_callbacks")
@@ -28,8 +42,11 @@ def _write_fake_ckpt(path, model, cfg_dict):
     try:
         def to_node(d):
             return CfgNode({k: to_node(v) if isinstance(v, dict) else v for k, v in d.items()})
+        hp = to_node(cfg_dict)
+        hp.freeze()                     # the reference freezes its config before Lightning pickles it
+        assert "__immutable__" in hp.__dict__ and isinstance(hp["model"], CfgNode)
         ckpt = {"epoch": 3, "state_dict": {"model." + k: v for k, v in model.state_dict().items()},
-                "hyper_parameters": to_node(cfg_dict), "callbacks": {"ckpt": ModelCheckpoint()}}
+                "hyper_parameters": hp, "callbacks": {"ckpt": ModelCheckpoint()}}
         torch.save(ckpt, path)
     finally:
         for k in ("fvcore", "fvcore.common", "fvcore.common.config", "pytorch_lightning_fake_callbacks"):
@@ -50,6 +67,10 @@ def test_load_checkpoint_without_fvcore(tmp_path):
     assert "fvcore" not in sys.modules
     sd, hp = load_lightning_checkpoint(path)
     assert isinstance(hp, CfgNode) and hp.model.token.len == 4 and hp["root_dir"] == "/stale/path"
+    assert isinstance(hp.model, CfgNode) and isinstance(hp.model.token, CfgNode)
+    assert hp.is_frozen() and hp.model.is_frozen()          # yacs' __immutable__ survives as the frozen flag
+    with pytest.raises(AttributeError):
+        hp.model.num_lines = 3
     assert set(sd) == set(model.state_dict()) and not any(k.startswith("model.") for k in sd)
     m2 = model_from_checkpoint(path)
     assert isinstance(m2, SurfaceFormer_Parallel) and not m2.training
@@ -58,3 +79,19 @@ def test_load_checkpoint_without_fvcore(tmp_path):
     torch.save({"foo": 1}, str(tmp_path / "bad.ckpt"))
     with pytest.raises(ValueError):
         load_lightning_checkpoint(str(tmp_path / "bad.ckpt"))
+
+
+def test_checkpoint_unpickler_refuses_arbitrary_globals(tmp_path):
+    """A .ckpt is a pickle: a global outside the allow-list must come back as an inert placeholder, not be
+    imported and called."""
+    import os
+    from faceformer_amd.checkpoint import load_lightning_checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    path = str(tmp_path / "evil.ckpt")
+    torch.save({"state_dict": {"model.w": torch.ones(2)}, "hyper_parameters": {"x": 1}, "payload": Evil()}, path)
+    sd, hp = load_lightning_checkpoint(path)
+    assert not (tmp_path / "pwned").exists()
+    assert torch.equal(sd["w"], torch.ones(2)) and hp["x"] == 1

@@ -31,16 +31,17 @@ class _OracleEngine:
     def decode(self, memory, mask, kv_len, variant, T, F, num_input, no_stop=False, **kw):
         from oracle import refpath
         assert no_stop
-        lo, hi = memory
-        sub = {"input": self.batch["input"][lo:hi], "input_mask": self.batch["input_mask"][lo:hi],
-               "label": self.batch["label"][lo:hi], "num_input": list(num_input)}
+        sub_in = memory          # the stand-in's "memory" is the sub-batch handed to _encode
+        n = sub_in["input"].size(0)
+        sub = {"input": sub_in["input"], "input_mask": sub_in["input_mask"],
+               "label": self.batch["label"][:n], "num_input": list(num_input)}
         trace = {}
         out = refpath.parallel_forward_eval(self.sd, sub, num_head=self.H, trace=trace, stop_rule=False,
                                             num_anchors=F)
         return {"predict": out["predict"].reshape(-1, T), "steps": T - 1, "step_counts": trace["counts"]}
 
 
-def _worker(rank, world, port, name, ret):
+def _worker(rank, world, port, name, ret, local=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -56,8 +57,18 @@ def _worker(rank, world, port, name, ret):
                                    num_encoder_layers=m["enc"], num_decoder_layers=m["dec"],
                                    num_lines=m["L"], max_face_length=m["seq_len"], token=token_ns()).eval()
     eng = _OracleEngine(sd, m["H"], batch)
-    lo, hi, _ = ffd.shard_range(batch["input"].size(0), rank, world)
-    model._encode = lambda sub: (eng, (lo, hi), None, None)   # carries the shard range to the stand-in
+    model._encode = lambda sub: (eng, sub, None, None)   # carries the rank's sub-batch to the stand-in
+    if local:
+        # every rank holds ONLY its own wireframes (rank 0 the first one, rank 1 the rest): F, the counters and
+        # the shard sizes are agreed by collectives; the result is the concatenation in rank order
+        N = batch["input"].size(0)
+        lo, hi = (0, 1) if rank == 0 else (1, N)
+        mine = {"input": batch["input"][lo:hi], "input_mask": batch["input_mask"][lo:hi],
+                "label": batch["label"][lo:hi], "num_input": batch["num_input"][lo:hi]}
+        out = ffd.decode_sharded(model, mine, dist, local_shard=True)
+        ret[rank] = bool(np.array_equal(out["predict"].numpy(), z["predict"]) and out["shard_sizes"] == [1, N - 1])
+        dist.destroy_process_group()
+        return
     out = ffd.decode_sharded(model, dict(batch), dist)
     ok = np.array_equal(out["predict"].numpy(), z["predict"])
     # face-loop JSON of every wireframe on every rank (parsed locally, gathered as bytes)
@@ -80,6 +91,21 @@ def test_sharded_decode_equals_single_process_gloo(name):
     ret = ctx.Manager().dict()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak"])
+def test_sharded_decode_with_shard_local_inputs_gloo(name):
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret, True)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -111,6 +137,24 @@ def test_gather_json_records_ragged_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True, 2: True}
+
+
+def test_shard_plan_balances_ragged_batches_by_cost():
+    from faceformer_amd import dist as ffd
+    # uniform batch: contiguous blocks (config C: 1024 wireframes over 8 GPUs -> 128 each)
+    plan = ffd.shard_plan([256] * 1024, 8)
+    assert [len(p) for p in plan] == [128] * 8 and plan[3][0] == 384 and plan[3][-1] == 511
+    # ragged batch (config E mix): every wireframe exactly once, per-rank cost within 15 % of the mean
+    rng = np.random.default_rng(0)
+    ni = rng.choice([64, 128, 256, 512, 1024], size=256, p=[.3, .3, .2, .1, .1]).tolist()
+    plan = ffd.shard_plan(ni, 8, F=1024)
+    assert sorted(i for p in plan for i in p) == list(range(256))
+    cost = [sum(ffd.wireframe_cost(ni[i], 1024) for i in p) for p in plan]
+    assert max(cost) <= 1.15 * (sum(cost) / 8)
+    by_index = [sum(ffd.wireframe_cost(ni[i], 1024) for i in range(*ffd.shard_range(256, r, 8)[:2])) for r in range(8)]
+    assert max(cost) <= max(by_index)          # never worse than splitting by index
+    for p in plan:                              # each rank sees its wireframes widest first
+        assert [ni[i] for i in p] == sorted((ni[i] for i in p), reverse=True)
 
 
 def test_shard_range_and_global_stop():
