@@ -9,15 +9,18 @@ One "step" = one pass of the hot path over one batch per GPU: encoder + all gree
 output packing (+ the RCCL all-gather of the predicted loops when N > 1).  Default workload =
 BASELINE config B: configs/ours.yml with model.num_lines=256, ONE synthetic 256-edge wireframe per
 GPU (F=256 anchor sequences x 36 steps = 9216 selections), default-xavier synthetic weights (never
-stops early), fp32.  `--wireframes-per-gpu 128` gives config C's per-GPU batch.
+stops early), fp32.  `--wireframes-per-gpu 128` gives config C's per-GPU batch.  `--config E` is
+BASELINE config 5: configs/ours-perspective.yml with model.num_lines=1024 and a seed-listed ragged mix
+of 64..1024-edge wireframes (32 per GPU by default = 256 over 8 GPUs).
 
 The JSON line also carries
   roofline     : the dominant kernel (the f32-MFMA GEMM): algorithmic flops (2MNK summed over its
                  launches of one step) / its summed duration, measured with HIP events on the launch
                  stream by the library's profiling hooks, against the 157.3 TF/s f32 matrix peak;
-  cpu_baseline : the CPU oracle (op-for-op restatement of the reference, oracle/refpath.py) timed on
-                 the host cores on a bounded sample of the SAME wireframe (first `anchors` anchor
-                 sequences, all 36 steps; sequences are independent so the sample is faithful).
+  cpu_baseline : the CPU oracle (op-for-op restatement of the reference, oracle/refpath.py) timed on the
+                 host's physical cores on ONE FULL wireframe of the workload (all anchor sequences, all
+                 steps); if that does not finish within --cpu-timeout, a 32-anchor sample of the same
+                 wireframe (sequences are independent, so the sample is faithful) -- `sample` says which.
 """
 import argparse
 import ctypes
@@ -32,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+E_SIZES, E_PROBS, E_SEED = (64, 128, 256, 512, 1024), (.3, .3, .2, .1, .1), 2024
 
 
 def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100):
@@ -49,24 +53,54 @@ def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100):
     return embed + enc + cross_kv + dec_lin + dec_self + dec_cross + ptr
 
 
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def config_e_edge_counts(total):
+    """Seed-listed edge counts of BASELINE config 5: n in {64..1024} with p = {.3,.3,.2,.1,.1}."""
+    import numpy as np
+    return [int(v) for v in np.random.default_rng(E_SEED).choice(E_SIZES, size=total, p=E_PROBS)]
+
+
+def run_cpu_child(code, timeout, threads):
+    import subprocess
+    cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout,
+                        env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads)))
+    return json.loads(cp.stdout.strip().splitlines()[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--wireframes-per-gpu", type=int, default=1)
+    ap.add_argument("--config", default="B", choices=["B", "E"],
+                    help="B: 256-edge wireframes (BASELINE configs 2/3, the headline); E: ours-perspective.yml with "
+                         "num_lines=1024, ragged 64..1024-edge wireframes (BASELINE config 5)")
+    ap.add_argument("--wireframes-per-gpu", type=int, default=0, help="0 = 1 (config B) / 32 (config E)")
     ap.add_argument("--edges", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=16, help="wireframes per micro-batch (0 = all)")
+    ap.add_argument("--chunk-max-seqs", type=int, default=8192, help="sequences per micro-batch of several wireframes")
     ap.add_argument("--chunk-seqs", type=int, default=0, help="sequences per intra-wireframe group (0 = off)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams for the micro-batches")
     ap.add_argument("--attn-algo", type=int, default=0, help="ff_attention kernel: 0 auto, 1 LDS-shared, 2 wave")
     ap.add_argument("--gemm-tuning", default="", help="min_units,two_per_cu_units,fix_tenths[,small_max_rows] of ff_set_gemm_tuning")
     ap.add_argument("--x3-min-rows", type=int, default=0,
                     help="3 x bf16 projections (fp32-accurate, bf16 matrix cores) on steps with at least this many rows")
+    ap.add_argument("--no-dedup", action="store_true", help="decode every padding-anchor row like the reference does")
     ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")
-    ap.add_argument("--cpu-anchors", type=int, default=32, help="anchor sequences in the CPU sample")
-    ap.add_argument("--cpu-threads", type=int, default=32, help="torch threads for the CPU oracle")
-    ap.add_argument("--cpu-timeout", type=int, default=150, help="wall-clock cap of the CPU sample [s]")
+    ap.add_argument("--cpu-anchors", type=int, default=0,
+                    help="anchor sequences in the CPU baseline (0 = all: the FULL wireframe, SURVEY 8d)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU oracle (0 = physical cores, at most 64)")
+    ap.add_argument("--cpu-timeout", type=int, default=200, help="wall-clock cap of the CPU baseline [s]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -89,35 +123,51 @@ def main():
     from faceformer_amd.config import load_cfg
     from faceformer_amd.dist import gather_predictions
     from faceformer_amd.hip import lib as L
+    from faceformer_amd.hip.engine import DEFAULT_FLAGS
     from faceformer_amd.models import SurfaceFormer_Parallel
     from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec
 
-    n, W = args.edges, args.wireframes_per_gpu
-    cfg = load_cfg(os.path.join(ROOT, "configs", "ours.yml"), ["model.num_lines", str(n)])
+    cfgE = args.config == "E"
+    W = args.wireframes_per_gpu or (32 if cfgE else 1)
+    L_lines = 1024 if cfgE else args.edges
+    cfg = load_cfg(os.path.join(ROOT, "configs", "ours-perspective.yml" if cfgE else "ours.yml"),
+                   ["model.num_lines", str(L_lines)])
     T = cfg.model.max_face_length
     model = SurfaceFormer_Parallel(**cfg.model)
-    spec = state_dict_spec("parallel", n, T, cfg.model.num_model, cfg.model.num_feedforward,
+    spec = state_dict_spec("parallel", L_lines, T, cfg.model.num_model, cfg.model.num_feedforward,
                            cfg.model.num_encoder_layers, cfg.model.num_decoder_layers)
     sd = make_state_dict(spec, "default", 0)
     model.load_state_dict(sd)
     model = model.eval().to(dev)
-    model.chunk_wireframes = args.chunk
+    model.chunk_wireframes, model.chunk_max_seqs = args.chunk, args.chunk_max_seqs
     model.chunk_seqs, model.num_streams = args.chunk_seqs, args.streams
     model.sync_every = args.sync_every
     model.x3_min_rows = args.x3_min_rows
+    if args.no_dedup:
+        model.decode_flags = DEFAULT_FLAGS & ~L.FF_DEDUP_PAD_ANCHORS
     from faceformer_amd.hip import ops as _ops
     _ops.set_attention_algo(args.attn_algo)
     if args.gemm_tuning:
         _ops.set_gemm_tuning(*[int(v) for v in args.gemm_tuning.split(",")])
     seeds = [rank * W + i for i in range(W)]
-    batch_cpu = make_wireframes(n, n, T, "parallel", seeds=seeds)
+    if cfgE:
+        all_n = config_e_edge_counts(world * W)
+        n_local = all_n[rank * W:(rank + 1) * W]
+    else:
+        all_n = [args.edges] * (world * W)
+        n_local = [args.edges] * W
+    batch_cpu = make_wireframes(n_local, L_lines, T, "parallel", seeds=seeds)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
+    F_local = max(n_local)
 
     def step():
         with torch.no_grad():
             out = model(dict(batch))
         pred = out["predict"]
         if world > 1:
+            if cfgE and pred.size(1) < max(all_n):   # ragged shards: pad the anchor dimension to the global F
+                pad = torch.zeros((pred.size(0), max(all_n) - pred.size(1), pred.size(2)), dtype=pred.dtype, device=dev)
+                pred = torch.cat([pred, pad], dim=1)
             pred = gather_predictions(pred, dist)
         return pred
 
@@ -143,25 +193,44 @@ def main():
     local = pred[rank * W:(rank + 1) * W] if world > 1 else pred
     nz = (local[:, :, 1:] != 0).any(dim=1).any(dim=0)
     steps_done = int(nz.nonzero().max().item()) + 1 if bool(nz.any()) else 0
-    sel_per_step = world * W * n * steps_done
+    # decoded edges = pointer selections of the REAL anchor sequences (n_w per wireframe); the reference
+    # additionally decodes F - n_w identical padding-anchor rows per wireframe, reported separately
+    sel_per_step = sum(all_n) * steps_done
     value = sel_per_step * args.steps / dt
+    stats = getattr(model, "last_decode_stats", None) or {}
 
+    if cfgE:
+        hist = {str(k): all_n.count(k) for k in E_SIZES}
+        workload = ("configs/ours-perspective.yml model.num_lines=1024: %d synthetic wireframes per GPU with edge counts "
+                    "drawn from %s p=%s (numpy default_rng(%d); this run: %s), F=max n anchor rows per wireframe x %d greedy "
+                    "steps, default-xavier synthetic weights" % (W, list(E_SIZES), list(E_PROBS), E_SEED, hist, steps_done))
+    else:
+        workload = ("configs/ours.yml model.num_lines=%d: %d synthetic %d-edge wireframe(s) per GPU, "
+                    "F=%d anchor sequences x %d greedy steps, default-xavier synthetic weights"
+                    % (args.edges, W, args.edges, args.edges, steps_done))
     result = {
-        "metric": "decoded edges/sec (greedy face-loop decode, pointer selections/s), 256-edge wireframes",
+        "metric": "decoded edges/sec (greedy face-loop decode, pointer selections/s), 256-edge wireframes"
+                  if not cfgE else "decoded edges/sec (greedy face-loop decode, pointer selections/s), ragged 64-1024-edge wireframes",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs/ours.yml model.num_lines=%d: %d synthetic %d-edge wireframe(s) per GPU, "
-                               "F=%d anchor sequences x %d greedy steps, default-xavier synthetic weights"
-                               % (n, W, n, n, steps_done),
-                   "wireframes_per_gpu": W, "edges": n, "max_face_length": T, "decode_steps": steps_done,
+        "config": {"workload": workload, "wireframes_per_gpu": W, "edges": args.edges if not cfgE else "64..1024",
+                   "max_face_length": T, "decode_steps": steps_done,
                    "parallelism": "wireframe-sharded x%d, RCCL all-gather of predictions" % world},
         "wireframes_per_s": world * W * args.steps / dt,
     }
-    falg = alg_flops_per_wireframe(n, T)
-    result["path_roofline"] = {"alg_tflop_per_wireframe": falg / 1e12,
-                               "achieved_tflops_per_gpu": falg * W * args.steps / dt / 1e12,
-                               "frac_of_f32_mfma_peak": falg * W * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    if cfgE:
+        rows = W * F_local
+        result["sequence_rows"] = {
+            "reference_rows_per_gpu": rows, "decoded_sequences_per_gpu": stats.get("decoded_seqs"),
+            "real_anchor_sequences_per_gpu": sum(n_local),
+            "padding_rows_not_decoded_per_gpu": rows - (stats.get("decoded_seqs") or rows),
+            "note": "rows f >= n_w of a wireframe are identical padding-anchor sequences (reference model_para.py:204-205); "
+                    "one is decoded per wireframe and copied"}
+    falg = sum(alg_flops_per_wireframe(n, T) for n in n_local)
+    result["path_roofline"] = {"alg_tflop_per_gpu_step": falg / 1e12,
+                               "achieved_tflops_per_gpu": falg * args.steps / dt / 1e12,
+                               "frac_of_f32_mfma_peak": falg * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
     if rank == 0 and not args.no_roofline:
         lib = L.load()
@@ -183,12 +252,12 @@ def main():
         traffic, traffic_src = None, None
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
-        if cands and n == 256 and W == 1:
+        if cands and not cfgE and args.edges == 256 and W == 1:
             with open(cands[-1]) as f:
                 tj = json.load(f)
             traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
         result["roofline"] = {
-            "kernel": "f32-MFMA GEMM (gemm_streamk_kernel / gemm_persist_kernel: one 64x64 tiling, two launch shapes)",
+            "kernel": "f32-MFMA GEMM (ff_gemm.hip; all launch shapes of one tiling family)",
             "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
@@ -203,49 +272,85 @@ def main():
             result["attention_tflops"] = work[1] / (ms[1] * 1e-3) / 1e12
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # The oracle runs in a child process with a hard wall-clock cap: the host of the GPU box has
-        # hundreds of hardware threads, and torch's CPU eager path gets SLOWER when all of them are
-        # used for these operator sizes (first bench run: 256 threads -> 1.4 edges/s), so the thread
-        # count is a flag (default 32) and `cores` reports what was actually used.
+        # The oracle runs in a child process with a hard wall-clock cap.  Threads = the host's physical cores
+        # (capped at 64: torch's CPU eager path gets SLOWER beyond that for these operator sizes -- round 1
+        # measured 1.4 edges/s with 256 threads); `cores` reports what was actually used.
         import subprocess
-        k = max(1, min(args.cpu_anchors, n))
-        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        child = (
-            "import sys, time, json, torch\n"
-            "sys.path.insert(0, %r)\n"
-            "torch.set_num_threads(%d)\n"
-            "from oracle import refpath\n"
-            "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\n"
-            "spec = state_dict_spec('parallel', %d, %d, %d, %d, %d, %d)\n"
-            "sd = make_state_dict(spec, 'default', 0)\n"
-            "one = make_wireframes(%d, %d, %d, 'parallel', seeds=[%d])\n"
-            "t0 = time.perf_counter()\n"
-            "ref = refpath.parallel_forward_eval(sd, one, num_head=%d, anchor_limit=%d)\n"
-            "tc = time.perf_counter() - t0\n"
-            "print(json.dumps({'t': tc, 'predict': ref['predict'][0].tolist()}))\n"
-            % (ROOT, threads, n, T, cfg.model.num_model, cfg.model.num_feedforward,
-               cfg.model.num_encoder_layers, cfg.model.num_decoder_layers, n, n, T, seeds[0],
-               cfg.model.num_head, k))
-        try:
-            cp = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True,
-                                timeout=args.cpu_timeout, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
-            rec = json.loads(cp.stdout.strip().splitlines()[-1])
+        n_cpu = n_local[0] if not cfgE else min(n_local)      # config E: the smallest wireframe of the shard
+        seed_cpu = seeds[0] if not cfgE else seeds[n_local.index(n_cpu)]
+        phys = physical_cores()
+        threads = args.cpu_threads if args.cpu_threads > 0 else min(phys, 64)
+        threads = max(1, min(threads, os.cpu_count() or 1))
+        pinfo = " ".join(torch.__config__.parallel_info().split())[:400]
+
+        def child_code(k):
+            return (
+                "import sys, time, json, torch\\n"
+                "sys.path.insert(0, %r)\\n"
+                "torch.set_num_threads(%d)\\n"
+                "from oracle import refpath\\n"
+                "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\\n"
+                "spec = state_dict_spec('parallel', %d, %d, %d, %d, %d, %d)\\n"
+                "sd = make_state_dict(spec, 'default', 0)\\n"
+                "one = make_wireframes(%d, %d, %d, 'parallel', seeds=[%d])\\n"
+                "t0 = time.perf_counter()\\n"
+                "ref = refpath.parallel_forward_eval(sd, one, num_head=%d, anchor_limit=%s)\\n"
+                "tc = time.perf_counter() - t0\\n"
+                "print(json.dumps({'t': tc, 'predict': ref['predict'][0].tolist()}))\\n"
+                % (ROOT, threads, L_lines, T, cfg.model.num_model, cfg.model.num_feedforward,
+                   cfg.model.num_encoder_layers, cfg.model.num_decoder_layers, n_cpu, L_lines, T, seed_cpu,
+                   cfg.model.num_head, "None" if k >= n_cpu else str(k)))
+
+        wf_local = local[seeds.index(seed_cpu)]
+        tried = []
+        for k in ([args.cpu_anchors] if args.cpu_anchors > 0 else [n_cpu, 32]):
+            k = max(1, min(k, n_cpu))
+            try:
+                rec = run_cpu_child(child_code(k), args.cpu_timeout, threads)
+            except (subprocess.TimeoutExpired, ValueError, IndexError) as e:
+                tried.append("%d anchors: no result within %ds (%s)" % (k, args.cpu_timeout, type(e).__name__))
+                continue
             ref_pred = torch.tensor(rec["predict"], dtype=torch.int64)
             tc = rec["t"]
             ref_steps = int((ref_pred[:, 1:] != 0).any(dim=0).nonzero().max().item()) + 1
-            same = bool(torch.equal(ref_pred[:k].to(dev), local[0, :k]))
+            same = bool(torch.equal(ref_pred[:k].to(dev), wf_local[:k]))
+            what = ("all %d anchor sequences" % k) if k >= n_cpu else ("first %d of %d anchor sequences" % (k, n_cpu))
             result["cpu_baseline"] = {
                 "value": k * ref_steps / tc, "unit": "edges/s", "cores": threads, "kind": "port",
-                "sample": "first %d of %d anchor sequences of the same %d-edge wireframe, all %d steps, "
-                          "oracle/refpath.py (torch %s CPU eager fp32, %d of %d host threads): %.1f s"
-                          % (k, n, n, ref_steps, torch.__version__, threads, os.cpu_count() or 1, tc),
-                "tokens_identical_to_gpu": same,
+                "sample": "%s of one %d-edge wireframe of the workload, all %d steps, oracle/refpath.py (torch %s CPU eager "
+                          "fp32; %d threads on %d physical cores / %d hardware threads): %.1f s%s"
+                          % (what, n_cpu, ref_steps, torch.__version__, threads, phys, os.cpu_count() or 1, tc,
+                             ("; earlier attempts: " + "; ".join(tried)) if tried else ""),
+                "parallel_info": pinfo, "tokens_identical_to_gpu": same,
             }
             result["speedup_vs_cpu"] = value / result["cpu_baseline"]["value"]
-        except (subprocess.TimeoutExpired, ValueError, IndexError) as e:
+            break
+        else:
             result["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": threads, "kind": "port",
-                                      "sample": "oracle sample did not finish within %ds (%s)"
-                                                % (args.cpu_timeout, type(e).__name__)}
+                                      "sample": "; ".join(tried)}
+        if not cfgE:
+            # BASELINE config 1 (configs/seq2seq.yml: L=110, T=259, one 64-edge wireframe) in full, CPU only
+            code_a = (
+                "import sys, time, json, torch\\n"
+                "sys.path.insert(0, %r)\\n"
+                "torch.set_num_threads(%d)\\n"
+                "from oracle import refpath\\n"
+                "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\\n"
+                "sd = make_state_dict(state_dict_spec('seq2seq', 110, 259), 'default', 0)\\n"
+                "one = make_wireframes(64, 110, 259, 'seq2seq', seeds=[3])\\n"
+                "t0 = time.perf_counter()\\n"
+                "ref = refpath.seq2seq_forward_eval(sd, one, num_head=8)\\n"
+                "tc = time.perf_counter() - t0\\n"
+                "p = ref['predict'][0]\\n"
+                "print(json.dumps({'t': tc, 'steps': int((p[1:] != 0).nonzero().max()) + 1}))\\n" % (ROOT, threads))
+            try:
+                rec = run_cpu_child(code_a, 120, threads)
+                result["cpu_baseline_config_a"] = {
+                    "value": rec["steps"] / rec["t"], "unit": "edges/s", "cores": threads, "kind": "port",
+                    "sample": "configs/seq2seq.yml sizes (L=110, T=259), one 64-edge wireframe, all %d executed steps: %.1f s"
+                              % (rec["steps"], rec["t"])}
+            except (subprocess.TimeoutExpired, ValueError, IndexError):
+                pass
 
     if rank == 0:
         print(json.dumps(result))

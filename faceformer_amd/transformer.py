@@ -375,39 +375,36 @@ class TransformerDecoder(nn.Module):
 
 
 class Transformer(nn.Module):
-    """DETR-style wrapper (reference transformer.py:18-59).  The decode path never instantiates it;
-    it is kept so that `faceformer.transformer.Transformer` stays importable and usable."""
+    """Encoder/decoder pair over an image-shaped feature map.  The reference carries such a wrapper
+    (transformer.py:18-59) that neither model class instantiates; it exists here only so that
+    `faceformer.transformer.Transformer(...)` keeps its constructor arguments and call contract:
+    (src N x C x H x W, mask N x H x W, query_embed Q x C, pos_embed N x C x H x W) ->
+    (decoder states [layers or 1] x N x Q x C, memory N x C x H x W)."""
 
     def __init__(self, num_model=512, num_head=8, num_encoder_layers=6, num_decoder_layers=6,
                  num_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
                  return_intermediate_dec=False):
         super().__init__()
-        enc_layer = TransformerEncoderLayer(num_model, num_head, num_feedforward, dropout, activation,
-                                            normalize_before)
-        self.encoder = TransformerEncoder(enc_layer, num_encoder_layers,
-                                          nn.LayerNorm(num_model) if normalize_before else None)
-        dec_layer = TransformerDecoderLayer(num_model, num_head, num_feedforward, dropout, activation,
-                                            normalize_before)
-        self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, nn.LayerNorm(num_model),
-                                          return_intermediate=return_intermediate_dec)
-        self._reset_parameters()
-        self.num_model = num_model
-        self.num_head = num_head
+        self.num_model, self.num_head = num_model, num_head
+        layer_args = (num_model, num_head, num_feedforward, dropout, activation, normalize_before)
+        self.encoder = TransformerEncoder(TransformerEncoderLayer(*layer_args), num_encoder_layers,
+                                          norm=nn.LayerNorm(num_model) if normalize_before else None)
+        self.decoder = TransformerDecoder(TransformerDecoderLayer(*layer_args), num_decoder_layers,
+                                          norm=nn.LayerNorm(num_model), return_intermediate=return_intermediate_dec)
+        for weight in (p for p in self.parameters() if p.dim() > 1):
+            nn.init.xavier_uniform_(weight)
 
-    def _reset_parameters(self):
-        for p in self.parameters():
-            if p.dim() > 1:
-                nn.init.xavier_uniform_(p)
+    @staticmethod
+    def _as_tokens(maps):
+        """N x C x H x W -> (H*W) x N x C (the sequence-first layout of the blocks above)."""
+        return maps.reshape(maps.size(0), maps.size(1), -1).permute(2, 0, 1)
 
     def forward(self, src, mask, query_embed, pos_embed):
-        bs, c, h, w = src.shape
-        src = src.flatten(2).permute(2, 0, 1)
-        pos_embed = pos_embed.flatten(2).permute(2, 0, 1)
-        query_embed = query_embed.unsqueeze(1).repeat(1, bs, 1)
-        mask = mask.flatten(1)
-        tgt = torch.zeros_like(query_embed)
-        memory = self.encoder(src, src_key_padding_mask=mask, pos=pos_embed)
-        hs = self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_embed, query_pos=query_embed)
-        if hs.dim() == 3:
-            hs = hs.unsqueeze(0)
-        return hs.transpose(1, 2), memory.permute(1, 2, 0).view(bs, c, h, w)
+        n, c, h, w = src.shape
+        pos, key_pad = self._as_tokens(pos_embed), mask.reshape(n, -1)
+        queries = query_embed[:, None, :].expand(-1, n, -1).contiguous()
+        memory = self.encoder(self._as_tokens(src), src_key_padding_mask=key_pad, pos=pos)
+        states = self.decoder(queries.new_zeros(queries.shape), memory, memory_key_padding_mask=key_pad,
+                              pos=pos, query_pos=queries)
+        states = states if states.dim() == 4 else states[None]
+        return states.transpose(1, 2), memory.permute(1, 2, 0).reshape(n, c, h, w)

@@ -44,6 +44,11 @@ def test_oracle_matches_golden_seq2seq_config_a():
     _check("seq_full_A64_gain4")
 
 
+@pytest.mark.slow
+def test_oracle_matches_golden_seq2seq_config_d_extra_mask():
+    _check("seq_full_D216_extramask")
+
+
 def test_anchor_limit_is_a_faithful_sample():
     """cpu_baseline times a subset of anchor sequences; their tokens must equal the full run's."""
     case, z = load_golden("par_small_gain4")

@@ -43,7 +43,7 @@ def run_traced(model, case, batch):
                          extra_mask=extra, sync_every=model.sync_every, flags=model.decode_flags,
                          x3_min_rows=model.x3_min_rows,
                          chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
-                         num_streams=model.num_streams)
+                         chunk_max_seqs=model.chunk_max_seqs, num_streams=model.num_streams)
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          extra_mask=extra, flags=model.decode_flags, return_pointer=True,
@@ -125,7 +125,11 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
                                   "par_small_extramask", "par_small_ragged300"])
 @pytest.mark.parametrize("flags,chunk,sync,cseq,nstr", [(0, 0, 1, 0, 1), (3, 0, 0, 0, 1), (3, 1, 3, 0, 2),
                                                         (1, 2, 1, 0, 3), (2, 1, 0, 0, 1), (3, 0, 2, 5, 4),
-                                                        (3, 0, 0, 7, 2), (0, 0, 1, 3, 8)])
+                                                        (3, 0, 0, 7, 2), (0, 0, 1, 3, 8),
+                                                        # 16 = FF_DEDUP_PAD_ANCHORS: one padding-anchor sequence
+                                                        # per wireframe, width-bucketed micro-batches
+                                                        (19, 0, 1, 0, 1), (19, 2, 0, 0, 2), (16, 0, 2, 5, 3),
+                                                        (19, 3, 4, 0, 1)])
 def test_engine_options_do_not_change_results(hip_lib, name, flags, chunk, sync, cseq, nstr):
     """Pruning flags, micro-batching (by wireframe or by sequence group), concurrent streams and the
     host sync period are pure scheduling choices."""
@@ -162,6 +166,137 @@ def test_model_forward_dict_contract(hip_lib, name):
         assert np.abs(got - z["pointer_last"]).max() < 1e-3 * max(1.0, np.abs(z["pointer_last"]).max())
     with pytest.raises(NotImplementedError):
         model.train()(b)
+
+
+@pytest.mark.parametrize("name", ["par_small_ragged", "par_small_ragged300", "par_full_E1024_gain4"])
+def test_padding_anchor_dedup_and_sorting_are_exact(hip_lib, name):
+    """BASELINE config E machinery: (i) with FF_DEDUP_PAD_ANCHORS the engine decodes n_w + 1 sequences per
+    wireframe instead of F = max(num_input) and copies the one padding-anchor sequence into every row
+    f >= n_w -- `predict` must equal the golden in EVERY row, so the copies are checked against the
+    reference's individually decoded padding rows; (ii) the model decodes a ragged batch sorted by edge count
+    and un-sorts the result; (iii) far fewer sequences are decoded."""
+    from faceformer_amd.hip import lib as L
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    ni = [int(n) for n in batch["num_input"]]
+    F, T = max(ni), case["model"]["seq_len"]
+    gold = z["predict"]
+    decisive = (z["margin"] > 4 * 1e-3 * max(1.0, float(np.abs(z["best"]).max()) / 40.0)).all()
+    b = batch_to(batch, "cuda")
+    eng, memory, mask, kv_len = model._encode(b)
+    outs = {}
+    for dedup in (0, L.FF_DEDUP_PAD_ANCHORS):
+        outs[dedup] = eng.decode(memory, mask, kv_len, L.FF_PARALLEL, T=T, F=F, num_input=ni, sync_every=0,
+                                 flags=3 | dedup, trace=True)
+    full, dd = outs[0], outs[L.FF_DEDUP_PAD_ANCHORS]
+    assert full["decoded_seqs"] == len(ni) * F
+    want = sum(min(F, n + 1) for n in ni)
+    assert want <= dd["decoded_seqs"] <= int(1.34 * want) + 1      # surplus only from 25 % width buckets
+    assert dd["steps"] == full["steps"] == int(z["steps"])
+    if decisive:
+        assert np.array_equal(dd["predict"].cpu().numpy().reshape(gold.shape), gold)
+        assert np.array_equal(full["predict"].cpu().numpy().reshape(gold.shape), gold)
+    compare_with_golden(case, z, dict(dd, memory=memory))
+    # rows f >= n_w of a wireframe all come from ONE decoded sequence
+    rows = dd["seq_of_row"].view(len(ni), F).cpu().numpy()
+    for w, n in enumerate(ni):
+        if n < F:
+            assert (rows[w, n:] == rows[w, n]).all() and len(set(rows[w, : n + 1])) == n + 1
+    # model-level path: sorted by edge count, default flags
+    with torch.no_grad():
+        pred = model(batch_to(batch, "cuda"))["predict"].cpu().numpy()
+    if decisive:
+        assert np.array_equal(pred, gold)
+    assert model.last_decode_stats["decoded_seqs"] == want
+
+
+def test_config_c_batch_of_256_edge_wireframes_full_size(hip_lib):
+    """BASELINE config C's per-GPU workload at the full model size: a batch of 16 distinct 256-edge
+    wireframes (seeds 0..15).  Wireframes 0..3 must reproduce the reference's rows of the 4-wireframe golden
+    `par_full_C4x256_gain4` (tokens at decisive margins, logits within tolerance), and the result must not
+    depend on the micro-batching (1, 8, 16 wireframes per chunk, or the whole batch)."""
+    from faceformer_amd.synth import make_wireframes
+    case, z = load_golden("par_full_C4x256_gain4")
+    sd, _ = case_weights_and_batch(case)
+    m = case["model"]
+    model = build_model(case, sd, "cuda")
+    N = 16
+    batch = batch_to(make_wireframes(256, m["L"], m["seq_len"], "parallel", seeds=list(range(N))), "cuda")
+    T, F = m["seq_len"], 256
+    gold = z["predict"]                                   # [4, 256, 37]
+    steps = int(z["steps"])
+    tol_scale = 1e-3 * max(1.0, float(np.abs(z["best"]).max()) / LOGIT_SCALE)
+    base = None
+    for chunk in (16, 1, 8, 0):
+        model.chunk_wireframes = chunk
+        case16 = dict(case, n_edges=[256] * N, seeds=list(range(N)))
+        out = run_traced(model, case16, batch)
+        assert out["steps"] == steps                      # gain-4 weights never stop early: 36 steps
+        pred = out["predict"].cpu().numpy().reshape(N, F, T)
+        best = out["best"].cpu().numpy()[:steps].reshape(steps, N, F)
+        # first four wireframes vs the reference
+        alive = np.ones((4, F), dtype=bool)
+        n_cmp = 0
+        for s_ in range(steps):
+            mg = z["margin"][s_].reshape(4, F)
+            must = alive & (mg > 2 * tol_scale)
+            same = pred[:4, :, s_ + 1] == gold[:, :, s_ + 1]
+            assert same[must].all(), "chunk=%d step %d: token mismatch at a decisive margin" % (chunk, s_)
+            d = np.abs(best[s_, :4] - z["best"][s_].reshape(4, F))[alive]
+            assert d.max() <= tol_scale, "chunk=%d step %d: best logit off by %g" % (chunk, s_, d.max())
+            n_cmp += int(must.sum())
+            alive &= same
+        assert n_cmp >= 0.9 * 4 * F * steps
+        # stored logit rows (wireframes 0..3) at the first and last step
+        logits = out["logits"].cpu().numpy()
+        for ri, b_ in enumerate(z["logit_rows"]):
+            for s_ in (0, steps - 1):
+                if s_ == 0 or alive.reshape(-1)[b_]:
+                    assert np.abs(logits[s_, b_] - z["logits"][s_, ri]).max() <= _tol(z["logits"][s_])
+        # all 16 wireframes: invariant under the micro-batching
+        if base is None:
+            base = (pred, best)
+        else:
+            same = pred == base[0]
+            frac = same.mean()
+            assert frac > 0.995, "chunk=%d: only %.4f of the tokens equal the 16-per-chunk run" % (chunk, frac)
+            assert np.abs(best[0] - base[1][0]).max() <= tol_scale     # step 0: identical prefixes
+
+
+def test_json_gather_over_rccl(hip_lib, tmp_path):
+    """The north-star's 'RCCL all-gather of predicted face-loop JSON': decode_to_face_json on the nccl backend
+    (world size 1 on this box; the gloo tests cover world sizes 2 and 3) incl. the co-edge post-processing
+    branch and the extra-mask pass-through of decode_sharded."""
+    import json
+    import torch.distributed as dist
+    from faceformer_amd import dist as ffd
+    from faceformer_amd import faces as FZ
+    from conftest import token_ns
+    case, z = load_golden("par_small_gain4")
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+        created = True
+    try:
+        recs = ffd.decode_to_face_json(model, batch_to(batch, "cuda"), dist)
+        case_m, z_m = load_golden("par_small_extramask")
+        sd_m, batch_m = case_weights_and_batch(case_m)
+        model_m = build_model(case_m, sd_m, "cuda")
+        out_m = ffd.decode_sharded(model_m, batch_to(batch_m, "cuda"), dist)
+        out_l = ffd.decode_sharded(model, batch_to(batch, "cuda"), dist, local_shard=True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert len(recs) == batch["input"].size(0)
+    for i, r in enumerate(recs):
+        pf, _ = FZ.parse_parallel_faces(z["predict"][i], batch["label"][i].numpy(), batch["num_input"][i], token_ns())
+        want = [[t, list(f)] for t, f in FZ.unique_faces_with_majority_type(pf)]
+        assert json.loads(r)["pred_faces"] == want
+    assert np.array_equal(out_m["predict"].cpu().numpy(), z_m["predict"])
+    assert np.array_equal(out_l["predict"].cpu().numpy(), z["predict"]) and out_l["shard_sizes"] == [2]
 
 
 FRESH_CASES = {
@@ -276,6 +411,49 @@ def test_cli_decode_writes_reference_json(hip_lib, tmp_path):
         m = FZ.face_metrics(pf, lf)
         assert rec["pred_faces"] == [[t, list(f)] for t, f in m["predictions"]]
         assert sorted(map(tuple, map(lambda x: (x[0], tuple(x[1])), rec["label_faces"]))) == sorted(m["labels"])
+
+
+def test_cli_decode_with_coedge_postprocessing_matches_reference(hip_lib, tmp_path):
+    """SURVEY 8f row 2 end to end: main.py's test branch with post_process.is_coedge at its DEFAULT (True,
+    reference config.py:52) on wireframes whose edges chain into closed loops and carry co-edge pairings.
+    Expected records = what the imported reference produced for the same files and weights
+    (oracle/make_golden_cli.py: dataset -> forward_eval -> face_accuracy, trainer.py:210-300)."""
+    import json
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    import main as cli
+    from faceformer_amd.config import load_cfg
+    from faceformer_amd.synth import make_state_dict, state_dict_spec
+    from conftest import GOLDEN
+    gold = json.load(open(os.path.join(GOLDEN, "cli_coedge_case.json")))
+    m = gold["model"]
+    root = tmp_path / "data"
+    (root / "json").mkdir(parents=True)
+    names = []
+    for i, smp in enumerate(gold["samples"]):
+        json.dump(smp["raw"], open(root / "json" / ("%08d.json" % i), "w"))
+        names.append("json/%08d.json" % i)
+    open(root / "test.txt", "w").write("\n".join(names) + "\n")
+    cfg = load_cfg("configs/ours.yml", ["model.num_lines", str(m["num_lines"]), "model.max_face_length",
+                                         str(m["max_face_length"]), "model.num_model", str(m["num_model"]),
+                                         "model.num_head", str(m["num_head"]), "model.num_feedforward",
+                                         str(m["num_feedforward"]), "model.num_encoder_layers",
+                                         str(m["num_encoder_layers"]), "model.num_decoder_layers",
+                                         str(m["num_decoder_layers"]), "root_dir", str(root)])
+    assert cfg.post_process.is_coedge is True and cfg.post_process.enclosedness_tol == gold["tol"]
+    spec = state_dict_spec("parallel", m["num_lines"], m["max_face_length"], m["num_model"], m["num_feedforward"],
+                           m["num_encoder_layers"], m["num_decoder_layers"])
+    sd = make_state_dict(spec, gold["recipe"], gold["wseed"])
+    ckpt = tmp_path / "last.ckpt"
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "hyper_parameters": dict(cfg)}, ckpt)
+    out_dir = cli.run_test(cfg, str(ckpt), out_dir=str(tmp_path / "out"))
+    for i, smp in enumerate(gold["samples"]):
+        rec = json.load(open(os.path.join(out_dir, "%08d.json" % i)))
+        assert set(rec) == {"edges", "dominant_directions", "pred_faces", "label_faces"}
+        assert rec["edges"] == smp["raw"]["edges"] and rec["dominant_directions"] == smp["raw"]["dominant_directions"]
+        assert len(smp["pred_faces"]) > 0                       # the post-processing branch saw real faces
+        assert rec["pred_faces"] == smp["pred_faces"]
+        assert sorted(map(json.dumps, rec["label_faces"])) == sorted(map(json.dumps, smp["label_faces"]))
 
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_full_n40_gain4", "par_full_n40_default"])
