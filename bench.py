@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")
     ap.add_argument("--cpu-anchors", type=int, default=0,
                     help="anchor sequences in the CPU baseline (0 = all: the FULL wireframe, SURVEY 8d)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU oracle (0 = physical cores, at most 64)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU oracle (0 = physical cores, at most 32)")
     ap.add_argument("--cpu-timeout", type=int, default=200, help="wall-clock cap of the CPU baseline [s]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -273,30 +273,31 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The oracle runs in a child process with a hard wall-clock cap.  Threads = the host's physical cores
-        # (capped at 64: torch's CPU eager path gets SLOWER beyond that for these operator sizes -- round 1
-        # measured 1.4 edges/s with 256 threads); `cores` reports what was actually used.
+        # (capped at 32: torch's CPU eager path gets SLOWER beyond that for these operator sizes -- measured on
+        # the MI355X host: 256 threads 1.4 edges/s, 64 threads 133, 32 threads 165-245); `cores` reports what
+        # was actually used.
         import subprocess
         n_cpu = n_local[0] if not cfgE else min(n_local)      # config E: the smallest wireframe of the shard
         seed_cpu = seeds[0] if not cfgE else seeds[n_local.index(n_cpu)]
         phys = physical_cores()
-        threads = args.cpu_threads if args.cpu_threads > 0 else min(phys, 64)
+        threads = args.cpu_threads if args.cpu_threads > 0 else min(phys, 32)
         threads = max(1, min(threads, os.cpu_count() or 1))
         pinfo = " ".join(torch.__config__.parallel_info().split())[:400]
 
         def child_code(k):
             return (
-                "import sys, time, json, torch\\n"
-                "sys.path.insert(0, %r)\\n"
-                "torch.set_num_threads(%d)\\n"
-                "from oracle import refpath\\n"
-                "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\\n"
-                "spec = state_dict_spec('parallel', %d, %d, %d, %d, %d, %d)\\n"
-                "sd = make_state_dict(spec, 'default', 0)\\n"
-                "one = make_wireframes(%d, %d, %d, 'parallel', seeds=[%d])\\n"
-                "t0 = time.perf_counter()\\n"
-                "ref = refpath.parallel_forward_eval(sd, one, num_head=%d, anchor_limit=%s)\\n"
-                "tc = time.perf_counter() - t0\\n"
-                "print(json.dumps({'t': tc, 'predict': ref['predict'][0].tolist()}))\\n"
+                "import sys, time, json, torch\n"
+                "sys.path.insert(0, %r)\n"
+                "torch.set_num_threads(%d)\n"
+                "from oracle import refpath\n"
+                "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\n"
+                "spec = state_dict_spec('parallel', %d, %d, %d, %d, %d, %d)\n"
+                "sd = make_state_dict(spec, 'default', 0)\n"
+                "one = make_wireframes(%d, %d, %d, 'parallel', seeds=[%d])\n"
+                "t0 = time.perf_counter()\n"
+                "ref = refpath.parallel_forward_eval(sd, one, num_head=%d, anchor_limit=%s)\n"
+                "tc = time.perf_counter() - t0\n"
+                "print(json.dumps({'t': tc, 'predict': ref['predict'][0].tolist()}))\n"
                 % (ROOT, threads, L_lines, T, cfg.model.num_model, cfg.model.num_feedforward,
                    cfg.model.num_encoder_layers, cfg.model.num_decoder_layers, n_cpu, L_lines, T, seed_cpu,
                    cfg.model.num_head, "None" if k >= n_cpu else str(k)))
@@ -313,7 +314,12 @@ def main():
             ref_pred = torch.tensor(rec["predict"], dtype=torch.int64)
             tc = rec["t"]
             ref_steps = int((ref_pred[:, 1:] != 0).any(dim=0).nonzero().max().item()) + 1
-            same = bool(torch.equal(ref_pred[:k].to(dev), wf_local[:k]))
+            # default-init weights give the reference EXACT logit ties in a few sequences (tests/golden:
+            # 174 of 9216 selections); a tie may legitimately resolve differently under another fp32
+            # summation order, after which that sequence's later tokens differ too
+            eq = (ref_pred[:k].to(dev) == wf_local[:k])
+            same = bool(eq.all())
+            seq_same = float(eq.all(dim=1).float().mean())
             what = ("all %d anchor sequences" % k) if k >= n_cpu else ("first %d of %d anchor sequences" % (k, n_cpu))
             result["cpu_baseline"] = {
                 "value": k * ref_steps / tc, "unit": "edges/s", "cores": threads, "kind": "port",
@@ -321,7 +327,7 @@ def main():
                           "fp32; %d threads on %d physical cores / %d hardware threads): %.1f s%s"
                           % (what, n_cpu, ref_steps, torch.__version__, threads, phys, os.cpu_count() or 1, tc,
                              ("; earlier attempts: " + "; ".join(tried)) if tried else ""),
-                "parallel_info": pinfo, "tokens_identical_to_gpu": same,
+                "parallel_info": pinfo, "tokens_identical_to_gpu": same, "sequences_identical_to_gpu": seq_same,
             }
             result["speedup_vs_cpu"] = value / result["cpu_baseline"]["value"]
             break
@@ -331,22 +337,22 @@ def main():
         if not cfgE:
             # BASELINE config 1 (configs/seq2seq.yml: L=110, T=259, one 64-edge wireframe) in full, CPU only
             code_a = (
-                "import sys, time, json, torch\\n"
-                "sys.path.insert(0, %r)\\n"
-                "torch.set_num_threads(%d)\\n"
-                "from oracle import refpath\\n"
-                "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\\n"
-                "sd = make_state_dict(state_dict_spec('seq2seq', 110, 259), 'default', 0)\\n"
-                "one = make_wireframes(64, 110, 259, 'seq2seq', seeds=[3])\\n"
-                "t0 = time.perf_counter()\\n"
-                "ref = refpath.seq2seq_forward_eval(sd, one, num_head=8)\\n"
-                "tc = time.perf_counter() - t0\\n"
-                "p = ref['predict'][0]\\n"
-                "print(json.dumps({'t': tc, 'steps': int((p[1:] != 0).nonzero().max()) + 1}))\\n" % (ROOT, threads))
-            try:
-                rec = run_cpu_child(code_a, 120, threads)
+                "import sys, time, json, torch\n"
+                "sys.path.insert(0, %r)\n"
+                "torch.set_num_threads(%d)\n"
+                "from oracle import refpath\n"
+                "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\n"
+                "sd = make_state_dict(state_dict_spec('seq2seq', 110, 259), 'default', 0)\n"
+                "one = make_wireframes(64, 110, 259, 'seq2seq', seeds=[3])\n"
+                "t0 = time.perf_counter()\n"
+                "ref = refpath.seq2seq_forward_eval(sd, one, num_head=8)\n"
+                "tc = time.perf_counter() - t0\n"
+                "p = ref['predict'][0]\n"
+                "print(json.dumps({'t': tc, 'steps': int((p[1:] != 0).nonzero().max()) + 1}))\n" % (ROOT, min(threads, 8)))
+            try:   # one sequence of <= 258 rows: more than 8 threads only add synchronisation (64 threads: 14/s)
+                rec = run_cpu_child(code_a, 120, min(threads, 8))
                 result["cpu_baseline_config_a"] = {
-                    "value": rec["steps"] / rec["t"], "unit": "edges/s", "cores": threads, "kind": "port",
+                    "value": rec["steps"] / rec["t"], "unit": "edges/s", "cores": min(threads, 8), "kind": "port",
                     "sample": "configs/seq2seq.yml sizes (L=110, T=259), one 64-edge wireframe, all %d executed steps: %.1f s"
                               % (rec["steps"], rec["t"])}
             except (subprocess.TimeoutExpired, ValueError, IndexError):

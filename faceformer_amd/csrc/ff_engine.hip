@@ -538,7 +538,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
         hipStream_t st = sts[c.sid];
         const Scratch& sc = buf.scr[c.sid];
         FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
-        const size_t trow = (size_t)step * Btot + c.b0;
+        const size_t trow = (size_t)step * ((size_t)N * F) + c.b0;  // traces: step stride N*F (caller sizes them so)
         FF_RETURN_IF(ff_pointer_argmax(
             sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
             extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,

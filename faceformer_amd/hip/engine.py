@@ -166,7 +166,7 @@ class PathEngine:
         prm.chunk_seqs, prm.num_streams = chunk_seqs, num_streams
         prm.chunk_max_seqs = int(chunk_max_seqs)
         prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0) | (_L.FF_NO_STOP if no_stop else 0)
-        if return_pointer:
+        if return_pointer or extra_mask is not None:   # (every padding-anchor row has its own extra-mask row)
             prm.flags &= ~_L.FF_DEDUP_PAD_ANCHORS
         prm.tok_sos, prm.tok_eos = tok_sos, tok_eos
         prm.x3_min_rows = int(x3_min_rows) if self._planes else 0

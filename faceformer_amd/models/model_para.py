@@ -10,6 +10,8 @@ lowest index (173-179); the loop stops after the first step whose tokens are all
 and masks are never replicated per sequence (212-214), cross-attention K/V are projected once, the
 last layer and the output projection are evaluated for the newest position only.
 """
+import torch
+
 from ..hip import lib as _L
 from .common import SurfaceFormerBase
 

@@ -334,9 +334,10 @@ typedef struct ff_decode_params {
  *                           stop rules (with de-duplication a padding-anchor sequence counts once: the
  *                           parallel rule only tests the count against zero)
  *   pointer_out           : optional [steps_done, N*F, E] (FF_RETURN_POINTER), position-major
- *   trace_logits          : optional [T-1, Bd, S] masked logits of every step (tests), or NULL; Bd = number
- *                           of decoded sequences <= N*F, indexed by the compact sequence id
- *   trace_best/second     : optional [T-1, Bd] top-2 logits, or NULL (size them for N*F)
+ *   trace_logits          : optional [T-1, N*F, S] masked logits of every step (tests), or NULL; within a step
+ *                           the entries are indexed by the COMPACT sequence id (see seq_of_row; only the
+ *                           first Bd <= N*F entries of a step are written)
+ *   trace_best/second     : optional [T-1, N*F] top-2 logits, same indexing, or NULL
  *   seq_of_row            : optional DEVICE int[N*F]: compact sequence id behind every row of `predict`
  * Stop rules reproduced exactly: parallel = first step whose tokens are all < num_token
  * (model_para.py:232); seq2seq = cumulative EOS count == N (model.py:207-210). */

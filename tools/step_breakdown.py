@@ -7,7 +7,7 @@ for n, s, e in rows:
     cur.append((n, s, e))
     if 'pointer_reduce' in n or 'pointer_kernel' in n:
         steps.append(cur); cur = []
-    if 'finalize_kernel' in n:
+    if 'finalize' in n and 'chunk' in n:
         decodes.append(steps); steps = []; cur = []
 d = decodes[-1]
 tot = 0
