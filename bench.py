@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--gemm-tuning", default="", help="min_units,two_per_cu_units,fix_tenths[,small_max_rows] of ff_set_gemm_tuning")
     ap.add_argument("--x3-min-rows", type=int, default=0,
                     help="3 x bf16 projections (fp32-accurate, bf16 matrix cores) on steps with at least this many rows")
+    ap.add_argument("--no-fuse-ln", action="store_true", help="standalone LayerNorm launches (A/B of FF_FUSE_LAYERNORM)")
     ap.add_argument("--no-dedup", action="store_true", help="decode every padding-anchor row like the reference does")
     ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")
     ap.add_argument("--cpu-anchors", type=int, default=0,
@@ -144,7 +145,9 @@ def main():
     model.sync_every = args.sync_every
     model.x3_min_rows = args.x3_min_rows
     if args.no_dedup:
-        model.decode_flags = DEFAULT_FLAGS & ~L.FF_DEDUP_PAD_ANCHORS
+        model.decode_flags = model.decode_flags & ~L.FF_DEDUP_PAD_ANCHORS
+    if args.no_fuse_ln:
+        model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
     from faceformer_amd.hip import ops as _ops
     _ops.set_attention_algo(args.attn_algo)
     if args.gemm_tuning:

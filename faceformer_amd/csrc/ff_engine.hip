@@ -134,6 +134,7 @@ int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, 
 // Scratch of one in-flight micro-batch (one set per stream): R = t*Bc active rows, position-major.
 struct Scratch {
   float *x, *y, *yq, *qkv, *o, *h, *p, *logits;
+  float* lnstat;   // [R, E/32, 2] per-row segment statistics of x (FF_FUSE_LAYERNORM)
 };
 
 struct DecodeBuffers {
@@ -228,6 +229,7 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, 
     c.h = bp.take<float>(Rmax * FFd);
     c.p = bp.take<float>(Bch * E);
     c.logits = bp.take<float>(Bch * (size_t)S);
+    c.lnstat = bp.take<float>(Rmax * (size_t)(E / 32 + 1) * 2);
   }
   b.cnt_ge = bp.take<int>(T);
   b.cnt_eq = bp.take<int>(T);
@@ -236,9 +238,26 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, 
   return bp.off;
 }
 
+// LayerNorm fusion is possible when the folded weights are bound and the shapes fit the fused GEMM forms.
+bool can_fuse_layernorm(const ff_model* m, const ff_decode_params* prm) {
+  if (!(prm->flags & FF_FUSE_LAYERNORM)) return false;
+  if (m->E % 64 != 0 || m->E < 128 || m->E > 512 || m->FF % 64 != 0 || m->FF < 128) return false;
+  if (!m->proj_fold_w || !m->proj_fold_b) return false;
+  for (int l = 0; l < m->num_dec_layers; ++l) {
+    const ff_layer_weights& w = m->dec[l];
+    if (!w.ln1_w || !w.ln1_b || !w.ln1_pos || !w.ln2_w || !w.ln2_b || !w.ln2_pos || !w.ln3_w || !w.ln3_b) return false;
+  }
+  return true;
+}
+
 // One decoder pass over the current prefix (t positions) of one micro-batch.
 // full_rows: evaluate every layer for all rows and project all rows into proj_all (ld = E rows
 // position-major within the chunk); otherwise the result is p[Bc, E] for the newest position.
+//
+// With FF_FUSE_LAYERNORM only layer 0's norm1 is a standalone launch: every other LayerNorm input x is produced
+// by a projection with a residual (out-proj, linear2), which leaves per-row segment statistics in `lnstat`; the
+// projection that consumes LN(x) (+ qpos) reads x and the statistics and applies gamma / beta / qpos W^T through
+// folded weights (ff_gemm_f32_ln).  19 -> 1 LayerNorm launches per decode step of a 6-layer decoder.
 int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuffers& bufs, const Scratch& buf,
                  const Chunk& ck, const unsigned char* mask, const int* kv_len, int t, bool full_rows,
                  float* proj_all, hipStream_t st) {
@@ -247,8 +266,24 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   const size_t newoff = (size_t)(t - 1) * Bc;
   const bool reuse0 = (prm->flags & FF_REUSE_LAYER0_QKV) != 0 && ck.qkv0 != nullptr;
   const bool prune_last = (prm->flags & FF_LAST_LAYER_LAST_ROW) != 0 && !full_rows;
+  const bool fuse = can_fuse_layernorm(m, prm);
+  const int nseg = E / 32;
   const float* qpos = m->qpos_table;
   const float* qpos_new = qpos + (size_t)(t - 1) * E;
+
+  // C = act(LN?(A) W^T + bias [+ table]) [+ residual], optionally leaving the row statistics of C
+  auto gemm_ln = [&](const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
+                     float* C, int ldc, int M, int N, int K, int act, const float* st_in, const float* table, int ldt,
+                     int tcols, float* st_out) -> int {
+    ff_gemm_ln_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.lda = lda; d.W = W; d.ldw = ldw; d.bias = bias; d.residual = res; d.ldr = ldr; d.C = C; d.ldc = ldc;
+    d.M = M; d.N = N; d.K = K; d.act = act; d.tile = 0;
+    d.ln_stats_in = st_in; d.ln_nseg = K / 32; d.ln_eps = m->ln_eps;
+    d.row_table = table; d.ld_row_table = ldt; d.row_div = Bc; d.row_cols = tcols;
+    d.ln_stats_out = st_out;
+    return ff_gemm_f32_ln(&d, st);
+  };
 
   for (int l = 0; l < nd; ++l) {
     const ff_layer_weights& w = m->dec[l];
@@ -262,6 +297,10 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       FF_RETURN_IF(gemm(buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
                         ck.qkv0 + newoff * 3 * E, 3 * E, Bc, 3 * E, E, 0, st));
       QKV = ck.qkv0;
+    } else if (fuse && l > 0) {
+      FF_RETURN_IF(gemm_ln(xin, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat,
+                           w.ln1_pos, 2 * E, 2 * E, nullptr));
+      QKV = buf.qkv;
     } else {
       FF_RETURN_IF(ff_layernorm(xin, E, w.norm1_w, w.norm1_b, m->ln_eps, buf.y, E, buf.yq, E, qpos, E, Bc, T,
                                 R, E, st));
@@ -272,6 +311,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     // rows that continue through the rest of this layer
     const size_t roff = last ? newoff : 0;
     const int Rl = last ? Bc : R;
+    float* stat = buf.lnstat + roff * nseg * 2;
     {
       ff_attn_desc d;
       memset(&d, 0, sizeof(d));
@@ -286,19 +326,27 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       d.scale = 0.125f;
       FF_RETURN_IF(ff_attention(&d, st));
     }
-    FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
-                            w.self_attn.out_b, xin + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
-    // ---- cross attention: q = LN2(x) + qpos, k = memory + pos, v = memory (transformer.py:247-252);
-    //      K/V come from the per-batch cache ----
-    if (last)
-      FF_RETURN_IF(ff_layernorm(buf.x + roff * E, E, w.norm2_w, w.norm2_b, m->ln_eps, nullptr, 0, buf.yq + roff * E,
-                                E, qpos_new, E, Bc, 1, Rl, E, st));
-    else
-      FF_RETURN_IF(ff_layernorm(buf.x, E, w.norm2_w, w.norm2_b, m->ln_eps, nullptr, 0, buf.yq, E, qpos, E, Bc, T,
-                                Rl, E, st));
     float* qc = buf.qkv;  // [rows, E] view of the scratch
-    FF_RETURN_IF(gemm_or_x3(prm, w.cross_q_planes, buf.yq + roff * E, E, nullptr, 0, w.cross_attn.in_proj_w, E,
-                            w.cross_attn.in_proj_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, st));
+    if (fuse) {
+      FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
+                           buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
+      // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
+      FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
+                           w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr));
+    } else {
+      FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
+                              w.self_attn.out_b, xin + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
+      // ---- cross attention: q = LN2(x) + qpos, k = memory + pos, v = memory (transformer.py:247-252);
+      //      K/V come from the per-batch cache ----
+      if (last)
+        FF_RETURN_IF(ff_layernorm(buf.x + roff * E, E, w.norm2_w, w.norm2_b, m->ln_eps, nullptr, 0, buf.yq + roff * E,
+                                  E, qpos_new, E, Bc, 1, Rl, E, st));
+      else
+        FF_RETURN_IF(ff_layernorm(buf.x, E, w.norm2_w, w.norm2_b, m->ln_eps, nullptr, 0, buf.yq, E, qpos, E, Bc, T,
+                                  Rl, E, st));
+      FF_RETURN_IF(gemm_or_x3(prm, w.cross_q_planes, buf.yq + roff * E, E, nullptr, 0, w.cross_attn.in_proj_w, E,
+                              w.cross_attn.in_proj_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, st));
+    }
     {
       ff_attn_desc d;
       memset(&d, 0, sizeof(d));
@@ -315,18 +363,35 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       d.scale = 0.125f;
       FF_RETURN_IF(ff_attention(&d, st));
     }
-    FF_RETURN_IF(gemm_or_x3(prm, w.cross_out_planes, buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E,
-                            w.cross_attn.out_b, buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
-    // ---- feed forward (transformer.py:253-255) ----
-    FF_RETURN_IF(ff_layernorm(buf.x + roff * E, E, w.norm3_w, w.norm3_b, m->ln_eps, buf.y + roff * E, E, nullptr, 0,
-                              nullptr, 0, 1, 1, Rl, E, st));
-    FF_RETURN_IF(gemm_or_x3(prm, w.lin1_planes, buf.y + roff * E, E, nullptr, 0, w.lin1_w, E, w.lin1_b, nullptr, 0,
-                            buf.h + roff * FFd, FFd, Rl, FFd, E, 1, st));
-    FF_RETURN_IF(gemm_or_x3(prm, w.lin2_planes, buf.h + roff * FFd, FFd, nullptr, 0, w.lin2_w, FFd, w.lin2_b,
-                            buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, FFd, 0, st));
+    if (fuse) {
+      FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.cross_attn.out_w, E, w.cross_attn.out_b, buf.x + roff * E, E,
+                           buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
+      // ---- feed forward (transformer.py:253-255) ----
+      FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln3_w, E, w.ln3_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl, FFd, E, 1,
+                           stat, nullptr, 0, 0, nullptr));
+      FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
+                           Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat));
+    } else {
+      FF_RETURN_IF(gemm_or_x3(prm, w.cross_out_planes, buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E,
+                              w.cross_attn.out_b, buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
+      // ---- feed forward (transformer.py:253-255) ----
+      FF_RETURN_IF(ff_layernorm(buf.x + roff * E, E, w.norm3_w, w.norm3_b, m->ln_eps, buf.y + roff * E, E, nullptr, 0,
+                                nullptr, 0, 1, 1, Rl, E, st));
+      FF_RETURN_IF(gemm_or_x3(prm, w.lin1_planes, buf.y + roff * E, E, nullptr, 0, w.lin1_w, E, w.lin1_b, nullptr, 0,
+                              buf.h + roff * FFd, FFd, Rl, FFd, E, 1, st));
+      FF_RETURN_IF(gemm_or_x3(prm, w.lin2_planes, buf.h + roff * FFd, FFd, nullptr, 0, w.lin2_w, FFd, w.lin2_b,
+                              buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, FFd, 0, st));
+    }
   }
   // ---- decoder.norm + project (transformer.py:115-116, model_para.py:225) ----
-  if (full_rows) {
+  if (fuse) {
+    if (full_rows)
+      FF_RETURN_IF(gemm_ln(buf.x, E, m->proj_fold_w, E, m->proj_fold_b, nullptr, 0, proj_all, E, R, E, E, 0, buf.lnstat,
+                           nullptr, 0, 0, nullptr));
+    else
+      FF_RETURN_IF(gemm_ln(buf.x + newoff * E, E, m->proj_fold_w, E, m->proj_fold_b, nullptr, 0, buf.p, E, Bc, E, E, 0,
+                           buf.lnstat + newoff * nseg * 2, nullptr, 0, 0, nullptr));
+  } else if (full_rows) {
     FF_RETURN_IF(ff_layernorm(buf.x, E, m->dec_norm_w, m->dec_norm_b, m->ln_eps, buf.y, E, nullptr, 0, nullptr, 0,
                               1, 1, R, E, st));
     FF_RETURN_IF(gemm(buf.y, E, nullptr, 0, m->proj_w, E, m->proj_b, nullptr, 0, proj_all, E, R, E, E, 0, st));

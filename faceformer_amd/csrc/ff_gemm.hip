@@ -44,7 +44,125 @@ struct GemmArgs {
   int n_split, act;
   int tiles_m, tiles_n;
   long long batch_stride_a, batch_stride_w, batch_stride_c;  // per-problem offsets (elements)
+  // LayerNorm fusion (persistent / stream-K / small-M kernels only; batch == 1):
+  const float* ln_in;   // MODE 1: [M][ln_nseg][2] (mean, M2 over 32 columns) segment statistics of the A rows
+  int ln_nseg;
+  float ln_eps;
+  const float* rowtab;  // MODE 1: C[m][n] += rowtab[(m / rowtab_div) * ld_rowtab + n] for n < rowtab_cols (no residual then)
+  int ld_rowtab, rowtab_div, rowtab_cols;
+  float* ln_out;        // MODE 2: [M][N/32][2] segment statistics of the stored C rows
 };
+
+// Row statistics of a LayerNorm input from the per-32-column (mean, M2) partials its producer left behind:
+// Chan's parallel update for equal-sized parts (no E[x^2] - mean^2 cancellation).  -> (mean, 1/sqrt(var + eps)).
+// One lane merges a whole row (small-M kernel): all segment loads are issued before the first use (nseg <= 16).
+__device__ __forceinline__ void ff_merge_ln_stats(const float* __restrict__ st, int nseg, float eps, float& mean,
+                                                  float& rstd) {
+  f32x4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(st + 4 * (2 * q < nseg ? q : 0));
+  float sm = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (2 * q < nseg) { sm += v[q].x + v[q].z; m2 += v[q].y + v[q].w; }
+  mean = sm / (float)nseg;
+  float dev = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (2 * q < nseg) { const float d0 = v[q].x - mean, d1 = v[q].z - mean; dev += d0 * d0 + d1 * d1; }
+  const float var = (m2 + 32.f * dev) / (32.f * (float)nseg);
+  rstd = 1.0f / sqrtf(var + eps);
+}
+
+// Staging side of the persistent kernels: the 8 lanes that stage one A row (lane & 7 = 16-byte column of the
+// slice) share the work of merging its segment statistics: lane c takes segments c, c + 8, ... (K <= 1024:
+// at most 4), the partial sums meet through DPP moves inside the group of 8 lanes.  The raw loads are issued
+// when the load cursor enters a tile and consumed ~3 slices later (ff_ln_finish), so their latency never sits
+// in front of the MFMA chain.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int LN_NQ = 2;                     // segments per lane: ln_nseg <= 8 * LN_NQ, i.e. K <= 512 for the fused consumer
+struct LnRaw { f32x2 seg[LN_NQ]; };          // (mean, M2) pairs exactly as loaded: no register shuffling behind the loads
+__device__ __forceinline__ void ff_ln_issue(const float* __restrict__ st, int nseg, int c, LnRaw& r) {
+#pragma unroll
+  for (int q = 0; q < LN_NQ; ++q) {
+    const int sidx = c + 8 * q;
+    r.seg[q] = *reinterpret_cast<const f32x2*>(st + 2 * (sidx < nseg ? sidx : 0));
+  }
+}
+__device__ __forceinline__ float ff_sum8(float v) {  // sum over the aligned group of 8 lanes, result on all of them
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ void ff_ln_finish(const LnRaw& r, int nseg, int c, float eps, float& mean, float& rstd) {
+  float sm = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < LN_NQ; ++q)
+    if (c + 8 * q < nseg) { sm += r.seg[q].x; m2 += r.seg[q].y; }
+  sm = ff_sum8(sm);
+  m2 = ff_sum8(m2);
+  mean = sm / (float)nseg;
+  float dev = 0.f;
+#pragma unroll
+  for (int q = 0; q < LN_NQ; ++q)
+    if (c + 8 * q < nseg) { const float d = r.seg[q].x - mean; dev += d * d; }
+  dev = ff_sum8(dev);
+  const float var = (m2 + 32.f * dev) / (32.f * (float)nseg);
+  rstd = 1.0f / sqrtf(var + eps);
+}
+
+// rv[e] = rowtab[(row_e / div), col] for the 16 accumulator rows row_e = row0 + (e&3) + 8*(e>>2) of a lane: one
+// division; the 28-row span crosses a multiple of div at most once when div >= 28 (sequences per micro-batch).
+__device__ __forceinline__ void ff_load_rowtab(const GemmArgs& g, int row0, int colc, float (&rv)[16]) {
+  const int div = g.rowtab_div;
+  const int qmax = (g.M - 1) / div;
+  const float* tp = g.rowtab + colc;
+  if (div >= 28) {
+    const int q0 = row0 / div, rem0 = row0 - q0 * div;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int q = q0 + ((rem0 + (e & 3) + 8 * (e >> 2)) >= div ? 1 : 0);
+      q = q < qmax ? q : qmax;
+      rv[e] = tp[(size_t)q * g.ld_rowtab];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int q = (row0 + (e & 3) + 8 * (e >> 2)) / div;
+      q = q < qmax ? q : qmax;
+      rv[e] = tp[(size_t)q * g.ld_rowtab];
+    }
+  }
+}
+
+// Epilogue side: one wave holds a finished 32x32 sub-tile in the MFMA accumulator layout (lane: column l32,
+// rows (e&3) + 8*(e>>2) + 4*half).  The values go through a wave-private LDS patch [32][33] so that lane
+// (row = l32, half) can sum 16 consecutive columns of ITS row; the two halves meet with one shuffle.  Two passes
+// (mean, then centred squares) like the standalone LayerNorm kernel.  Writes (mean, M2) of rows < M.
+__device__ __forceinline__ void ff_emit_ln_stats(const float (&v)[16], float* patch, int l32, int half, int row0, int M,
+                                                 float* __restrict__ ln_out, int nseg_out, int seg) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * half) * 33 + l32] = v[e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float x[16], sm = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { x[c] = patch[l32 * 33 + half * 16 + c]; sm += x[c]; }
+  sm += __shfl_xor(sm, 32, FF_WAVE);
+  const float mean = sm * (1.0f / 32.0f);
+  float m2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { const float d = x[c] - mean; m2 += d * d; }
+  m2 += __shfl_xor(m2, 32, FF_WAVE);
+  const int row = row0 + l32;
+  if (half == 0 && row < M) {
+    *reinterpret_cast<f32x2*>(ln_out + ((size_t)row * nseg_out + seg) * 2) = f32x2{mean, m2};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();   // the patch is reused by this wave's next tile
+}
 
 // One 32x32 MFMA per k pair: MFMA-interleave hints shared by the pipelined kernels.
 template <int N_MFMA, int N_DSR, int N_DSW, int N_VM>
@@ -65,6 +183,31 @@ __device__ __forceinline__ void ff_interleave_hints() {
   for (int q = 0; q < N_VM; ++q) {
     __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
+  }
+}
+
+// The persistent kernels' slice: 16 MFMA, 8 fragment reads, 4 LDS writes, 4 global loads; MODE 1 additionally
+// normalises the two A float4s it writes (subtract, scale: up to 16 VALU), which belong in the MFMA shadows too.
+template <int MODE>
+__device__ __forceinline__ void ff_persist_hints() {
+  // (MODE 1: the normalisation VALU shares the fragment-read section.  Measured alternatives, by the emitted ISA:
+  //  VALU groups behind the LDS-write groups, or only in the second half of the read section, make the scheduler
+  //  give up the whole interleave -- 16 back-to-back MFMAs followed by every LDS / VMEM instruction)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    if (MODE == 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU: normalisation of the staged rows
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
   }
 }
 
@@ -415,6 +558,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 2 : 1)) void gemm_pipe_kernel(Gemm
 // flight while the current tile finishes: no pipeline fill/drain per tile, only per block (+4-6 %).  Bias
 // and residual of a tile are fetched when its first slice is computed and consumed after its last one.
 // Requires K % 64 == 0 and K >= 128.
+template <int MODE>  // 0 plain, 1 LayerNorm-normalised A rows + row-indexed additive table, 2 emits row statistics of C
 __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total_tiles) {
   constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4, KF = BK / 8;
   constexpr int BUF_FLOATS = (BM + BN) * LDS_LD;
@@ -446,7 +590,17 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
   // load cursor: runs 4 slices ahead of the MFMA chain and crosses tile boundaries early
   const float* a_ptr[2];
   const float* w_ptr[2];
-  auto set_load_tile = [&](int k) {
+  // MODE 1: (mean, rstd) of the two rows this thread stages.  Entering a tile issues the raw statistics loads
+  // (ln_raw); they replace `cur` exactly when the first slice of that tile is written to LDS: `pend` slices later
+  // (the load cursor runs 2 slices ahead of the LDS writes, switches are >= 4 slices apart inside the loop).
+  float cur_mu[2] = {0.f, 0.f}, cur_rs[2] = {1.f, 1.f};
+  LnRaw ln_raw[2];
+  int pend = 0;
+  auto ln_finish = [&]() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ff_ln_finish(ln_raw[p], g.ln_nseg, c4, g.ln_eps, cur_mu[p], cur_rs[p]);
+  };
+  auto set_load_tile = [&](int k, bool defer) {
     const int id = first + (k < my_tiles ? k : my_tiles - 1) * stride;
     const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
     const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
@@ -457,15 +611,17 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
       int row = m0 + r + 32 * p;
       row = row < g.M ? row : g.M - 1;
       a_ptr[p] = Asrc + (size_t)row * g.lda + c4 * 4;
+      if (MODE == 1) ff_ln_issue(g.ln_in + (size_t)row * g.ln_nseg * 2, g.ln_nseg, c4, ln_raw[p]);
       int n = n0 + r + 32 * p;
       n = n < g.N ? n : g.N - 1;
       w_ptr[p] = W + (size_t)n * g.ldw + c4 * 4;
     }
+    if (MODE == 1) { if (defer) pend = 3; else ln_finish(); }
   };
   int ld_k = 0, ld_j = 0;
-  set_load_tile(0);
+  set_load_tile(0, false);
   f32x4 ra[2][2], rw[2][2];
-  auto load_next = [&](f32x4* xa, f32x4* xw) {  // loads slice (ld_k, ld_j); branch-free
+  auto load_next = [&](f32x4* xa, f32x4* xw, int u) {  // loads slice (ld_k, ld_j); branch-free
     const int k0 = ld_j * BK;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -473,18 +629,19 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
       xw[p] = *reinterpret_cast<const f32x4*>(w_ptr[p] + k0);
     }
   };
-  auto advance = [&]() {  // block-uniform; past the last tile the cursor stays on the last slice
+  auto advance = [&](bool defer) {  // block-uniform; past the last tile the cursor stays on the last slice
     if (++ld_j == nsl) {
-      if (ld_k + 1 < my_tiles) { ld_j = 0; ++ld_k; set_load_tile(ld_k); }
+      if (ld_k + 1 < my_tiles) { ld_j = 0; ++ld_k; set_load_tile(ld_k, defer); }
       else ld_j = nsl - 1;
     }
   };
   float* const st_a = lds + r * LDS_LD + c4 * 4;
   float* const st_w = st_a + BM * LDS_LD;
-  auto store_from = [&](const f32x4* xa, const f32x4* xw, int buf) {
+  auto store_from = [&](const f32x4* xa, const f32x4* xw, int buf, int u) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + 32 * p * LDS_LD) = xa[p];
+      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + 32 * p * LDS_LD) =
+          MODE == 1 ? (xa[p] - cur_mu[p]) * cur_rs[p] : xa[p];
       *reinterpret_cast<f32x4*>(st_w + buf * BUF_FLOATS + 32 * p * LDS_LD) = xw[p];
     }
   };
@@ -509,7 +666,7 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
   };
 
   // compute-side tile state (epilogue operands)
-  int cp_k = 0, cp_j = 0;
+  int cp_k = 0;
   int e_row0 = 0, e_col = 0;
   long long e_coff = 0;
   bool e_colok = false;
@@ -531,6 +688,8 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
         row = row < g.M ? row : g.M - 1;
         rv[e] = g.res[e_coff + (size_t)row * g.ldr + colc];
       }
+    } else if (MODE == 1 && g.rowtab && colc < g.rowtab_cols) {  // additive table indexed by row / div (positions)
+      ff_load_rowtab(g, e_row0, colc, rv);
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e) rv[e] = 0.f;
@@ -538,47 +697,55 @@ __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total
   };
   auto end_tile = [&]() {
     float* cp = g.C + e_coff;
+    float fin[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = e_row0 + (e & 3) + 8 * (e >> 2);
-      float v = acc[e] + bv;
+      const bool tab = MODE == 1 && g.rowtab != nullptr;   // a position table belongs INSIDE the activation
+      float v = acc[e] + bv + (tab ? rv[e] : 0.f);
       if (g.act == 1) v = fmaxf(v, 0.f);
-      v += rv[e];
+      if (!tab) v += rv[e];
       if (row < g.M && e_colok) cp[(size_t)row * g.ldc + e_col] = v;
+      fin[e] = v;
       acc[e] = 0.f;
     }
+    if (MODE == 2)
+      ff_emit_ln_stats(fin, lds + 3 * BUF_FLOATS + wave * (32 * 33), l32, half, e_row0 - 4 * half, g.M, g.ln_out,
+                       g.N >> 5, (e_col - l32) >> 5);
   };
 
   // prologue: slices 0,1 -> LDS; slices 2,3 -> staging registers
-  load_next(ra[0], rw[0]); advance();
-  load_next(ra[1], rw[1]); advance();
-  store_from(ra[0], rw[0], 0);
-  store_from(ra[1], rw[1], 1);
-  load_next(ra[0], rw[0]); advance();
-  load_next(ra[1], rw[1]); advance();
+  load_next(ra[0], rw[0], 0); advance(false);   // (nsl >= 4: slices 0..3 belong to the first tile)
+  load_next(ra[1], rw[1], 1); advance(false);
+  store_from(ra[0], rw[0], 0, 0);
+  store_from(ra[1], rw[1], 1, 1);
+  load_next(ra[0], rw[0], 0); advance(false);
+  load_next(ra[1], rw[1], 1); advance(true);
   begin_tile(0);
   __syncthreads();
   read_frags(fa[0], fb[0], 0);
 
   int b0 = 0, b1 = 1, b2 = 2;
-  const int total_slices = my_tiles * nsl;  // nsl is even (checked on the host)
-  for (int s = 0; s < total_slices; s += 2) {
+  // Outer loop over this block's tiles, inner loop over the K-slices of one tile (two per trip: static register-set
+  // indices).  The software pipeline (staging registers, LDS ring, load cursor) runs across the tile boundary; only
+  // the epilogue sits between two inner loops, so the hot loop body is one straight basic block.
+  for (cp_k = 0; cp_k < my_tiles; ++cp_k) {
+    for (int s = 0; s < nsl; s += 2) {  // nsl is even (checked on the host)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      read_frags(fa[u ^ 1], fb[u ^ 1], b1);
-      store_from(ra[u], rw[u], b2);
-      load_next(ra[u], rw[u]);
-      mfma_frags(fa[u], fb[u]);
-      ff_interleave_hints<16, 8, 4, 4>();
-      advance();
-      if (++cp_j == nsl) {  // block-uniform: the last slice of the tile was just issued
-        end_tile();
-        cp_j = 0;
-        if (++cp_k < my_tiles) begin_tile(cp_k);
+      for (int u = 0; u < 2; ++u) {
+        if (MODE == 1 && pend > 0 && --pend == 0) ln_finish();   // block-uniform
+        read_frags(fa[u ^ 1], fb[u ^ 1], b1);
+        store_from(ra[u], rw[u], b2, u);
+        load_next(ra[u], rw[u], u);
+        mfma_frags(fa[u], fb[u]);
+        ff_persist_hints<MODE>();
+        advance(true);
+        __syncthreads();
+        { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
       }
-      __syncthreads();
-      { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
     }
+    end_tile();
+    if (cp_k + 1 < my_tiles) begin_tile(cp_k + 1);
   }
 }
 
@@ -606,6 +773,7 @@ struct StreamK {
   int base, rem;               // block lb owns base + (lb < rem) units
 };
 
+template <int MODE>  // as gemm_persist_kernel
 __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK sk) {
   constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4, KF = BK / 8;
   constexpr int BUF_FLOATS = (BM + BN) * LDS_LD;
@@ -647,7 +815,14 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   // load cursor
   const float* a_ptr[2];
   const float* w_ptr[2];
-  auto set_load_tile = [&](int id) {
+  float cur_mu[2] = {0.f, 0.f}, cur_rs[2] = {1.f, 1.f};   // MODE 1: see gemm_persist_kernel
+  LnRaw ln_raw[2];
+  int pend = 0;
+  auto ln_finish = [&]() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ff_ln_finish(ln_raw[p], g.ln_nseg, c4, g.ln_eps, cur_mu[p], cur_rs[p]);
+  };
+  auto set_load_tile = [&](int id, bool defer) {
     const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
     const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
     const float* Asrc = ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + (long long)bz * g.batch_stride_a;
@@ -657,20 +832,22 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       int row = m0 + r + 32 * p;
       row = row < g.M ? row : g.M - 1;
       a_ptr[p] = Asrc + (size_t)row * g.lda + c4 * 4;
+      if (MODE == 1) ff_ln_issue(g.ln_in + (size_t)row * g.ln_nseg * 2, g.ln_nseg, c4, ln_raw[p]);
       int n = n0 + r + 32 * p;
       n = n < g.N ? n : g.N - 1;
       w_ptr[p] = W + (size_t)n * g.ldw + c4 * 4;
     }
+    if (MODE == 1) { if (defer) pend = 3; else ln_finish(); }
   };
   int ld_p = 0, ld_j, ld_end;
   {
     int tile, j0, n, kind;
     segment(0, tile, j0, n, kind);
-    set_load_tile(tile);
+    set_load_tile(tile, false);
     ld_j = j0; ld_end = j0 + n;
   }
   f32x4 ra[2][2], rw[2][2];
-  auto load_next = [&](f32x4* xa, f32x4* xw) {
+  auto load_next = [&](f32x4* xa, f32x4* xw, int u) {
     const int kk0 = ld_j * BK;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -678,12 +855,12 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       xw[p] = *reinterpret_cast<const f32x4*>(w_ptr[p] + kk0);
     }
   };
-  auto advance = [&]() {  // block-uniform; past the last segment the cursor stays on its last slice
+  auto advance = [&](bool defer) {  // block-uniform; past the last segment the cursor stays on its last slice
     if (++ld_j == ld_end) {
       if (ld_p + 1 < nseg) {
         int tile, j0, n, kind;
         segment(++ld_p, tile, j0, n, kind);
-        set_load_tile(tile);
+        set_load_tile(tile, defer);
         ld_j = j0; ld_end = j0 + n;
       } else {
         ld_j = ld_end - 1;
@@ -692,10 +869,11 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   };
   float* const st_a = lds + r * LDS_LD + c4 * 4;
   float* const st_w = st_a + BM * LDS_LD;
-  auto store_from = [&](const f32x4* xa, const f32x4* xw, int buf) {
+  auto store_from = [&](const f32x4* xa, const f32x4* xw, int buf, int u) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + 32 * p * LDS_LD) = xa[p];
+      *reinterpret_cast<f32x4*>(st_a + buf * BUF_FLOATS + 32 * p * LDS_LD) =
+          MODE == 1 ? (xa[p] - cur_mu[p]) * cur_rs[p] : xa[p];
       *reinterpret_cast<f32x4*>(st_w + buf * BUF_FLOATS + 32 * p * LDS_LD) = xw[p];
     }
   };
@@ -745,6 +923,8 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
         row = row < g.M ? row : g.M - 1;
         rv[e] = g.res[e_coff + (size_t)row * g.ldr + colc];
       }
+    } else if (MODE == 1 && g.rowtab && colc < g.rowtab_cols) {  // additive table indexed by row / div (positions)
+      ff_load_rowtab(g, e_row0, colc, rv);
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e) rv[e] = 0.f;
@@ -788,46 +968,63 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       if (tid < lb - c0) __hip_atomic_store(sk.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     float* cp = g.C + e_coff;
+    float fin[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = e_row0 + (e & 3) + 8 * (e >> 2);
-      float v = acc[e] + bv;
+      const bool tab = MODE == 1 && g.rowtab != nullptr;   // a position table belongs INSIDE the activation
+      float v = acc[e] + bv + (tab ? rv[e] : 0.f);
       if (g.act == 1) v = fmaxf(v, 0.f);
-      v += rv[e];
+      if (!tab) v += rv[e];
       if (row < g.M && e_colok) cp[(size_t)row * g.ldc + e_col] = v;
+      fin[e] = v;
       acc[e] = 0.f;
     }
+    if (MODE == 2)
+      ff_emit_ln_stats(fin, lds + 3 * BUF_FLOATS + wave * (32 * 33), l32, half, e_row0 - 4 * half, g.M, g.ln_out,
+                       g.N >> 5, (e_col - l32) >> 5);
   };
 
   // prologue: slices 0,1 -> LDS; slices 2,3 -> staging registers
-  load_next(ra[0], rw[0]); advance();
-  load_next(ra[1], rw[1]); advance();
-  store_from(ra[0], rw[0], 0);
-  store_from(ra[1], rw[1], 1);
-  load_next(ra[0], rw[0]); advance();
-  load_next(ra[1], rw[1]); advance();
+  // Segments hold an even number (>= 2) of slices: a 2-slice first segment ends at the second advance -- the
+  // statistics of the next tile are then merged on the spot (slices 0, 1 keep the first segment's, captured here).
+  load_next(ra[0], rw[0], 0); advance(false);
+  load_next(ra[1], rw[1], 1);
+  const float p_mu0 = cur_mu[0], p_mu1 = cur_mu[1], p_rs0 = cur_rs[0], p_rs1 = cur_rs[1];
+  advance(false);
+  {
+    const float n_mu0 = cur_mu[0], n_mu1 = cur_mu[1], n_rs0 = cur_rs[0], n_rs1 = cur_rs[1];
+    cur_mu[0] = p_mu0; cur_mu[1] = p_mu1; cur_rs[0] = p_rs0; cur_rs[1] = p_rs1;
+    store_from(ra[0], rw[0], 0, 0);
+    store_from(ra[1], rw[1], 1, 1);
+    cur_mu[0] = n_mu0; cur_mu[1] = n_mu1; cur_rs[0] = n_rs0; cur_rs[1] = n_rs1;
+  }
+  load_next(ra[0], rw[0], 0); advance(false);
+  load_next(ra[1], rw[1], 1); advance(true);
   begin_segment(0);
   __syncthreads();
   read_frags(fa[0], fb[0], 0);
 
   int b0 = 0, b1 = 1, b2 = 2;
-  const int total_slices = 2 * (u1 - u0);
-  for (int s = 0; s < total_slices; s += 2) {
+  // Outer loop over the segments of this block's unit range, inner loop over the slices of one segment (as in
+  // gemm_persist_kernel: the pipeline state runs across, the hand-over / epilogue sits between two inner loops).
+  for (cp_p = 0; cp_p < nseg; ++cp_p) {
+    for (int s = 0; s < cp_n; s += 2) {  // segments hold an even number of slices
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      read_frags(fa[u ^ 1], fb[u ^ 1], b1);
-      store_from(ra[u], rw[u], b2);
-      load_next(ra[u], rw[u]);
-      mfma_frags(fa[u], fb[u]);
-      ff_interleave_hints<16, 8, 4, 4>();
-      advance();
-      if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
-        end_segment();
-        if (++cp_p < nseg) begin_segment(cp_p);
+      for (int u = 0; u < 2; ++u) {
+        if (MODE == 1 && pend > 0 && --pend == 0) ln_finish();   // block-uniform
+        read_frags(fa[u ^ 1], fb[u ^ 1], b1);
+        store_from(ra[u], rw[u], b2, u);
+        load_next(ra[u], rw[u], u);
+        mfma_frags(fa[u], fb[u]);
+        ff_persist_hints<MODE>();
+        advance(true);
+        __syncthreads();
+        { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
       }
-      __syncthreads();
-      { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
     }
+    end_segment();
+    if (cp_p + 1 < nseg) begin_segment(cp_p + 1);
   }
 }
 
@@ -874,18 +1071,32 @@ int launch_pipe(GemmArgs g, int batch, hipStream_t st) {
   return FF_OK;
 }
 
-int launch_persist(GemmArgs g, int batch, hipStream_t st) {
-  if (g.K % 64 != 0 || g.K < 128) return launch_pipe<64, 64, 32, 32>(g, batch, st);
+inline int gemm_mode(const GemmArgs& g) { return g.ln_in ? 1 : (g.ln_out ? 2 : 0); }
+constexpr int LN_PATCH_BYTES = 4 * 32 * 33 * (int)sizeof(float);  // MODE 2: one [32][33] patch per wave
+
+template <int MODE>
+int launch_persist_mode(GemmArgs g, int batch, hipStream_t st) {
   static AttrFlags attr_set = {};
-  constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float);
-  FF_RETURN_IF(set_lds_limit(&gemm_persist_kernel, bytes, &attr_set));
+  constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float) + (MODE == 2 ? LN_PATCH_BYTES : 0);
+  FF_RETURN_IF(set_lds_limit(&gemm_persist_kernel<MODE>, bytes, &attr_set));
   g.tiles_m = ff_cdiv(g.M, 64);
   g.tiles_n = ff_cdiv(g.N, 64);
   const long total = (long)g.tiles_m * g.tiles_n * batch;
   const int grid = total < 512 ? (int)total : 512;  // 256 CUs x 2 resident blocks
-  hipLaunchKernelGGL(gemm_persist_kernel, dim3(grid), dim3(256), bytes, st, g, (int)total);
+  hipLaunchKernelGGL(gemm_persist_kernel<MODE>, dim3(grid), dim3(256), bytes, st, g, (int)total);
   FF_CHECK_LAUNCH();
   return FF_OK;
+}
+
+int launch_persist(GemmArgs g, int batch, hipStream_t st) {
+  const int mode = gemm_mode(g);
+  if (g.K % 64 != 0 || g.K < 128) {
+    FF_CHECK_ARG(mode == 0, "ff_gemm_f32: the LayerNorm-fused forms need K %% 64 == 0 and K >= 128 (K=%d)", g.K);
+    return launch_pipe<64, 64, 32, 32>(g, batch, st);
+  }
+  if (mode == 1) return launch_persist_mode<1>(g, batch, st);
+  if (mode == 2) return launch_persist_mode<2>(g, batch, st);
+  return launch_persist_mode<0>(g, batch, st);
 }
 
 // Stream-K workspace: one per (device, stream) -- launches on one stream are ordered, launches on
@@ -932,9 +1143,9 @@ int sk_acquire(hipStream_t st, StreamK* out) {
 // global memory (row = lane & 31, four consecutive k per 16-byte load; lane half h takes k = 8j + 4h .. +3 of
 // every 8-wide group, the same for A and W), each wave accumulates a quarter of K for the same 32x32 tile,
 // and the four partial tiles meet in 16 KB of LDS; every wave finishes four of the sixteen accumulator rows.
-template <int KQ>  // K / 4 (per-wave K range), a multiple of 8
+template <int KQ, int MODE>  // KQ = K / 4 (per-wave K range), a multiple of 8; MODE as gemm_persist_kernel
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64 + (MODE == 2 ? 32 * 33 : 0)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int m0 = (blockIdx.x / g.tiles_n) * 32, n0 = (blockIdx.x % g.tiles_n) * 32;
   const long long bz = blockIdx.y;
@@ -944,6 +1155,8 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   col = col < g.N ? col : g.N - 1;
   const float* ap = Asrc + (size_t)row * g.lda + wave * KQ + half * 4;
   const float* wp = g.W + bz * g.batch_stride_w + (size_t)col * g.ldw + wave * KQ + half * 4;
+  float mu = 0.f, rs = 1.f;
+  if (MODE == 1) ff_merge_ln_stats(g.ln_in + (size_t)row * g.ln_nseg * 2, g.ln_nseg, g.ln_eps, mu, rs);
   constexpr int NG = KQ / 8;  // 8-wide k groups per wave
   f32x16 acc;
 #pragma unroll
@@ -958,9 +1171,11 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
       b[j] = *reinterpret_cast<const f32x4*>(wp + (g0 + j) * 8);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (MODE == 1) a[j] = (a[j] - mu) * rs;
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][c], b[j][c], acc, 0, 0, 0);
+    }
   }
   // partial tiles -> LDS [wave][reg][lane]; wave w then owns registers 4w .. 4w+3 (rows 8w + 0..3 + 4*half)
 #pragma unroll
@@ -978,41 +1193,81 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
     v[q] = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
            (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
     orow[q] = m0 + 8 * wave + q + 4 * half;
-    rv[q] = (g.res && colok && orow[q] < g.M) ? g.res[bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol] : 0.f;
+    const bool ok = colok && orow[q] < g.M;
+    rv[q] = 0.f;
+    if (g.res) { if (ok) rv[q] = g.res[bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol]; }
+    else if (MODE == 1 && g.rowtab && ok && ocol < g.rowtab_cols)
+      rv[q] = g.rowtab[(size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol];
   }
+  float* patch = red + 4 * 16 * 64;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    float o = v[q] + bv;
+    const bool tab = MODE == 1 && g.rowtab != nullptr && !g.res;
+    float o = v[q] + bv + (tab ? rv[q] : 0.f);
     if (g.act == 1) o = fmaxf(o, 0.f);
-    o += rv[q];
+    if (!tab) o += rv[q];
     if (colok && orow[q] < g.M) Cout[(size_t)orow[q] * g.ldc + ocol] = o;
+    if (MODE == 2) patch[(8 * wave + q + 4 * half) * 33 + l32] = o;
   }
+  if (MODE == 2) {  // row statistics of the finished 32x32 tile: 64 threads, (row, column half) each
+    __syncthreads();
+    if (tid < 64) {
+      float x[16], sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { x[c] = patch[l32 * 33 + half * 16 + c]; sm += x[c]; }
+      sm += __shfl_xor(sm, 32, FF_WAVE);
+      const float mean = sm * (1.0f / 32.0f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { const float d = x[c] - mean; m2 += d * d; }
+      m2 += __shfl_xor(m2, 32, FF_WAVE);
+      const int r = m0 + l32;
+      if (half == 0 && r < g.M) {
+        *reinterpret_cast<f32x2*>(g.ln_out + ((size_t)r * (g.N >> 5) + (n0 >> 5)) * 2) = f32x2{mean, m2};
+      }
+    }
+  }
+}
+
+template <int MODE>
+int launch_small_mode(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  switch (g.K) {
+    case 512: hipLaunchKernelGGL((gemm_small_kernel<128, MODE>), grid, dim3(256), 0, st, g); break;
+    case 1024: hipLaunchKernelGGL((gemm_small_kernel<256, MODE>), grid, dim3(256), 0, st, g); break;
+    case 128: hipLaunchKernelGGL((gemm_small_kernel<32, MODE>), grid, dim3(256), 0, st, g); break;
+    case 256: hipLaunchKernelGGL((gemm_small_kernel<64, MODE>), grid, dim3(256), 0, st, g); break;
+    default: ff_set_error("ff_gemm_f32: small-M kernel supports K in {128, 256, 512, 1024}"); return FF_ERR_ARG;
+  }
+  FF_CHECK_LAUNCH();
+  return FF_OK;
 }
 
 int launch_small(GemmArgs g, int batch, hipStream_t st) {
   g.tiles_m = ff_cdiv(g.M, 32);
   g.tiles_n = ff_cdiv(g.N, 32);
   const dim3 grid(g.tiles_m * g.tiles_n, batch);
-  switch (g.K) {
-    case 512: hipLaunchKernelGGL(gemm_small_kernel<128>, grid, dim3(256), 0, st, g); break;
-    case 1024: hipLaunchKernelGGL(gemm_small_kernel<256>, grid, dim3(256), 0, st, g); break;
-    case 128: hipLaunchKernelGGL(gemm_small_kernel<32>, grid, dim3(256), 0, st, g); break;
-    case 256: hipLaunchKernelGGL(gemm_small_kernel<64>, grid, dim3(256), 0, st, g); break;
-    default: ff_set_error("ff_gemm_f32: small-M kernel supports K in {128, 256, 512, 1024}"); return FF_ERR_ARG;
-  }
-  FF_CHECK_LAUNCH();
-  return FF_OK;
+  const int mode = gemm_mode(g);
+  if (mode == 1) return launch_small_mode<1>(g, grid, st);
+  if (mode == 2) return launch_small_mode<2>(g, grid, st);
+  return launch_small_mode<0>(g, grid, st);
 }
 bool small_ok(const GemmArgs& g) {
   return (g.K == 128 || g.K == 256 || g.K == 512 || g.K == 1024) && (!g.A2 || (g.n_split % 32) == 0);
 }
 
 // mode 0: whole tiles (persistent kernel) or equal unit ranges, whichever the cost model prefers; 2: unit ranges
-int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
-  if (g.K % 64 != 0 || g.K < 128) return launch_pipe<64, 64, 32, 32>(g, batch, st);
+template <int MODE>
+int launch_streamk_mode(const GemmArgs& g, const StreamK& sk, int grid, hipStream_t st) {
   static AttrFlags attr_set = {};
-  constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float);
-  FF_RETURN_IF(set_lds_limit(&gemm_streamk_kernel, bytes, &attr_set));
+  constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float) + (MODE == 2 ? LN_PATCH_BYTES : 0);
+  FF_RETURN_IF(set_lds_limit(&gemm_streamk_kernel<MODE>, bytes, &attr_set));
+  hipLaunchKernelGGL(gemm_streamk_kernel<MODE>, dim3(grid), dim3(256), bytes, st, g, sk);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
+  if (g.K % 64 != 0 || g.K < 128) return launch_persist(g, batch, st);   // (reports the LN-fused restriction)
   g.tiles_m = ff_cdiv(g.M, 64);
   g.tiles_n = ff_cdiv(g.N, 64);
   StreamK sk;
@@ -1036,9 +1291,10 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   sk.base = (int)(units / grid);
   sk.rem = (int)(units % grid);
   FF_RETURN_IF(sk_acquire(st, &sk));
-  hipLaunchKernelGGL(gemm_streamk_kernel, dim3((int)grid), dim3(256), bytes, st, g, sk);
-  FF_CHECK_LAUNCH();
-  return FF_OK;
+  const int lm = gemm_mode(g);
+  if (lm == 1) return launch_streamk_mode<1>(g, sk, (int)grid, st);
+  if (lm == 2) return launch_streamk_mode<2>(g, sk, (int)grid, st);
+  return launch_streamk_mode<0>(g, sk, (int)grid, st);
 }
 
 }  // namespace
@@ -1058,6 +1314,31 @@ extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_t
   g_small_max_rows = small_max_rows;
   return FF_OK;
 }
+
+namespace {
+int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
+  const bool split128 = !g.A2 || (g.n_split % 128) == 0;
+  if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
+  if (tile == 5 && !split128) tile = 4;
+  const int M = g.M, N = g.N, K = g.K;
+  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
+  ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (g.res ? 2 : 1)));
+  switch (tile) {
+    case 1: return launch_generic<64, 64, 32, 32>(g, batch, st);
+    case 2: return launch_pipe<64, 64, 32, 32>(g, batch, st);
+    case 3: return launch_persist(g, batch, st);
+    case 4: return launch_pipe<128, 64, 64, 32>(g, batch, st);
+    case 6: return launch_streamk(g, batch, st, 2);
+    case 7:
+      // few rows, the path's K (512 / 1024): the unstaged split-K kernel (its unshared operand loads cost more
+      // than the staging from ~1000 rows on; with K < 512 a wave's share of K is too short to be worth it)
+      if ((long)M * batch <= g_small_max_rows && K >= 512 && small_ok(g)) return launch_small(g, batch, st);
+      return launch_streamk(g, batch, st, 0);
+    case 8: FF_CHECK_ARG(small_ok(g), "ff_gemm_f32: tile 8 needs K in {128,256,512,1024}"); return launch_small(g, batch, st);
+    default: return launch_pipe<128, 128, 64, 64>(g, batch, st);
+  }
+}
+}  // namespace
 
 extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
                                    const float* W, int ldw, const float* bias, const float* residual,
@@ -1079,27 +1360,37 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
   if (A2) FF_CHECK_ARG(n_split > 0 && n_split < N && (n_split % 64) == 0, "ff_gemm_f32: n_split must be a multiple of 64 inside (0,N)");
   GemmArgs g{A, A2, W, bias, residual, C, lda, ldw, ldr, ldc, M, N, K, A2 ? n_split : N, act, 0, 0,
-             stride_a, stride_w, stride_c};
-  const bool split128 = !A2 || (n_split % 128) == 0;
-  if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
-  if (tile == 5 && !split128) tile = 4;
-  hipStream_t st = (hipStream_t)stream;
-  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
-  ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));
-  switch (tile) {
-    case 1: return launch_generic<64, 64, 32, 32>(g, batch, st);
-    case 2: return launch_pipe<64, 64, 32, 32>(g, batch, st);
-    case 3: return launch_persist(g, batch, st);
-    case 4: return launch_pipe<128, 64, 64, 32>(g, batch, st);
-    case 6: return launch_streamk(g, batch, st, 2);
-    case 7:
-      // few rows, the path's K (512 / 1024): the unstaged split-K kernel (its unshared operand loads cost more
-      // than the staging from ~1000 rows on; with K < 512 a wave's share of K is too short to be worth it)
-      if ((long)M * batch <= g_small_max_rows && K >= 512 && small_ok(g)) return launch_small(g, batch, st);
-      return launch_streamk(g, batch, st, 0);
-    case 8: FF_CHECK_ARG(small_ok(g), "ff_gemm_f32: tile 8 needs K in {128,256,512,1024}"); return launch_small(g, batch, st);
-    default: return launch_pipe<128, 128, 64, 64>(g, batch, st);
-  }
+             stride_a, stride_w, stride_c, nullptr, 0, 0.f, nullptr, 0, 1, 0, nullptr};
+  return gemm_dispatch(g, batch, tile, (hipStream_t)stream);
+}
+
+extern "C" int ff_gemm_f32_ln(const ff_gemm_ln_desc* d, ff_stream_t stream) {
+  FF_CHECK_ARG(d != nullptr, "ff_gemm_f32_ln: null descriptor");
+  const int M = d->M, N = d->N, K = d->K;
+  if (M == 0 || N == 0) return FF_OK;
+  FF_CHECK_ARG(M > 0 && N > 0 && K > 0 && (K & 3) == 0, "ff_gemm_f32_ln: bad M=%d N=%d K=%d (K %% 4)", M, N, K);
+  FF_CHECK_ARG(d->A && d->W && d->C, "ff_gemm_f32_ln: null operand");
+  FF_CHECK_ARG((d->lda & 3) == 0 && (d->ldw & 3) == 0 && d->lda >= K && d->ldw >= K && d->ldc >= N,
+               "ff_gemm_f32_ln: bad leading dimensions lda=%d ldw=%d ldc=%d", d->lda, d->ldw, d->ldc);
+  FF_CHECK_ARG(ff_aligned16(d->A) && ff_aligned16(d->W), "ff_gemm_f32_ln: A/W must be 16-byte aligned");
+  FF_CHECK_ARG(!d->residual || d->ldr >= N, "ff_gemm_f32_ln: bad ldr");
+  FF_CHECK_ARG(d->act == 0 || d->act == 1, "ff_gemm_f32_ln: act must be 0 or 1");
+  FF_CHECK_ARG(d->tile == 0 || d->tile == 3 || d->tile == 6 || d->tile == 7 || d->tile == 8,
+               "ff_gemm_f32_ln: tile must be 0, 3, 6, 7 or 8 (the kernels that carry the LayerNorm fusion)");
+  FF_CHECK_ARG(!(d->ln_stats_in && d->ln_stats_out), "ff_gemm_f32_ln: statistics in AND out in one launch are not supported");
+  FF_CHECK_ARG(!d->ln_stats_in || (d->ln_nseg > 0 && d->ln_nseg * 32 == K && d->ln_eps >= 0.f),
+               "ff_gemm_f32_ln: ln_nseg * 32 must equal K (the statistics describe whole rows of A)");
+  FF_CHECK_ARG(!d->ln_stats_in || d->ln_nseg <= 8 * LN_NQ, "ff_gemm_f32_ln: ln_stats_in supports K <= %d", 256 * LN_NQ);
+  FF_CHECK_ARG(!d->row_table || (d->ln_stats_in && !d->residual && d->row_div > 0 && d->row_cols > 0 &&
+                                 d->row_cols <= N && d->ld_row_table >= d->row_cols),
+               "ff_gemm_f32_ln: row_table needs ln_stats_in, no residual, row_div > 0 and 0 < row_cols <= N");
+  FF_CHECK_ARG(!d->ln_stats_out || (N & 31) == 0, "ff_gemm_f32_ln: ln_stats_out needs N %% 32 == 0");
+  FF_CHECK_ARG(!(d->ln_stats_in || d->ln_stats_out) || (K % 64 == 0 && K >= 128),
+               "ff_gemm_f32_ln: the fused forms need K %% 64 == 0 and K >= 128");
+  GemmArgs g{d->A, nullptr, d->W, d->bias, d->residual, d->C, d->lda, d->ldw, d->ldr, d->ldc, M, N, K, N, d->act, 0, 0,
+             0, 0, 0, d->ln_stats_in, d->ln_nseg, d->ln_eps, d->row_table, d->ld_row_table, d->row_div > 0 ? d->row_div : 1,
+             d->row_cols, d->ln_stats_out};
+  return gemm_dispatch(g, 1, d->tile, (hipStream_t)stream);
 }
 
 extern "C" int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split, const float* W,

@@ -378,3 +378,37 @@ extern "C" int ff_assemble_embedding(const float* tok_embed, int num_token, cons
   FF_CHECK_LAUNCH();
   return FF_OK;
 }
+
+// ---- LayerNorm affine folded into the following Linear ------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_columns_kernel(const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ gamma, float* __restrict__ out,
+                                                            int N, int nvec) {
+  const size_t total = (size_t)N * nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / nvec), vi = (int)(i % nvec);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + vi * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + vi * 4);
+    *reinterpret_cast<f32x4*>(out + ((size_t)n * nvec + vi) * 4) = w * g;
+  }
+}
+
+extern "C" int ff_fold_layernorm_linear(const float* W, int ldw, int N, int K, const float* bias, const float* gamma,
+                                        const float* beta, const float* pos, int ldpos, int pos_rows, int pos_cols,
+                                        float* Wf, float* bf, float* P, ff_stream_t stream) {
+  FF_CHECK_ARG(W && gamma && beta && Wf && bf && N > 0 && K > 0 && (K & 3) == 0 && (ldw & 3) == 0 && ldw >= K,
+               "ff_fold_layernorm_linear: bad arguments");
+  FF_CHECK_ARG(ff_aligned16(W) && ff_aligned16(gamma) && ff_aligned16(beta) && ff_aligned16(Wf),
+               "ff_fold_layernorm_linear: tensors must be 16-byte aligned");
+  FF_CHECK_ARG(!pos || (P && pos_rows > 0 && pos_cols > 0 && pos_cols <= N && (ldpos & 3) == 0 && ldpos >= K &&
+                        ff_aligned16(pos)), "ff_fold_layernorm_linear: bad position table arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)N * (K / 4);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(scale_columns_kernel, dim3(grid), dim3(256), 0, st, W, ldw, gamma, Wf, N, K / 4);
+  FF_CHECK_LAUNCH();
+  // bf = beta W^T + bias: one-row product; P = pos W^T
+  FF_RETURN_IF(ff_gemm_f32(beta, K, nullptr, 0, W, ldw, bias, nullptr, 0, bf, N, 1, N, K, 0, 1, stream));
+  if (pos) FF_RETURN_IF(ff_gemm_f32(pos, ldpos, nullptr, 0, W, ldw, nullptr, nullptr, 0, P, pos_cols, pos_rows, pos_cols, K, 0, 1, stream));
+  return FF_OK;
+}

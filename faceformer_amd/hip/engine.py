@@ -7,7 +7,8 @@ import torch
 from . import lib as _L
 from .ops import _dev, _p, _stream, split_weight
 
-DEFAULT_FLAGS = _L.FF_REUSE_LAYER0_QKV | _L.FF_LAST_LAYER_LAST_ROW | _L.FF_DEDUP_PAD_ANCHORS
+DEFAULT_FLAGS = (_L.FF_REUSE_LAYER0_QKV | _L.FF_LAST_LAYER_LAST_ROW | _L.FF_DEDUP_PAD_ANCHORS
+                 | _L.FF_FUSE_LAYERNORM)
 
 
 def _kv_len_from_mask(mask_u8):
@@ -24,10 +25,11 @@ class PathEngine:
     (SURVEY.md Appendix B).  Tensors are referenced, not copied: in-place weight updates are seen.
     """
 
-    def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5, bf16_split_planes=False):
+    def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5, bf16_split_planes=False, fold_layernorm=True):
         self._lib = _L.load()
         self._keep = {}
         self._planes = {}
+        self._folded = {}
         m = _L.Model()
         get = self._get
         self.tensors = tensors
@@ -89,14 +91,48 @@ class PathEngine:
                     setattr(m.dec[i], field, pl.data_ptr())
         m.dec_norm_w, m.dec_norm_b = get("decoder.norm.weight"), get("decoder.norm.bias")
         m.proj_w, m.proj_b = get("project.weight"), get("project.bias")
+        if fold_layernorm and E % 64 == 0 and E >= 128 and m.FF % 64 == 0 and m.FF >= 128:
+            # FF_FUSE_LAYERNORM: gamma / beta of every decoder LayerNorm and the query-position table are folded
+            # ONCE into the projection that consumes them (derived copies: re-made when a weight is updated in place)
+            dev = tensors["project.weight"].device
+            qpos = tensors["query_pos_enc.pos_embed.weight"]
+            with torch.cuda.device(dev):
+                for i in range(n_dec):
+                    p = "decoder.layers.%d." % i
+                    lw = m.dec[i]
+                    lw.ln1_w, lw.ln1_b, lw.ln1_pos = self._fold(
+                        (i, 1), tensors[p + "self_attn.in_proj_weight"], tensors[p + "self_attn.in_proj_bias"],
+                        tensors[p + "norm1.weight"], tensors[p + "norm1.bias"], qpos, 2 * E)
+                    lw.ln2_w, lw.ln2_b, lw.ln2_pos = self._fold(
+                        (i, 2), tensors[p + "multihead_attn.in_proj_weight"][:E], tensors[p + "multihead_attn.in_proj_bias"][:E],
+                        tensors[p + "norm2.weight"], tensors[p + "norm2.bias"], qpos, E)
+                    lw.ln3_w, lw.ln3_b, _ = self._fold(
+                        (i, 3), tensors[p + "linear1.weight"], tensors[p + "linear1.bias"],
+                        tensors[p + "norm3.weight"], tensors[p + "norm3.bias"], None, 0)
+                m.proj_fold_w, m.proj_fold_b, _ = self._fold(
+                    ("proj",), tensors["project.weight"], tensors["project.bias"],
+                    tensors["decoder.norm.weight"], tensors["decoder.norm.bias"], None, 0)
         self.model = m
         self.E, self.H, self.num_token = E, num_head, num_token
         self.device = tensors["project.weight"].device
         self._ws = None
-        self._versions = {k: v._version for k, v in self._keep.items()} if self._planes else {}
+        self._versions = {k: v._version for k, v in self._keep.items()} if (self._planes or self._folded) else {}
         # the stream-K exchange buffer of the launch stream is allocated here, not inside the first decode
         with torch.cuda.device(self.device):
             _L.check(self._lib.ff_gemm_prepare_stream(_stream()), "ff_gemm_prepare_stream")
+
+    def _fold(self, key, W, bias, gamma, beta, pos, pos_cols):
+        """(Wf, bf, P) device pointers of ff_fold_layernorm_linear for one LayerNorm -> Linear pair."""
+        N, K = W.shape
+        Wf = torch.empty((N, K), device=W.device, dtype=torch.float32)
+        bf = torch.empty((N,), device=W.device, dtype=torch.float32)
+        P = torch.empty((pos.shape[0], pos_cols), device=W.device, dtype=torch.float32) if pos is not None else None
+        _L.check(self._lib.ff_fold_layernorm_linear(
+            _p(W), W.stride(0), N, K, _p(bias), _p(gamma), _p(beta), _p(pos), pos.stride(0) if pos is not None else 0,
+            pos.shape[0] if pos is not None else 0, pos_cols, _p(Wf), _p(bf), _p(P), _stream()),
+            "ff_fold_layernorm_linear")
+        self._folded[key] = (Wf, bf, P)
+        return Wf.data_ptr(), bf.data_ptr(), (P.data_ptr() if P is not None else None)
 
     def _get(self, name):
         t = self.tensors[name]

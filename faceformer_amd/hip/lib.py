@@ -13,6 +13,7 @@ FF_MAX_LAYERS = 16
 FF_HEAD_DIM = 64
 FF_PARALLEL, FF_SEQ2SEQ = 0, 1
 FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP, FF_DEDUP_PAD_ANCHORS = 1, 2, 4, 8, 16
+FF_FUSE_LAYERNORM = 32
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -50,6 +51,17 @@ class GemmX3Desc(C.Structure):
     ]
 
 
+class GemmLnDesc(C.Structure):
+    _fields_ = [
+        ("A", fptr), ("lda", C.c_int), ("W", fptr), ("ldw", C.c_int), ("bias", fptr),
+        ("residual", fptr), ("ldr", C.c_int), ("C", fptr), ("ldc", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("act", C.c_int), ("tile", C.c_int),
+        ("ln_stats_in", fptr), ("ln_nseg", C.c_int), ("ln_eps", C.c_float),
+        ("row_table", fptr), ("ld_row_table", C.c_int), ("row_div", C.c_int), ("row_cols", C.c_int),
+        ("ln_stats_out", fptr),
+    ]
+
+
 class MhaWeights(C.Structure):
     _fields_ = [("in_proj_w", fptr), ("in_proj_b", fptr), ("out_w", fptr), ("out_b", fptr)]
 
@@ -62,6 +74,9 @@ class LayerWeights(C.Structure):
         ("norm3_w", fptr), ("norm3_b", fptr),
         ("in_proj_planes", fptr), ("lin1_planes", fptr), ("lin2_planes", fptr),
         ("self_out_planes", fptr), ("cross_q_planes", fptr), ("cross_out_planes", fptr),
+        ("ln1_w", fptr), ("ln1_b", fptr), ("ln1_pos", fptr),
+        ("ln2_w", fptr), ("ln2_b", fptr), ("ln2_pos", fptr),
+        ("ln3_w", fptr), ("ln3_b", fptr),
     ]
 
 
@@ -80,6 +95,7 @@ class Model(C.Structure):
         ("dec", LayerWeights * FF_MAX_LAYERS),
         ("dec_norm_w", fptr), ("dec_norm_b", fptr),
         ("proj_w", fptr), ("proj_b", fptr),
+        ("proj_fold_w", fptr), ("proj_fold_b", fptr),
     ]
 
 
@@ -112,6 +128,9 @@ SIGNATURES = {
     "ff_gemm_f32_batched": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_longlong, C.c_longlong, C.c_longlong, fptr]),
+    "ff_gemm_f32_ln": (C.c_int, [C.POINTER(GemmLnDesc), fptr]),
+    "ff_fold_layernorm_linear": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_int, C.c_int,
+                                           C.c_int, fptr, fptr, fptr, fptr]),
     "ff_split_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ff_split_weight_bf16x3": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, fptr]),
     "ff_gemm_x3": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_int,

@@ -115,6 +115,58 @@ def linear(x, weight, bias=None, act=0, residual=None, x2=None, n_split=0, tile=
 
 
 @_on_tensor_device
+def linear_ln(x, weight, bias=None, act=0, residual=None, stats_in=None, eps=1e-5, row_table=None, row_div=1,
+              row_cols=0, want_stats=False, tile=0, out=None):
+    """ff_gemm_f32_ln: out = act(z @ weight.T + bias [+ row_table[row // row_div]]) [+ residual], where z = x, or --
+    with `stats_in` ([M, K/32, 2] segment statistics of x's rows) -- the row-normalised x.  `want_stats` also
+    returns the [M, N/32, 2] (mean, M2) segment statistics of `out` for the next LayerNorm."""
+    x, lda = _rows(x, "x")
+    weight, ldw = _rows(weight, "weight")
+    M, K = x.shape
+    N = weight.size(0)
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    out, ldc = _rows(out, "out")
+    d = _L.GemmLnDesc()
+    d.A, d.lda, d.W, d.ldw, d.bias = _p(x), lda, _p(weight), ldw, _p(bias)
+    if residual is not None:
+        residual, ldr = _rows(residual, "residual")
+        d.residual, d.ldr = _p(residual), ldr
+    d.C, d.ldc, d.M, d.N, d.K, d.act, d.tile = _p(out), ldc, M, N, K, act, tile
+    if stats_in is not None:
+        _dev(stats_in, "stats_in")
+        stats_in = stats_in.contiguous()
+        d.ln_stats_in, d.ln_nseg, d.ln_eps = _p(stats_in), stats_in.size(1), eps
+    if row_table is not None:
+        row_table, ldt = _rows(row_table, "row_table")
+        d.row_table, d.ld_row_table, d.row_div, d.row_cols = _p(row_table), ldt, row_div, row_cols or row_table.size(1)
+    stats = None
+    if want_stats:
+        stats = torch.full((M, N // 32, 2), float("nan"), device=x.device, dtype=torch.float32)
+        d.ln_stats_out = _p(stats)
+    _L.check(_L.load().ff_gemm_f32_ln(C.byref(d), _stream()), "ff_gemm_f32_ln")
+    return (out, stats) if want_stats else out
+
+
+@_on_tensor_device
+def fold_layernorm_linear(weight, bias, gamma, beta, pos=None, pos_cols=0):
+    """(Wf, bf, P) of ff_fold_layernorm_linear: LN(x) @ weight.T + bias == z @ Wf.T + bf with z the normalised x;
+    P = pos @ weight[:pos_cols].T."""
+    weight, ldw = _rows(weight, "weight")
+    N, K = weight.shape
+    Wf = torch.empty((N, K), device=weight.device, dtype=torch.float32)
+    bf = torch.empty((N,), device=weight.device, dtype=torch.float32)
+    P, ldpos = None, 0
+    if pos is not None:
+        pos, ldpos = _rows(pos, "pos")
+        P = torch.empty((pos.size(0), pos_cols), device=weight.device, dtype=torch.float32)
+    _L.check(_L.load().ff_fold_layernorm_linear(_p(weight), ldw, N, K, _p(bias), _p(gamma), _p(beta), _p(pos), ldpos,
+                                                pos.size(0) if pos is not None else 0, pos_cols, _p(Wf), _p(bf), _p(P),
+                                                _stream()), "ff_fold_layernorm_linear")
+    return Wf, bf, P
+
+
+@_on_tensor_device
 def attention(q, k, v, num_groups, num_heads, nq, nk, q_group_stride, q_inner, q_outer_stride,
               k_group_stride, k_stride, kv_len=None, key_mask=None, causal=False, scale=0.125,
               out=None):

@@ -109,7 +109,7 @@ class SurfaceFormerBase(nn.Module):
                     "device through libfaceformer_hip.so (no CPU fallback). Move the model with "
                     ".cuda()." % dev)
             eng = PathEngine(tensors, self.num_head, self.num_token, self.encoder.norm.eps,
-                             bf16_split_planes=self.x3_min_rows > 0)
+                             bf16_split_planes=self.x3_min_rows > 0, fold_layernorm=True)
             self._engine_obj = eng
         return eng
 

@@ -114,6 +114,42 @@ int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
                         int batch, long long stride_a, long long stride_w, long long stride_c,
                         ff_stream_t stream);
 
+/* The same product with the neighbouring LayerNorm folded in (what ff_decode uses; removes the standalone
+ * LayerNorm launches between the projections of a decoder layer, reference transformer.py:242-253):
+ *   ln_stats_out : the launch that PRODUCES a LayerNorm input x (out-proj / linear2 with their residual) also
+ *                  leaves, per row and per 32-column segment, (mean, M2 = sum of squared deviations) of the
+ *                  stored values: [M][N/32][2] floats.  N % 32 == 0.
+ *   ln_stats_in  : the launch that CONSUMES LayerNorm(x) reads x itself as A and normalises every row while
+ *                  staging it: a <- (a - mean) * rstd with (mean, rstd) merged from the ln_nseg = K/32 segment
+ *                  statistics (Chan's update: no E[x^2] - mean^2 cancellation).  gamma / beta are NOT applied
+ *                  here: the caller passes the folded weight W' = W diag(gamma) and bias' = bias + W beta
+ *                  (ff_fold_layernorm_linear), so that act(LN(x) W^T + bias) = act(z W'^T + bias').
+ *   row_table    : optional [*, ld_row_table] table added to columns < row_cols, row m taking line m / row_div:
+ *                  (LN(x) + pos_j) W^T = LN(x) W^T + (pos W^T)_j for the position-major rows of the decoder
+ *                  (j = m / sequences).  Needs ln_stats_in and no residual.
+ * tile: 0 (automatic), 3, 6, 7 or 8; K % 64 == 0 and K >= 128 for the fused forms, K <= 512 with ln_stats_in. */
+typedef struct ff_gemm_ln_desc {
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;
+  const float* residual; int ldr;
+  float* C; int ldc;
+  int M, N, K, act, tile;
+  const float* ln_stats_in; int ln_nseg; float ln_eps;
+  const float* row_table; int ld_row_table, row_div, row_cols;
+  float* ln_stats_out;
+} ff_gemm_ln_desc;
+int ff_gemm_f32_ln(const ff_gemm_ln_desc* desc, ff_stream_t stream);
+
+/* Fold a LayerNorm's affine part (and a learned position table) into the Linear that follows it:
+ *   Wf[n,k] = W[n,k] * gamma[k]            bf[n] = bias[n] + sum_k W[n,k] * beta[k]
+ *   P[j,n]  = sum_k pos[j,k] * W[n,k]      for j < pos_rows, n < pos_cols   (skipped when pos == NULL)
+ * W [N,K] (ld = ldw), Wf [N,K] contiguous, bf [N], P [pos_rows, pos_cols] contiguous.  Done once per weight
+ * binding by the host side of ff_decode (faceformer_amd/hip/engine.py); products on the f32 MFMA GEMM. */
+int ff_fold_layernorm_linear(const float* W, int ldw, int N, int K, const float* bias, const float* gamma,
+                             const float* beta, const float* pos, int ldpos, int pos_rows, int pos_cols,
+                             float* Wf, float* bf, float* P, ff_stream_t stream);
+
 /* The same product evaluated on the bf16 matrix cores with fp32 accuracy ("3 x bf16"): every fp32
  * operand is split exactly into three bf16 terms and the six partial products of weight >= 2^-16 are
  * accumulated in fp32 (v_mfma_f32_32x32x16_bf16); what is dropped is below one fp32 rounding of the
@@ -256,6 +292,14 @@ typedef struct ff_layer_weights {
   const void *in_proj_planes, *lin1_planes, *lin2_planes;
   /* the same for self_attn.out_w, the q rows of cross_attn.in_proj_w ([E, E]) and cross_attn.out_w */
   const void *self_out_planes, *cross_q_planes, *cross_out_planes;
+  /* optional (decoder layers), written by ff_fold_layernorm_linear: the affine part of norm1 / norm2 / norm3 and
+     the query-position table folded into the projection that consumes the LayerNorm (FF_FUSE_LAYERNORM):
+       ln1_* : norm1 -> self_attn.in_proj   Wf [3E,E], bf [3E], P = qpos [Wq;Wk]^T [qpos_len, 2E]
+       ln2_* : norm2 -> q rows of cross_attn.in_proj   Wf [E,E], bf [E], P = qpos Wq^T [qpos_len, E]
+       ln3_* : norm3 -> linear1             Wf [FF,E], bf [FF] */
+  const float *ln1_w, *ln1_b, *ln1_pos;
+  const float *ln2_w, *ln2_b, *ln2_pos;
+  const float *ln3_w, *ln3_b;
 } ff_layer_weights;
 
 typedef struct ff_model {
@@ -274,6 +318,7 @@ typedef struct ff_model {
   ff_layer_weights dec[FF_MAX_LAYERS];
   const float *dec_norm_w, *dec_norm_b;
   const float *proj_w, *proj_b;        /* project [E, E], [E] */
+  const float *proj_fold_w, *proj_fold_b; /* optional: decoder.norm folded into project (ff_fold_layernorm_linear) */
 } ff_model;
 
 /* Encoder (a1-a4 of SURVEY.md 8a): embedding MLP + token rows, 6 pre-norm layers, final LayerNorm.
@@ -294,6 +339,10 @@ enum ff_decode_flags {
   FF_RETURN_POINTER = 4,     /* also produce project(decoder(...)) for ALL prefix rows of the last step */
   FF_NO_STOP = 8,            /* run all T-1 steps and do not apply the stop rule (multi-GPU: the caller
                                 all-reduces step_counts and applies the GLOBAL rule) */
+  FF_FUSE_LAYERNORM = 32,    /* decoder: no standalone LayerNorm launches between the projections -- the GEMM that
+                                produces a LayerNorm input leaves per-row segment statistics, the GEMM that consumes
+                                it normalises its A rows while staging them (ff_gemm_f32_ln).  Needs the folded
+                                weights (ln1_w ... proj_fold_b) and E, FF multiples of 64, 128 <= E <= 512; otherwise ignored */
   FF_DEDUP_PAD_ANCHORS = 16  /* parallel variant: the F - num_input[w] padding-anchor sequences of a wireframe
                                 (start token num_token-1, reference model_para.py:204-205) are identical by
                                 construction; decode ONE of them and copy its tokens into all those rows of

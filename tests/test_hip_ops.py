@@ -390,3 +390,75 @@ def test_pointer_ties_and_all_masked(ops):
     extra[1, 2] = 1          # per-sequence extra mask removes key 2 for sequence 1 only
     res = ops.pointer_argmax(p.cuda(), mem.cuda(), extra_mask=extra.cuda(), seqs_per_group=2)
     assert res["next"].cpu().tolist() == [2, 5]
+
+
+# ---- LayerNorm folded into the neighbouring projections (ff_gemm_f32_ln) -------------------------------------------
+def _seg_stats(x64):
+    """[M, N] float64 -> [M, N/32, 2] (mean, M2) per 32-column segment."""
+    M, N = x64.shape
+    seg = x64.view(M, N // 32, 32)
+    mean = seg.mean(dim=2)
+    m2 = ((seg - mean[..., None]) ** 2).sum(dim=2)
+    return torch.stack([mean, m2], dim=2)
+
+
+@pytest.mark.parametrize("tile", [0, 3, 6, 8])
+@pytest.mark.parametrize("M,N,K", [(37, 512, 512), (300, 512, 1024), (1300, 512, 512), (5000, 512, 512), (640, 128, 256)])
+def test_gemm_emits_layernorm_segment_statistics(hip_lib, ops, M, N, K, tile):
+    """Producer side: C = A W^T + b + residual plus, per row and 32-column segment, (mean, M2) of the stored C."""
+    if tile == 8 and M > 1024:
+        pytest.skip("small-M kernel")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = (3.0 + 2.0 * torch.randn(M, N, generator=g)).cuda()          # non-zero mean: the cancellation trap
+    out, stats = ops.linear_ln(A, W, b, residual=res, want_stats=True, tile=tile)
+    ref = A.double() @ W.double().t() + b.double() + res.double()
+    assert (out.double() - ref).abs().max() < 2e-5 * ref.abs().max()
+    want = _seg_stats(out.double())                                    # statistics of what was actually stored
+    assert not torch.isnan(stats).any()
+    assert (stats[..., 0].double() - want[..., 0]).abs().max() < 1e-5
+    assert ((stats[..., 1].double() - want[..., 1]).abs() / want[..., 1].clamp_min(1e-6)).max() < 1e-5
+
+
+@pytest.mark.parametrize("tile", [0, 3, 6, 8])
+@pytest.mark.parametrize("M,N,K,div", [(37, 1536, 512, 5), (300, 512, 512, 7), (1300, 1536, 512, 64), (5000, 1024, 512, 256),
+                                       (256, 512, 128, 16)])
+def test_gemm_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, M, N, K, div, tile):
+    """Consumer side: act((LN(x) + pos[row // div]) W^T + b) from raw x, its segment statistics, the folded
+    weight / bias and the pos W^T table -- against the unfused arithmetic in float64."""
+    if tile == 8 and M > 1024:
+        pytest.skip("small-M kernel")
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = (1.5 + 2.0 * torch.randn(M, K, generator=g)) * (1.0 + torch.rand(M, 1, generator=g))   # row-dependent scale / mean
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    npos = (M + div - 1) // div
+    pos = torch.randn(npos, K, generator=g)
+    pos_cols = N // 2 if N >= 1024 else N
+    xd, Wd = x.cuda(), W.cuda()
+    Wf, bf, P = ops.fold_layernorm_linear(Wd, b.cuda(), gamma.cuda(), beta.cuda(), pos.cuda(), pos_cols)
+    stats = _seg_stats(xd.double()).float().contiguous()
+    out = ops.linear_ln(xd, Wf, bf, act=1, stats_in=stats, row_table=P, row_div=div, row_cols=pos_cols, tile=tile)
+    x64 = x.double()
+    ln = torch.nn.functional.layer_norm(x64, (K,), gamma.double(), beta.double(), 1e-5)
+    rows = torch.arange(M) // div
+    addp = torch.zeros(M, N, dtype=torch.float64)
+    addp[:, :pos_cols] = pos.double()[rows] @ W.double()[:pos_cols].t()
+    ref = torch.relu(ln @ W.double().t() + b.double() + addp)
+    err = (out.cpu().double() - ref).abs().max()
+    assert err < 3e-5 * max(1.0, ref.abs().max()), err
+
+
+def test_gemm_ln_argument_validation(hip_lib, ops):
+    from faceformer_amd.hip import lib as L
+    x = torch.randn(64, 512).cuda()
+    W = torch.randn(512, 512).cuda()
+    with pytest.raises(L.HipExtensionError):       # statistics must describe whole rows: nseg * 32 == K
+        ops.linear_ln(x, W, stats_in=torch.zeros(64, 8, 2).cuda(), tile=0)
+    with pytest.raises(L.HipExtensionError):       # a row table needs statistics
+        ops.linear_ln(x, W, row_table=torch.zeros(4, 512).cuda(), row_div=16, row_cols=512)
+    with pytest.raises(L.HipExtensionError):       # not on the generic kernels
+        ops.linear_ln(x, W, want_stats=True, tile=1)

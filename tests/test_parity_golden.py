@@ -129,7 +129,11 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
                                                         # 16 = FF_DEDUP_PAD_ANCHORS: one padding-anchor sequence
                                                         # per wireframe, width-bucketed micro-batches
                                                         (19, 0, 1, 0, 1), (19, 2, 0, 0, 2), (16, 0, 2, 5, 3),
-                                                        (19, 3, 4, 0, 1)])
+                                                        (19, 3, 4, 0, 1),
+                                                        # 32 = FF_FUSE_LAYERNORM (the default): LayerNorm folded into
+                                                        # the projections; the rows above run the unfused kernels
+                                                        (32, 0, 1, 0, 1), (35, 1, 0, 0, 2), (51, 0, 2, 5, 3),
+                                                        (33, 2, 1, 0, 1), (34, 0, 0, 0, 1)])
 def test_engine_options_do_not_change_results(hip_lib, name, flags, chunk, sync, cseq, nstr):
     """Pruning flags, micro-batching (by wireframe or by sequence group), concurrent streams and the
     host sync period are pure scheduling choices."""
