@@ -452,6 +452,225 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_
   }
 }
 
+// ---- K/V-resident variant ------------------------------------------------------------------------------
+// For key sets of at most 288 rows (every decoder cross-attention of the 64..256-edge configurations, and the
+// encoder): the K and V rows of ONE (group, head) pair -- <= 2 x 72 KB -- are loaded into LDS once per block and
+// stay there; the pair's query tiles are dealt out to `c` blocks (one per CU), so the K/V bytes leave L2 once per
+// block instead of once per 128 (block-shared kernel) or 32 (wave kernel) queries.
+// Work balance: a block's work is the list of (query tile, key tile) ITEMS of its query tiles, cut into eight equal
+// consecutive ranges, one per wave (two per SIMD).  Whole query tiles inside a range are finished by their wave; a
+// query tile cut between waves leaves partial (max, sum, O) records, which meet in LDS (the K/V area is free by
+// then) and are merged in ascending key order by the wave that holds the tile's first keys: deterministic, and the
+// per-SIMD load differs by at most one key tile -- no "2304 tiles on 2048 slots take two rounds" cliff.
+constexpr int RK_KEYS = 288;                     // 9 key tiles
+constexpr int RK_NW = 8;
+constexpr int RK_REC = 34 * 64;                  // one partial record: O[32 regs][64 lanes], m[64], l[64]
+constexpr int RK_LDS_FLOATS = RK_KEYS * 128 + RK_KEYS;
+static_assert(2 * RK_NW * RK_REC <= RK_KEYS * 128, "records must fit the K/V area");
+
+struct RkState {
+  float m, l;
+  f32x16 o0, o1;
+};
+
+__global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const Ks = lds;                       // [key][64], 16-byte chunks XOR-swizzled with (key & 15)
+  float* const Vs = lds + RK_KEYS * 64;        // [key][64]
+  float* const Ms = lds + RK_KEYS * 128;       // additive key bias: 0 or -inf
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+  const float qscale = d.scale * 1.4426950408889634f;
+
+  const int nblk = gridDim.x;
+  const int rank = (P <= nblk) ? blockIdx.x / P : 0;           // which share of the pair's query tiles
+  for (int pair = (P <= nblk) ? blockIdx.x % P : blockIdx.x; pair < P; pair += (P <= nblk ? P : nblk)) {
+    const int g = pair / d.num_heads, h = pair % d.num_heads;
+    const float* kbase = d.k + (size_t)g * d.k_group_stride * d.ldk + h * FF_HEAD_DIM;
+    const float* vbase = d.v + (size_t)g * d.k_group_stride * d.ldv + h * FF_HEAD_DIM;
+    // ---- everything the block needs from memory is requested in ONE round trip: kv_len, the mask bytes, K and V
+    //      (LDS-DMA: no staging registers, all 2 x 9 tiles in flight), the first query tile of every wave ----
+    const int tiles_max = (d.nk + 31) >> 5;               // static bound; the group's own length arrives meanwhile
+    int nk = d.nk;
+    if (d.kv_len) { const int kl = d.kv_len[g]; nk = kl < nk ? kl : nk; }
+    unsigned char mbyte = 0;
+    if (d.key_mask && tid < tiles_max * 32 && tid < d.nk) mbyte = d.key_mask[(size_t)g * d.mask_stride + tid];
+    {
+      // piece = 4 key rows x 256 B of one operand = one wave-instruction (lane: row lane/16, 16-byte slot lane%16);
+      // the LDS image is lane-linear, so K's bank swizzle (slot ^ (row & 15)) is applied to the SOURCE column.
+      // Rows past d.nk read the last row again (finite values; their softmax weight is exactly 0).
+      const int npieces = tiles_max * 8;
+      const int prow = lane >> 4, pos = lane & 15;
+      for (int p = wave; p < npieces; p += RK_NW) {
+        const int row = 4 * p + prow;
+        const int rc = row < d.nk ? row : d.nk - 1;
+        const size_t krow = (size_t)rc * d.k_stride;
+        __builtin_amdgcn_global_load_lds(kbase + krow * d.ldk + ((pos ^ (row & 15)) << 2),
+                                         (__attribute__((address_space(3))) void*)(Ks + p * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(vbase + krow * d.ldv + (pos << 2),
+                                         (__attribute__((address_space(3))) void*)(Vs + p * 256), 16, 0, 0);
+      }
+    }
+    const int ntiles = (nk + 31) >> 5;
+    const int nq_blk = rank < q_tiles ? (q_tiles - rank + c - 1) / c : 0;
+    // ---- this wave's item range ----
+    const int I = nq_blk * ntiles;
+    const int ia = (wave * I) / RK_NW, ib = ((wave + 1) * I) / RK_NW;
+    auto query_row = [&](int qt, bool& valid) -> size_t {
+      const int qi = qt * 32 + l32;
+      valid = qi < d.nq;
+      const int qc = valid ? qi : d.nq - 1;
+      return (size_t)g * d.q_group_stride + (size_t)(qc / d.q_inner) * d.q_outer_stride + (size_t)(qc % d.q_inner);
+    };
+    f32x4 qraw[8];   // query rows of the wave's current tile (one register set: a second one for prefetching every
+                     // tile spills -- 256 VGPRs + scratch; the first tile is fetched under the K/V transfer)
+    auto fetch_q = [&](int qt) {
+      bool qv;
+      const float* qp = d.q + query_row(qt, qv) * d.ldq + h * FF_HEAD_DIM + half * 32;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) qraw[cc] = *reinterpret_cast<const f32x4*>(qp + cc * 4);
+    };
+    if (ia < ib) fetch_q(rank + (ia / ntiles) * c);
+    if (tid < tiles_max * 32) Ms[tid] = (tid >= nk || mbyte != 0) ? -INFINITY : 0.f;
+    __syncthreads();   // (waits for the LDS-DMA: it counts in vmcnt)
+
+    auto process = [&](int qt, int kt0, int kt1, bool fetched, RkState& st) {
+      const int qi = qt * 32 + l32;
+      if (!fetched) fetch_q(qt);
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) qraw[cc] *= qscale;   // in place: one register set for the queries
+      st.m = -INFINITY; st.l = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st.o0[e] = 0.f; st.o1[e] = 0.f; }
+      for (int kt = kt0; kt < kt1; ++kt) {
+        // S^T tile: 32 keys x 32 queries
+        f32x16 sacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+        const float* krow_p = Ks + (kt * 32 + l32) * 64;
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(krow_p + (((half * 8 + cg) ^ (l32 & 15)) << 2));
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qraw[cg].x, sacc, 0, 0, 0);
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qraw[cg].y, sacc, 0, 0, 0);
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qraw[cg].z, sacc, 0, 0, 0);
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qraw[cg].w, sacc, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int keyl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = sacc[r] + Ms[keyl];
+          if (d.causal && keyl > qi) v = -INFINITY;
+          sacc[r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
+        const float m_new = fmaxf(st.m, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = ff_exp2(st.m - m_safe);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pp = ff_exp2(sacc[r] - m_safe);
+          sacc[r] = pp;
+          psum += pp;
+        }
+        st.l = st.l * alpha + psum;
+        st.m = m_new;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int keyl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v0 = Vs[keyl * 64 + l32];
+          const float v1 = Vs[keyl * 64 + 32 + l32];
+          st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[r], st.o0, 0, 0, 0);
+          st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[r], st.o1, 0, 0, 0);
+        }
+      }
+    };
+    auto store_out = [&](int qt, const RkState& st) {
+      bool qv;
+      const size_t qrow = query_row(qt, qv);
+      const float l_tot = st.l + __shfl_xor(st.l, 32, FF_WAVE);
+      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+      if (qv) {
+        float* op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 a = {st.o0[g4 * 4 + 0] * inv, st.o0[g4 * 4 + 1] * inv, st.o0[g4 * 4 + 2] * inv, st.o0[g4 * 4 + 3] * inv};
+          f32x4 b = {st.o1[g4 * 4 + 0] * inv, st.o1[g4 * 4 + 1] * inv, st.o1[g4 * 4 + 2] * inv, st.o1[g4 * 4 + 3] * inv};
+          *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
+          *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = b;
+        }
+      }
+    };
+
+    RkState cur, first;
+    bool has_first = false, has_last = false;
+    int last_k = -1, last_kt0 = 0;
+    for (int it = ia; it < ib;) {   // wave-uniform control flow
+      const int k = it / ntiles, kt0 = it - k * ntiles;
+      const int kt1 = (ntiles - kt0) < (ib - it) ? ntiles : kt0 + (ib - it);
+      process(rank + k * c, kt0, kt1, it == ia, cur);
+      it += kt1 - kt0;
+      if (kt0 == 0 && kt1 == ntiles) {
+        store_out(rank + k * c, cur);
+      } else if (it < ib) {          // more items follow: this is the wave's FIRST partial
+        first = cur;
+        has_first = true;
+      } else {                       // the wave's LAST partial stays in `cur`
+        has_last = true; last_k = k; last_kt0 = kt0;
+      }
+    }
+    __syncthreads();                 // every wave is done with K / V: the area now carries the partial records
+    auto put = [&](const RkState& st, int slot) {
+      float* rec = lds + (wave * 2 + slot) * RK_REC;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { rec[e * 64 + lane] = st.o0[e]; rec[(16 + e) * 64 + lane] = st.o1[e]; }
+      rec[32 * 64 + lane] = st.m;
+      rec[33 * 64 + lane] = st.l;
+    };
+    if (has_first) put(first, 0);
+    if (has_last) put(cur, 1);
+    __syncthreads();
+    if (has_last && last_kt0 == 0) {  // this wave holds the first keys of a cut query tile: merge in ascending key order
+      const int kend = (last_k + 1) * ntiles;
+      float m_star = cur.m;
+      for (int w2 = wave + 1; w2 < RK_NW; ++w2) {
+        const int a2 = (w2 * I) / RK_NW, b2 = ((w2 + 1) * I) / RK_NW;
+        if (a2 >= kend) break;
+        if (b2 == a2) continue;
+        const float* rec = lds + (w2 * 2 + (b2 > kend ? 0 : 1)) * RK_REC;
+        m_star = fmaxf(m_star, rec[32 * 64 + lane]);
+      }
+      const float ms = (m_star == -INFINITY) ? 0.f : m_star;
+      const float sc0 = ff_exp2(cur.m - ms);
+      cur.l *= sc0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { cur.o0[e] *= sc0; cur.o1[e] *= sc0; }
+      for (int w2 = wave + 1; w2 < RK_NW; ++w2) {
+        const int a2 = (w2 * I) / RK_NW, b2 = ((w2 + 1) * I) / RK_NW;
+        if (a2 >= kend) break;
+        if (b2 == a2) continue;
+        const float* rec = lds + (w2 * 2 + (b2 > kend ? 0 : 1)) * RK_REC;
+        const float scj = ff_exp2(rec[32 * 64 + lane] - ms);
+        cur.l += rec[33 * 64 + lane] * scj;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          cur.o0[e] += rec[e * 64 + lane] * scj;
+          cur.o1[e] += rec[(16 + e) * 64 + lane] * scj;
+        }
+      }
+      cur.m = m_star;
+      store_out(rank + last_k * c, cur);
+    }
+    __syncthreads();                 // the next pair overwrites the area
+  }
+}
+
 int g_attention_algo = 0;  // 0 = automatic, 1 = block-shared LDS staging, 2 = wave-independent
 
 }  // namespace
@@ -487,6 +706,29 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   // (at most two query tiles per group: the block-shared kernel then runs one- or two-wave blocks whose LDS
   // chunk limits a CU to four of them); above that the block-shared LDS staging moves 4x fewer bytes from L2
   // and is faster.
+  // K/V-resident kernel: key sets of at most 288 rows shared by several query tiles (decoder cross-attention of the
+  // 64..256-edge configurations, encoder); not for the per-sequence self-attention (2048+ tiny key sets)
+  const int qt32 = ff_cdiv(d.nq, 32);
+  const bool resident_ok = d.nk <= RK_KEYS && d.nk > 0;
+  if (g_attention_algo == 3 ? resident_ok : (g_attention_algo == 0 && resident_ok && qt32 >= 4)) {
+    static bool attr_done[16] = {};
+    int dev = 0;
+    FF_CHECK_HIP(hipGetDevice(&dev));
+    constexpr int lds_bytes = RK_LDS_FLOATS * (int)sizeof(float);
+    if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+      FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_resident_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    }
+    const int P = (int)gh;
+    int c = P <= 256 ? 256 / P : 1;
+    if (c > qt32) c = qt32;
+    if (c < 1) c = 1;
+    const int nblocks = P <= 256 ? P * c : 256;
+    hipLaunchKernelGGL(attention_resident_kernel, dim3(nblocks), dim3(64 * RK_NW), lds_bytes, st, d, P, c, qt32);
+    FF_CHECK_LAUNCH();
+    return FF_OK;
+  }
   const bool use_wave = g_attention_algo == 2 ||
                         (g_attention_algo == 0 && (gh * ff_cdiv(d.nq, 32) < 1536 || d.nq <= 64));
   if (use_wave) {

@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   };
 
   // compute-side segment state
-  int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
+  int cp_p = 0, cp_n = 0, cp_kind = 0;
   int e_row0 = 0, e_col = 0;
   long long e_coff = 0;
   bool e_colok = false;
@@ -906,7 +906,6 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   auto begin_segment = [&](int p) {
     int id, j0;
     segment(p, id, j0, cp_n, cp_kind);
-    cp_cnt = 0;
     if (cp_kind == 1) return;  // raw partial: no epilogue operands
     const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
     const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
@@ -1332,7 +1331,9 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
     case 7:
       // few rows, the path's K (512 / 1024): the unstaged split-K kernel (its unshared operand loads cost more
       // than the staging from ~1000 rows on; with K < 512 a wave's share of K is too short to be worth it)
-      if ((long)M * batch <= g_small_max_rows && K >= 512 && small_ok(g)) return launch_small(g, batch, st);
+      // (wide outputs leave it earlier: at 1024 rows the persistent kernel is 8 % / 22 % faster for N = 1536 / 1024)
+      if ((long)M * batch <= (N <= 512 ? g_small_max_rows : (g_small_max_rows * 3) / 4) && K >= 512 && small_ok(g))
+        return launch_small(g, batch, st);
       return launch_streamk(g, batch, st, 0);
     case 8: FF_CHECK_ARG(small_ok(g), "ff_gemm_f32: tile 8 needs K in {128,256,512,1024}"); return launch_small(g, batch, st);
     default: return launch_pipe<128, 128, 64, 64>(g, batch, st);

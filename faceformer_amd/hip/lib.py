@@ -105,7 +105,7 @@ class DecodeParams(C.Structure):
         ("chunk_wireframes", C.c_int), ("chunk_seqs", C.c_int), ("num_streams", C.c_int),
         ("sync_every", C.c_int), ("flags", C.c_int),
         ("tok_sos", C.c_int), ("tok_eos", C.c_int),
-        ("x3_min_rows", C.c_int), ("chunk_max_seqs", C.c_int),
+        ("x3_min_rows", C.c_int), ("chunk_max_seqs", C.c_int), ("ln_fuse_max_rows", C.c_int),
     ]
 
 

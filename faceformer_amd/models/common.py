@@ -50,8 +50,13 @@ class SurfaceFormerBase(nn.Module):
         self.num_streams = 1           # micro-batches are issued round-robin on this many HIP streams
         self.chunk_max_seqs = 8192     # ... and at most this many sequences per micro-batch of several wireframes
         self.sort_by_edges = True      # ragged batches: decode the wireframes sorted by edge count (tight micro-batches)
+        self.ln_fuse_max_rows = 0      # LayerNorm folded into the projections on steps with at most this many rows (0: 4096)
         self.sync_every = 4            # host evaluation period of the stop rule
-        self.x3_min_rows = 0           # >0: q|k|v / FFN projections as 3 x bf16 products from this many rows on
+        # Decoder projections of launches with at least this many rows (q|k|v; linear2 from 1.5x, linear1 from 2x, the
+        # E x E ones from 4x as many) run as 3 x bf16 split products on the bf16 matrix cores: fp32-accurate (error
+        # vs fp64 = an fp32 dot product's, tests/test_hip_ops.py) and 1.2-1.5x the f32-MFMA kernel from ~9000 rows
+        # on (config C / E micro-batches; a single 256-edge wireframe reaches that only in its last steps).  0 = off.
+        self.x3_min_rows = 4096
         self._engine_obj = None
 
     def _reset_parameters(self):

@@ -226,7 +226,8 @@ typedef struct ff_attn_desc {
 
 int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
 /* Kernel selection for ff_attention (tuning / tests): 0 automatic, 1 block-shared LDS staging,
- * 2 wave-independent with in-block key splitting.  Returns the previous value. */
+ * 2 wave-independent with in-block key splitting, 3 K/V-resident (key sets of at most 288 rows; larger ones fall
+ * back to the automatic choice between 1 and 2).  Returns the previous value. */
 int ff_set_attention_algo(int algo);
 
 /* ---------------------------------------------------------------------------------------------
@@ -368,6 +369,8 @@ typedef struct ff_decode_params {
                            has at least this many prefix rows (t * sequences); 0: never */
   int chunk_max_seqs;   /* > 0: a micro-batch of several wireframes holds at most this many sequences
                            (a single wireframe is never cut by it); 0: no limit */
+  int ln_fuse_max_rows; /* FF_FUSE_LAYERNORM applies to decode steps with at most this many active rows
+                           (t * sequences of the micro-batch); 0: the default (4096) */
 } ff_decode_params;
 
 /* Greedy pointer decode (a5-a12 of SURVEY.md 8a).

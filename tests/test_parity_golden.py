@@ -43,7 +43,8 @@ def run_traced(model, case, batch):
                          extra_mask=extra, sync_every=model.sync_every, flags=model.decode_flags,
                          x3_min_rows=model.x3_min_rows,
                          chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
-                         chunk_max_seqs=model.chunk_max_seqs, num_streams=model.num_streams)
+                         chunk_max_seqs=model.chunk_max_seqs, num_streams=model.num_streams,
+                         ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0))
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          extra_mask=extra, flags=model.decode_flags, return_pointer=True,
@@ -104,6 +105,27 @@ def test_golden_parity(hip_lib, name):
     out = run_traced(model, case, batch_to(batch, "cuda"))
     stats = compare_with_golden(case, z, out)
     print(name, stats)
+
+
+@pytest.mark.parametrize("name", ["par_full_B256_gain4", "par_full_B256_default", "par_full_n40_gain4", "par_small_ragged300"])
+def test_golden_parity_on_the_f32_matrix_cores_only(hip_lib, name):
+    """The package default sends large decoder projections through the 3 x bf16 split kernel and folds the
+    LayerNorms into the projections of the small steps; this is the plain form (f32 MFMA everywhere, standalone
+    LayerNorm launches) -- what bench.py's headline measures for the GEMMs -- and the always-fused form."""
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    model.x3_min_rows = 0
+    out = run_traced(model, case, batch_to(batch, "cuda"))
+    print(name, "f32", compare_with_golden(case, z, out))
+    from faceformer_amd.hip import lib as L
+    model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
+    out = run_traced(model, case, batch_to(batch, "cuda"))
+    print(name, "f32, unfused", compare_with_golden(case, z, out))
+    model.decode_flags = model.decode_flags | L.FF_FUSE_LAYERNORM
+    model.ln_fuse_max_rows = 1 << 30
+    out = run_traced(model, case, batch_to(batch, "cuda"))
+    print(name, "f32, LayerNorm fused at every size", compare_with_golden(case, z, out))
 
 
 @pytest.mark.parametrize("min_rows", [1, 300])

@@ -1,0 +1,45 @@
+"""Cross-attention (config B shapes, one wireframe) over decode steps and key counts, every kernel variant.
+Back-to-back launches timed with events (queue depth hides the host): us per launch.
+    python tools/attn_sweep.py"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from faceformer_amd.hip import lib as L, ops  # noqa: E402
+
+lib = L.load()
+F, H, E = 256, 8, 512
+
+
+def run(t, S, algo, iters=30):
+    ops.set_attention_algo(algo)
+    q = torch.randn(t * F, E, device="cuda")
+    kv = torch.randn(S, 2 * E, device="cuda")
+    out = torch.empty(t * F, E, device="cuda")
+    d = L.AttnDesc()
+    d.q, d.k, d.v, d.o = q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * E, out.data_ptr()
+    d.ldq, d.ldk, d.ldv, d.ldo = E, 2 * E, 2 * E, E
+    d.num_groups, d.num_heads, d.nq, d.nk = 1, H, F * t, S
+    d.q_group_stride, d.q_inner, d.q_outer_stride = F, F, F
+    d.k_group_stride, d.k_stride = S, 1
+    d.scale = 0.125
+    st = torch.cuda.current_stream().cuda_stream
+    lib.ff_attention(C.byref(d), st)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        lib.ff_attention(C.byref(d), st)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+print("%4s %5s | %8s %8s %8s" % ("t", "S", "lds(1)", "wave(2)", "resid(3)"))
+for S in (32, 64, 132, 260):
+    for t in (1, 4, 8, 16, 24, 32, 36):
+        print("%4d %5d | %8.1f %8.1f %8.1f" % (t, S, run(t, S, 1), run(t, S, 2), run(t, S, 3)))
+ops.set_attention_algo(0)
