@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfaceformer_hip.so")
+LIB_PATH = os.environ.get("FF_HIP_LIB") or os.path.join(HERE, "libfaceformer_hip.so")   # (override: A/B of kernel builds, tools/)
 
 FF_MAX_LAYERS = 16
 FF_HEAD_DIM = 64
