@@ -409,9 +409,12 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
 }
 
 // Internal side streams + fork/join events: one pool per device, created on first use.
+constexpr int FF_PINNED_COUNTERS = 8192;
 struct StreamPool {
   hipStream_t side[FF_MAX_STREAMS];
   hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];
+  hipEvent_t chk_ev[FF_MAX_STREAMS], chk_done;   // stop-rule check: per-stream progress marks, copy completion
+  int* hpin;                                       // pinned host copy of the per-step counters
   int created;
   bool events;
 };
@@ -427,8 +430,12 @@ int pool_get(int n, StreamPool** out) {
   StreamPool& pool = g_pools[dev];
   if (!pool.events) {
     FF_CHECK_HIP(hipEventCreateWithFlags(&pool.fork_ev, hipEventDisableTiming));
-    for (int i = 0; i < FF_MAX_STREAMS; ++i)
+    for (int i = 0; i < FF_MAX_STREAMS; ++i) {
       FF_CHECK_HIP(hipEventCreateWithFlags(&pool.join_ev[i], hipEventDisableTiming));
+      FF_CHECK_HIP(hipEventCreateWithFlags(&pool.chk_ev[i], hipEventDisableTiming));
+    }
+    FF_CHECK_HIP(hipEventCreateWithFlags(&pool.chk_done, hipEventDisableTiming));
+    FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.hpin), sizeof(int) * FF_PINNED_COUNTERS, hipHostMallocDefault));
     pool.events = true;
   }
   while (pool.created < n) {
@@ -559,10 +566,9 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   sts[0] = main_st;
   StreamPool* pool = nullptr;
   FF_RETURN_IF(ff_gemm_prepare_stream(main_st));
-  if (ns > 1) {
-    FF_RETURN_IF(pool_get(ns, &pool));
+  FF_RETURN_IF(pool_get(ns > 1 ? ns : 0, &pool));   // (also owns the pinned counter buffer / events of the stop check)
+  if (ns > 1)
     for (int s = 0; s < ns; ++s) sts[s] = pool->side[s];
-  }
   auto sync_all = [&]() -> int {
     for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamSynchronize(sts[s]));
     return FF_OK;
@@ -600,8 +606,23 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     const int max_steps = T - 1;
     const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
-    std::vector<int> hcnt(T > 0 ? T : 1);
+    // Stop rule on the host WITHOUT draining the queue: every sync_every steps the counters of the steps enqueued so
+    // far are copied to pinned memory behind the work (event-ordered on every stream); the copy issued at step c is
+    // looked at when step c + sync_every has been enqueued -- by then the host is a whole period ahead of it, so the
+    // wait normally returns at once and the GPU always has a period of steps queued.  A stop is noticed at most
+    // 2 * sync_every - 1 steps late; those surplus steps are dropped by the finalize kernels (exact results).
     bool stopped = false;
+    int pending_enq = 0;   // > 0: a counter copy covering steps [0, pending_enq) is in flight
+    const bool lagged = T <= FF_PINNED_COUNTERS;
+    auto eval_counts = [&](const int* cnt, int n) {
+      if (p->variant == FF_PARALLEL) {
+        for (int s = 0; s < n; ++s) if (cnt[s] == 0) return true;
+      } else {
+        int cum = 0;
+        for (int s = 0; s < n; ++s) { cum += cnt[s]; if (cum == N) return true; }
+      }
+      return false;
+    };
     for (int step = 0; step < max_steps && !stopped; ++step) {
       const int t = step + 1;
       for (const Chunk& c : chunks) {
@@ -618,18 +639,33 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       }
       enq = step + 1;
       if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
-        FF_RETURN_IF(sync_all());
         const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
-        FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
-        FF_CHECK_HIP(hipStreamSynchronize(main_st));
-        if (p->variant == FF_PARALLEL) {
-          for (int s = 0; s < enq; ++s) if (hcnt[s] == 0) { stopped = true; break; }
+        if (lagged) {
+          if (pending_enq > 0) {
+            FF_CHECK_HIP(hipEventSynchronize(pool->chk_done));
+            stopped = eval_counts(pool->hpin, pending_enq);
+            pending_enq = 0;
+          }
+          if (!stopped) {
+            if (ns > 1)
+              for (int s = 0; s < ns; ++s) {
+                FF_CHECK_HIP(hipEventRecord(pool->chk_ev[s], sts[s]));
+                FF_CHECK_HIP(hipStreamWaitEvent(main_st, pool->chk_ev[s], 0));
+              }
+            FF_CHECK_HIP(hipMemcpyAsync(pool->hpin, src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+            FF_CHECK_HIP(hipEventRecord(pool->chk_done, main_st));
+            pending_enq = enq;
+          }
         } else {
-          int cum = 0;
-          for (int s = 0; s < enq; ++s) { cum += hcnt[s]; if (cum == N) { stopped = true; break; } }
+          std::vector<int> hcnt(enq);
+          FF_RETURN_IF(sync_all());
+          FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+          FF_CHECK_HIP(hipStreamSynchronize(main_st));
+          stopped = eval_counts(hcnt.data(), enq);
         }
       }
     }
+    if (pending_enq > 0) FF_CHECK_HIP(hipEventSynchronize(pool->chk_done));   // hpin is reused by the next call
     if (dbg_timing) {
       const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
       FF_RETURN_IF(sync_all());
