@@ -510,7 +510,13 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
                                          (__attribute__((address_space(3))) void*)(Vs + p * 256), 16, 0, 0);
       }
     }
-    const int ntiles = (nk + 31) >> 5;
+    const int ntiles_all = (nk + 31) >> 5;
+    // A last key tile with at most 4 keys (S = edges + 4 special tokens with a multiple of 32 edges: every
+    // benchmark configuration) is not worth a 32x32 MFMA tile (64 instructions for <= 1/4 useful work): its scores
+    // and its P.V contribution are evaluated on the VALU (LDS broadcast reads) as an appendix of the last full tile.
+    const int tail = nk - (ntiles_all - 1) * 32;
+    const bool vtail = ntiles_all > 1 && tail <= 4;
+    const int ntiles = vtail ? ntiles_all - 1 : ntiles_all;   // MFMA key tiles = work items per query tile
     const int nq_blk = rank < q_tiles ? (q_tiles - rank + c - 1) / c : 0;
     // ---- this wave's item range ----
     const int I = nq_blk * ntiles;
@@ -588,6 +594,54 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
           const float v1 = Vs[keyl * 64 + 32 + l32];
           st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[r], st.o0, 0, 0, 0);
           st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[r], st.o1, 0, 0, 0);
+        }
+      }
+      if (vtail && kt1 == ntiles) {   // wave-uniform: this range ends with the query tile's last full key tile
+        float sj[4];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = ntiles * 32 + (j < tail ? j : 0);
+          const float* kr = Ks + key * 64;
+          float acc = 0.f;
+#pragma unroll
+          for (int cg = 0; cg < 8; ++cg) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + (((half * 8 + cg) ^ (key & 15)) << 2));
+            acc += (kf.x * qraw[cg].x + kf.y * qraw[cg].y) + (kf.z * qraw[cg].z + kf.w * qraw[cg].w);
+          }
+          acc += __shfl_xor(acc, 32, FF_WAVE);           // the two lane halves hold the two halves of the head dimension
+          float v = acc + Ms[key];
+          if (d.causal && key > qi) v = -INFINITY;
+          if (j >= tail) v = -INFINITY;
+          sj[j] = v;
+          tmax = fmaxf(tmax, v);
+        }
+        const float m_new = fmaxf(st.m, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = ff_exp2(st.m - m_safe);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sj[j] = ff_exp2(sj[j] - m_safe); psum += sj[j]; }
+        st.l = st.l * alpha + (half == 0 ? psum : 0.f);   // both halves hold the SAME tail weights: count them once
+        st.m = m_new;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < tail) {   // block-uniform
+            const float* vr = Vs + (ntiles * 32 + j) * 64 + 4 * half;   // O register e <-> d = (e&3) + 8*(e>>2) + 4*half
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(vr + 8 * g4);
+              const f32x4 b = *reinterpret_cast<const f32x4*>(vr + 32 + 8 * g4);
+              st.o0[g4 * 4 + 0] += sj[j] * a.x; st.o0[g4 * 4 + 1] += sj[j] * a.y;
+              st.o0[g4 * 4 + 2] += sj[j] * a.z; st.o0[g4 * 4 + 3] += sj[j] * a.w;
+              st.o1[g4 * 4 + 0] += sj[j] * b.x; st.o1[g4 * 4 + 1] += sj[j] * b.y;
+              st.o1[g4 * 4 + 2] += sj[j] * b.z; st.o1[g4 * 4 + 3] += sj[j] * b.w;
+            }
+          }
         }
       }
     };

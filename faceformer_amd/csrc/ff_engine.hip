@@ -303,14 +303,32 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
                         ck.qkv0 + newoff * 3 * E, 3 * E, Bc, 3 * E, E, 0, st));
       QKV = ck.qkv0;
     } else if (fuse && l > 0) {
-      FF_RETURN_IF(gemm_ln(xin, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat,
-                           w.ln1_pos, 2 * E, 2 * E, nullptr));
+      if (last && t > 1) {
+        // the pruned last layer attends from its newest position only: k | v for every row, q for the last Bc rows
+        FF_RETURN_IF(gemm_ln(xin, E, w.ln1_w + (size_t)E * E, E, w.ln1_b + E, nullptr, 0, buf.qkv + E, 3 * E, R, 2 * E, E,
+                             0, buf.lnstat, w.ln1_pos + E, 2 * E, E, nullptr));
+        FF_RETURN_IF(gemm_ln(xin + newoff * E, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E,
+                             0, buf.lnstat + newoff * nseg * 2, w.ln1_pos + (size_t)(t - 1) * 2 * E, 2 * E, E, nullptr));
+      } else {
+        FF_RETURN_IF(gemm_ln(xin, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat,
+                             w.ln1_pos, 2 * E, 2 * E, nullptr));
+      }
       QKV = buf.qkv;
     } else {
       FF_RETURN_IF(ff_layernorm(xin, E, w.norm1_w, w.norm1_b, m->ln_eps, buf.y, E, buf.yq, E, qpos, E, Bc, T,
                                 R, E, st));
-      FF_RETURN_IF(gemm_or_x3(prm, w.in_proj_planes, buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E,
-                              w.self_attn.in_proj_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, st));
+      const long x3_need = (long)prm->x3_min_rows;   // (the bf16 planes cover the whole [3E, E] weight: no row ranges)
+      const bool x3_here = w.in_proj_planes && prm->x3_min_rows > 0 && R >= x3_need;
+      if (last && t > 1 && !x3_here && (E % 64) == 0) {
+        // pruned last layer: k (from LN(x)+qpos) | v (from LN(x)) for every row, q for the newest position only
+        FF_RETURN_IF(gemm(buf.yq, E, buf.y, E, w.self_attn.in_proj_w + (size_t)E * E, E, w.self_attn.in_proj_b + E, nullptr,
+                          0, buf.qkv + E, 3 * E, R, 2 * E, E, 0, st));
+        FF_RETURN_IF(gemm(buf.yq + newoff * E, E, nullptr, 0, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
+                          buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E, 0, st));
+      } else {
+        FF_RETURN_IF(gemm_or_x3(prm, w.in_proj_planes, buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E,
+                                w.self_attn.in_proj_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, st));
+      }
       QKV = buf.qkv;
     }
     // rows that continue through the rest of this layer
