@@ -64,6 +64,9 @@ struct FFProfScope {
   }
 };
 
+// partial-tile workspace of the 3 x bf16 kernel for (current device, stream): allocate now (ff_gemm_x3.hip)
+extern "C" int ff_x3_prepare_stream(hipStream_t st);
+
 // ---- device helpers --------------------------------------------------------------------------
 __device__ __forceinline__ float ff_wave_sum(float v) {
 #pragma unroll

@@ -1300,7 +1300,8 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
 
 extern "C" int ff_gemm_prepare_stream(ff_stream_t stream) {
   StreamK sk;
-  return sk_acquire((hipStream_t)stream, &sk);
+  FF_RETURN_IF(sk_acquire((hipStream_t)stream, &sk));
+  return ff_x3_prepare_stream((hipStream_t)stream);
 }
 
 extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths, int small_max_rows) {

@@ -52,14 +52,6 @@ struct X3Args {
   int n_split, act;
   int tiles_m, tiles_n;
   long long plane_stride;  // elements between two planes of Wp
-  // A given pre-split (gemm_x3p_kernel): [3][K/16][a_rows][16] bf16 planes, and optional planes output
-  const unsigned short* Ap;
-  const unsigned short* Ap2;
-  long long a_plane_stride;
-  int a_rows;
-  unsigned short* Cp;      // optional: C also written as planes [3][N/16][c_rows][16] (input of the next product)
-  long long c_plane_stride;
-  int c_rows;
   float* ws;               // [grid][64 accumulator registers][256 threads]
   unsigned int* flags;     // [grid]: 1 = slot holds a partial tile
   int upt;                 // units (32 k) per tile
@@ -104,7 +96,7 @@ __global__ void split_weight_kernel(const float* __restrict__ W, int ldw, int N,
 //
 // End of a segment of the flat (tile, slice) sequence: hand the partial tile over (kind 1), or finish the
 // tile -- after adding the partials of the lower-numbered blocks (kind 2) -- with bias / activation /
-// residual and the store(s).  Shared by both kernels.
+// residual and the store.
 __device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2][2], int cp_kind, int lb, int k0,
                                                int e_m0, int e_n0) {
   constexpr int BM = 128, BN = 128;
@@ -184,17 +176,7 @@ __device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2]
           if (g.act == 1) v = fmaxf(v, 0.f);
           v += rl[e];
           if (row < g.M && colok) {
-            if (g.C) g.C[(size_t)row * g.ldc + col] = v;
-            if (g.Cp) {  // exact three-term split of the result for the next product
-              const unsigned u1 = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
-              const float r1 = v - __builtin_bit_cast(float, u1);
-              const unsigned u2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-              const float r2 = r1 - __builtin_bit_cast(float, u2);
-              unsigned short* cp = g.Cp + ((size_t)(col >> 4) * g.c_rows + row) * 16 + (col & 15);
-              cp[0] = (unsigned short)(u1 >> 16);
-              cp[g.c_plane_stride] = (unsigned short)(u2 >> 16);
-              cp[2 * g.c_plane_stride] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
-            }
+            g.C[(size_t)row * g.ldc + col] = v;
           }
           acc[mi][ni][e] = 0.f;
         }
@@ -395,205 +377,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
   }
 }
 
-// ---- both operands pre-split: every byte reaches LDS by DMA ------------------------------------------------
-// When the producer of A already wrote it as three bf16 planes (LayerNorm, attention and the previous
-// projection do, on the large-M steps), nothing has to pass through registers: each wave issues six
-// global_load_lds_dwordx4 per slice (one instruction = 32 rows x 32 B of one plane = 1 KB, lane-linear in
-// LDS; the chunk swizzle is applied to the GLOBAL address a lane reads).  Ring of three slots, data two
-// slices ahead: slice s+2 is issued in iteration s into the slot whose last readers finished before the
-// previous barrier, and "s_waitcnt vmcnt(6); s_barrier" at the end of iteration s retires slice s+1 for
-// every wave while the six pieces of slice s+2 stay in flight.  Raw s_barrier: __syncthreads() would
-// drain the DMA queue (its release fence waits for vmcnt(0)).
-__global__ __launch_bounds__(256, 2) void gemm_x3p_kernel(X3Args g) {
-  constexpr int BM = 128, BN = 128, BK = 16;
-  constexpr int PLANE_B = (BM + BN) * 32, BUF_B = 3 * PLANE_B;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int nsl = g.K / BK;
-  const int tiles_mn = g.tiles_m * g.tiles_n;
-
-  const int G = gridDim.x;
-  const int lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int upt = g.upt;
-  const int u0 = lb * g.base + (lb < g.rem ? lb : g.rem);
-  const int u1 = u0 + g.base + (lb < g.rem ? 1 : 0);
-  if (u0 >= u1) return;
-  const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
-  const int ja = u0 - k0 * upt;
-  const int jb = u1 - k1 * upt;
-  const bool has_c = jb < upt;
-  const bool has_o = ja > 0 && !(k0 == k1 && has_c);
-  const int kf0 = k0 + (ja > 0 ? 1 : 0);
-  const int nfull = (k1 + (has_c ? 0 : 1) - kf0) > 0 ? (k1 + (has_c ? 0 : 1) - kf0) : 0;
-  const int nseg = (has_c ? 1 : 0) + nfull + (has_o ? 1 : 0);
-  auto segment = [&](int p, int& tile, int& j0, int& n, int& kind) {
-    if (has_c && p == 0) {
-      tile = k1; j0 = 2 * (k1 == k0 ? ja : 0); n = 2 * jb - j0; kind = 1;
-    } else {
-      const int q = p - (has_c ? 1 : 0);
-      if (q < nfull) { tile = kf0 + q; j0 = 0; n = nsl; kind = 0; }
-      else { tile = k0; j0 = 2 * ja; n = nsl - j0; kind = 2; }
-    }
-  };
-
-  // DMA pieces of this wave: i = 0..2 are A pieces a = 3 * wave + i (plane a / 4, row block a % 4), i = 3..5
-  // the W pieces of the same numbers.  Running per-lane pointers, bumped by one K block per slice.
-  const int prow = lane >> 1;                       // row inside the piece
-  const unsigned short* dsrc[6];
-  int ddst[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int a = 3 * wave + (i % 3);
-    ddst[i] = (a >> 2) * PLANE_B + ((i < 3 ? 0 : 4) + (a & 3)) * 1024;
-  }
-  const long long a_step = (long long)g.a_rows * 16, w_step = (long long)g.N * 16;  // elements per K block
-  auto set_load_tile = [&](int id, int j0) {
-    const int rem2 = id % tiles_mn;
-    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
-    const unsigned short* Asrc = (g.Ap2 != nullptr && n0 >= g.n_split) ? g.Ap2 : g.Ap;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int a = 3 * wave + (i % 3), plane = a >> 2;
-      const int row = (a & 3) * 32 + prow;                         // row inside the A or W half of the slot
-      const int chunk = (lane & 1) ^ ((row >> 4) & 1);             // logical 16-byte chunk this lane fetches
-      if (i < 3) {
-        int r = m0 + row;
-        r = r < g.M ? r : g.M - 1;
-        dsrc[i] = Asrc + plane * g.a_plane_stride + j0 * a_step + (size_t)r * 16 + chunk * 8;
-      } else {
-        int n = n0 + row;
-        n = n < g.N ? n : g.N - 1;
-        dsrc[i] = g.Wp + plane * g.plane_stride + j0 * w_step + (size_t)n * 16 + chunk * 8;
-      }
-    }
-  };
-  int ld_p = 0, ld_j, ld_end;
-  {
-    int tile, j0, n, kind;
-    segment(0, tile, j0, n, kind);
-    set_load_tile(tile, j0);
-    ld_j = j0; ld_end = j0 + n;
-  }
-  auto issue_piece = [&](int slot, int i) {
-    __builtin_amdgcn_global_load_lds(dsrc[i], (__attribute__((address_space(3))) void*)(lds + slot * BUF_B + ddst[i]),
-                                     16, 0, 0);
-  };
-  auto issue = [&](int slot) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) issue_piece(slot, i);
-  };
-  auto advance = [&]() {  // block-uniform; past the last segment the cursor stays on its last slice
-    if (++ld_j == ld_end) {
-      if (ld_p + 1 < nseg) {
-        int tile, j0, n, kind;
-        segment(++ld_p, tile, j0, n, kind);
-        set_load_tile(tile, j0);
-        ld_j = j0; ld_end = j0 + n;
-      } else {
-        ld_j = ld_end - 1;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) dsrc[i] += (i < 3 ? a_step : w_step);
-    }
-  };
-  // Fragment reads are inline asm: the compiler orders an LDS read it can see after ALL outstanding
-  // global_load_lds (s_waitcnt vmcnt(0)), which would collapse the two-slice lead to one.  The DMA ->
-  // read order is established by the counted vmcnt + barrier at the end of the previous iteration.
-  const int fchunk = (half ^ ((l32 >> 4) & 1)) * 16;
-  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)lds);
-  const unsigned fra = lds0 + (wm0 + l32) * 32 + fchunk;
-  const unsigned frb = lds0 + (BM + wn0 + l32) * 32 + fchunk;
-  u32x4 fa[3][2], fb[3][2];
-#define FF_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-  // issue order = consumption order of the products: (a2,b0) | (a1,b1) | (a0,b2)
-  auto read_frags = [&](int slot) {
-    const unsigned ra = fra + slot * BUF_B, rb = frb + slot * BUF_B;
-    FF_DSR(fa[2][0], ra, 16384); FF_DSR(fa[2][1], ra, 17408);
-    FF_DSR(fb[0][0], rb, 0);     FF_DSR(fb[0][1], rb, 1024);
-    FF_DSR(fa[1][0], ra, 8192);  FF_DSR(fa[1][1], ra, 9216);
-    FF_DSR(fb[1][0], rb, 8192);  FF_DSR(fb[1][1], rb, 9216);
-    FF_DSR(fa[0][0], ra, 0);     FF_DSR(fa[0][1], ra, 1024);
-    FF_DSR(fb[2][0], rb, 16384); FF_DSR(fb[2][1], rb, 17408);
-  };
-  // Counted LDS waits (LDS returns in order and the loop holds no scalar loads): each one is tied to the
-  // fragments it releases so that no MFMA using them can be scheduled above it.
-#define FF_LGKM(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-  auto product = [&](int pa, int pb) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][mi]),
-                                                              __builtin_bit_cast(bf16x8, fb[pb][ni]), acc[mi][ni], 0, 0, 0);
-  };
-  // One slice: small terms first; the first products start while later fragments are still in flight, and
-  // each DMA piece of slice +2 (60-100 issue cycles) goes out behind a group of four MFMAs instead of in
-  // front of the slice.
-  auto mfma_frags = [&](int dma_slot) {
-    FF_LGKM(8, fa[2][0], fa[2][1], fb[0][0], fb[0][1]);
-    product(2, 0);
-    issue_piece(dma_slot, 0);
-    FF_LGKM(4, fa[1][0], fa[1][1], fb[1][0], fb[1][1]);
-    product(1, 1);
-    issue_piece(dma_slot, 1);
-    FF_LGKM(0, fa[0][0], fa[0][1], fb[2][0], fb[2][1]);
-    product(0, 2);
-    issue_piece(dma_slot, 2);
-    product(1, 0);
-    issue_piece(dma_slot, 3);
-    product(0, 1);
-    issue_piece(dma_slot, 4);
-    product(0, 0);
-    issue_piece(dma_slot, 5);
-  };
-
-  int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
-  int e_m0 = 0, e_n0 = 0;
-  auto begin_segment = [&](int p) {
-    int id, j0;
-    segment(p, id, j0, cp_n, cp_kind);
-    cp_cnt = 0;
-    const int rem2 = id % tiles_mn;
-    e_m0 = (rem2 / g.tiles_n) * BM;
-    e_n0 = (rem2 % g.tiles_n) * BN;
-  };
-
-  // prologue: slices 0 and 1 in flight, slice 0 landed
-  issue(0); advance();
-  issue(1); advance();
-  begin_segment(0);
-  __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
-  __builtin_amdgcn_s_barrier();
-
-  int b0 = 0, b1 = 1, b2 = 2;
-  const int total_slices = 2 * (u1 - u0);
-  for (int s = 0; s < total_slices; ++s) {
-    read_frags(b0);
-    mfma_frags(b2);
-    advance();
-    if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
-      x3_end_segment(g, acc, cp_kind, lb, k0, e_m0, e_n0);
-      if (++cp_p < nseg) begin_segment(cp_p);
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // known-empty counter on the rare path (see gemm_x3_kernel)
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): slice s+1 has landed, slice s+2 may still be in flight
-    __builtin_amdgcn_s_barrier();
-    { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // do not leave DMA writes to a dead block's LDS in flight
-}
-
 // Partial-tile workspace: one per (device, stream), as in ff_gemm.hip (64 KB slots here).
 constexpr int X3_MAX_GRID = 512;
 struct X3Workspace {
@@ -639,40 +422,31 @@ extern "C" int ff_split_weight_bf16x3(const float* W, int ldw, int N, int K, voi
   return FF_OK;
 }
 
-extern "C" int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream) {
-  FF_CHECK_ARG(desc != nullptr, "ff_gemm_x3: null descriptor");
-  const ff_gemm_x3_desc d = *desc;
-  const int M = d.M, N = d.N, K = d.K;
+extern "C" int ff_x3_prepare_stream(hipStream_t st) {
+  X3Args g;
+  return x3_acquire(st, &g);
+}
+
+extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
+                          const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
+                          int K, int act, ff_stream_t stream) {
   if (M == 0 || N == 0) return FF_OK;
   FF_CHECK_ARG(M > 0 && N > 0 && K >= 64 && (K % 32) == 0, "ff_gemm_x3: bad M=%d N=%d K=%d (K %% 32, K >= 64)", M, N, K);
-  const bool apl = d.A_planes != nullptr;
-  FF_CHECK_ARG((d.A || apl) && d.w_planes && (d.C || d.C_planes), "ff_gemm_x3: null operand");
-  FF_CHECK_ARG(ff_aligned16(d.w_planes) && ((size_t)N * K % 8) == 0, "ff_gemm_x3: weight planes must be 16-byte aligned");
-  if (apl) {
-    FF_CHECK_ARG(d.a_rows >= M && d.a_plane_stride >= (long long)(K / 16) * d.a_rows * 16 && ff_aligned16(d.A_planes) &&
-                     (d.a_plane_stride & 7) == 0 && (!d.A2_planes || ff_aligned16(d.A2_planes)),
-                 "ff_gemm_x3: bad activation planes (a_rows=%d)", d.a_rows);
-  } else {
-    FF_CHECK_ARG((d.lda & 3) == 0 && d.lda >= K && ff_aligned16(d.A) && (!d.A2 || ff_aligned16(d.A2)),
-                 "ff_gemm_x3: A/A2 must be 16-byte aligned with lda %% 4 == 0 (lda=%d)", d.lda);
-  }
-  FF_CHECK_ARG(!d.C || d.ldc >= N, "ff_gemm_x3: bad ldc");
-  FF_CHECK_ARG(!d.C_planes || (d.c_rows >= M && (N % 16) == 0 && d.c_plane_stride >= (long long)(N / 16) * d.c_rows * 16),
-               "ff_gemm_x3: bad output planes (c_rows=%d, N %% 16)", d.c_rows);
-  FF_CHECK_ARG(!d.residual || d.ldr >= N, "ff_gemm_x3: bad ldr");
-  FF_CHECK_ARG(d.act == 0 || d.act == 1, "ff_gemm_x3: act must be 0 or 1");
-  const bool two = apl ? d.A2_planes != nullptr : d.A2 != nullptr;
-  if (two) FF_CHECK_ARG(d.n_split > 0 && d.n_split < N && (d.n_split % 128) == 0, "ff_gemm_x3: n_split must be a multiple of 128 inside (0,N)");
+  FF_CHECK_ARG(A && w_planes && C, "ff_gemm_x3: null operand");
+  FF_CHECK_ARG(ff_aligned16(w_planes) && ((size_t)N * K % 8) == 0, "ff_gemm_x3: weight planes must be 16-byte aligned");
+  FF_CHECK_ARG((lda & 3) == 0 && lda >= K && ff_aligned16(A) && (!A2 || ff_aligned16(A2)),
+               "ff_gemm_x3: A/A2 must be 16-byte aligned with lda %% 4 == 0 (lda=%d)", lda);
+  FF_CHECK_ARG(ldc >= N, "ff_gemm_x3: bad ldc");
+  FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_x3: bad ldr");
+  FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_x3: act must be 0 or 1");
+  if (A2) FF_CHECK_ARG(n_split > 0 && n_split < N && (n_split % 128) == 0, "ff_gemm_x3: n_split must be a multiple of 128 inside (0,N)");
   hipStream_t st = (hipStream_t)stream;
   X3Args g;
   memset(&g, 0, sizeof(g));
-  g.A = d.A; g.A2 = d.A2; g.lda = d.lda;
-  g.Ap = static_cast<const unsigned short*>(d.A_planes); g.Ap2 = static_cast<const unsigned short*>(d.A2_planes);
-  g.a_plane_stride = d.a_plane_stride; g.a_rows = d.a_rows;
-  g.Wp = static_cast<const unsigned short*>(d.w_planes); g.bias = d.bias; g.res = d.residual; g.ldr = d.ldr;
-  g.C = d.C; g.ldc = d.ldc;
-  g.Cp = static_cast<unsigned short*>(d.C_planes); g.c_rows = d.c_rows; g.c_plane_stride = d.c_plane_stride;
-  g.M = M; g.N = N; g.K = K; g.n_split = two ? d.n_split : N; g.act = d.act;
+  g.A = A; g.A2 = A2; g.lda = lda;
+  g.Wp = static_cast<const unsigned short*>(w_planes); g.bias = bias; g.res = residual; g.ldr = ldr;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.n_split = A2 ? n_split : N; g.act = act;
   g.tiles_m = ff_cdiv(M, 128); g.tiles_n = ff_cdiv(N, 128);
   g.plane_stride = (long long)N * K;
   g.upt = K / 32;
@@ -694,28 +468,17 @@ extern "C" int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream) {
   g.base = (int)(units / grid);
   g.rem = (int)(units % grid);
   FF_RETURN_IF(x3_acquire(st, &g));
-  static bool attr_set = false;
+  static bool attr_set[16] = {};   // hipFuncSetAttribute is per device
   constexpr int bytes = 3 * 3 * 256 * 32;
-  if (!attr_set) {
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
     FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3p_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_set = true;
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K, st);
-  if (apl) hipLaunchKernelGGL(gemm_x3p_kernel, dim3((int)grid), dim3(256), bytes, st, g);
-  else hipLaunchKernelGGL(gemm_x3_kernel, dim3((int)grid), dim3(256), bytes, st, g);
+  hipLaunchKernelGGL(gemm_x3_kernel, dim3((int)grid), dim3(256), bytes, st, g);
   FF_CHECK_LAUNCH();
   return FF_OK;
-}
-
-extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
-                          const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
-                          int K, int act, ff_stream_t stream) {
-  ff_gemm_x3_desc d;
-  memset(&d, 0, sizeof(d));
-  d.A = A; d.lda = lda; d.A2 = A2; d.n_split = n_split; d.w_planes = w_planes; d.bias = bias;
-  d.residual = residual; d.ldr = ldr; d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K; d.act = act;
-  return ff_gemm_x3_ex(&d, stream);
 }

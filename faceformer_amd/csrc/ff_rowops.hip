@@ -178,115 +178,6 @@ extern "C" int ff_layernorm(const float* x, int ldx, const float* gamma, const f
   return FF_OK;
 }
 
-// ---- LayerNorm writing its result pre-split for the bf16 matrix cores ----------------------------------------
-// Same statistics and affine as layernorm_kernel; the result (and result + pos) is stored as the exact
-// three-term bf16 split in the K-blocked plane layout of ff_gemm_x3 ([3][E/16][plane_rows][16]): the four
-// values a lane holds per float4 are 8 contiguous bytes of one 16-wide block in each plane.
-__device__ __forceinline__ void ff_store_split4(f32x4 o, unsigned short* dst, long long pstride) {
-  unsigned h1[4], h2[4], h3[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float f = o[j];  // (bit_cast of the vector element itself reads element 0)
-    const unsigned u1 = __builtin_bit_cast(unsigned, f) & 0xffff0000u;
-    const float r1 = f - __builtin_bit_cast(float, u1);
-    const unsigned u2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, u2);  // at most 8 significant bits left: exact in bf16
-    h1[j] = u1; h2[j] = u2; h3[j] = __builtin_bit_cast(unsigned, r2);
-  }
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  *reinterpret_cast<u32x2*>(dst) = u32x2{(h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3]};
-  *reinterpret_cast<u32x2*>(dst + pstride) = u32x2{(h2[0] >> 16) | h2[1], (h2[2] >> 16) | h2[3]};
-  *reinterpret_cast<u32x2*>(dst + 2 * pstride) =
-      u32x2{(h3[0] >> 16) | (h3[1] & 0xffff0000u), (h3[2] >> 16) | (h3[3] & 0xffff0000u)};
-}
-
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_planes_kernel(
-    const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    unsigned short* __restrict__ yp, unsigned short* __restrict__ yposp, int plane_rows, long long pstride,
-    const float* __restrict__ pos, int ldpos, int pos_div, int pos_mod, int rows, int E) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int nvec = E >> 2;
-  const float* xr = x + (size_t)row * ldx;
-  f32x4 v[NV];
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    int vi = lane + c * 64;
-    if (vi < nvec) {
-      v[c] = *reinterpret_cast<const f32x4*>(xr + vi * 4);
-      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-    } else {
-      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  const float inv_e = 1.0f / (float)E;
-  const float mean = ff_wave_sum(s) * inv_e;
-  float ss = 0.f;
-#pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    int vi = lane + c * 64;
-    if (vi < nvec) {
-      f32x4 d = v[c] - mean;
-      ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-    }
-  }
-  const float var = ff_wave_sum(ss) * inv_e;
-  const float rstd = 1.0f / sqrtf(var + eps);
-  const float* pr = nullptr;
-  if (yposp != nullptr) pr = pos + (size_t)((row / pos_div) % pos_mod) * ldpos;
-#pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    int vi = lane + c * 64;
-    if (vi < nvec) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + vi * 4);
-      f32x4 b = *reinterpret_cast<const f32x4*>(beta + vi * 4);
-      f32x4 o = (v[c] - mean) * rstd * g + b;
-      const size_t at = ((size_t)(vi >> 2) * plane_rows + row) * 16 + (vi & 3) * 4;
-      if (yp != nullptr) ff_store_split4(o, yp + at, pstride);
-      if (yposp != nullptr) {
-        f32x4 p = *reinterpret_cast<const f32x4*>(pr + vi * 4);
-        ff_store_split4(o + p, yposp + at, pstride);
-      }
-    }
-  }
-}
-
-extern "C" int ff_layernorm_planes(const float* x, int ldx, const float* gamma, const float* beta, float eps,
-                                   void* y_planes, void* ypos_planes, int plane_rows, long long plane_stride,
-                                   const float* pos, int ldpos, int pos_div, int pos_mod, int rows, int E,
-                                   ff_stream_t stream) {
-  if (rows == 0) return FF_OK;
-  FF_CHECK_ARG(rows > 0 && E > 0 && (E & 15) == 0 && E <= 2048, "ff_layernorm_planes: bad rows=%d E=%d (E %% 16)", rows, E);
-  FF_CHECK_ARG(x && gamma && beta && (y_planes || ypos_planes), "ff_layernorm_planes: null pointer");
-  FF_CHECK_ARG((ldx & 3) == 0 && ff_aligned16(x) && ff_aligned16(gamma) && ff_aligned16(beta),
-               "ff_layernorm_planes: x/gamma/beta must be 16-byte aligned, ld %% 4 == 0");
-  FF_CHECK_ARG(plane_rows >= rows && plane_stride >= (long long)(E / 16) * plane_rows * 16 && (plane_stride & 3) == 0 &&
-                   (!y_planes || ff_aligned16(y_planes)) && (!ypos_planes || ff_aligned16(ypos_planes)),
-               "ff_layernorm_planes: bad plane geometry");
-  if (ypos_planes)
-    FF_CHECK_ARG(pos && pos_div > 0 && pos_mod > 0 && (ldpos & 3) == 0 && ff_aligned16(pos),
-                 "ff_layernorm_planes: bad pos arguments");
-  hipStream_t st = (hipStream_t)stream;
-  FFProfScope prof(FF_CAT_LN, (double)rows * E * (4.0 + 6.0 * ((y_planes != nullptr) + (ypos_planes != nullptr))), st);
-  dim3 block(256), grid(ff_cdiv(rows, 4));
-  const int nv = ff_cdiv(E / 4, 64);
-  unsigned short* yp = static_cast<unsigned short*>(y_planes);
-  unsigned short* yqp = static_cast<unsigned short*>(ypos_planes);
-#define FF_LNP_LAUNCH(NV)                                                                                    \
-  hipLaunchKernelGGL(layernorm_planes_kernel<NV>, grid, block, 0, st, x, ldx, gamma, beta, eps, yp, yqp, plane_rows, \
-                     plane_stride, pos, ldpos, pos_div, pos_mod, rows, E)
-  if (nv <= 1) FF_LNP_LAUNCH(1);
-  else if (nv <= 2) FF_LNP_LAUNCH(2);
-  else if (nv <= 4) FF_LNP_LAUNCH(4);
-  else FF_LNP_LAUNCH(8);
-#undef FF_LNP_LAUNCH
-  FF_CHECK_LAUNCH();
-  return FF_OK;
-}
-
 // ---- out = x + pos[(row / div) % mod] ----------------------------------------------------------
 __global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ x, int ldx,
                                                       const float* __restrict__ pos, int ldpos,

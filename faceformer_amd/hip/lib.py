@@ -38,19 +38,6 @@ class AttnDesc(C.Structure):
     ]
 
 
-class GemmX3Desc(C.Structure):
-    _fields_ = [
-        ("A", fptr), ("A2", fptr), ("lda", C.c_int),
-        ("A_planes", fptr), ("A2_planes", fptr), ("a_rows", C.c_int), ("a_plane_stride", C.c_longlong),
-        ("n_split", C.c_int),
-        ("w_planes", fptr),
-        ("bias", fptr), ("residual", fptr), ("ldr", C.c_int),
-        ("C", fptr), ("ldc", C.c_int),
-        ("C_planes", fptr), ("c_rows", C.c_int), ("c_plane_stride", C.c_longlong),
-        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("act", C.c_int),
-    ]
-
-
 class GemmLnDesc(C.Structure):
     _fields_ = [
         ("A", fptr), ("lda", C.c_int), ("W", fptr), ("ldw", C.c_int), ("bias", fptr),
@@ -119,8 +106,6 @@ SIGNATURES = {
     "ff_profile_bytes": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
                                fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
-    "ff_layernorm_planes": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, fptr, C.c_int, C.c_longlong,
-                                      fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,
                              C.c_int, fptr]),
     "ff_gemm_f32": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,
@@ -135,7 +120,6 @@ SIGNATURES = {
     "ff_split_weight_bf16x3": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, fptr]),
     "ff_gemm_x3": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_int,
                              C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
-    "ff_gemm_x3_ex": (C.c_int, [C.POINTER(GemmX3Desc), fptr]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),
     "ff_set_gemm_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -281,76 +281,26 @@ def _check_planes(p, what):
 
 
 @_on_tensor_device
-def linear_x3(x, planes, bias=None, act=0, residual=None, x2=None, n_split=0, out=None, x_planes=None,
-              x2_planes=None, out_planes=None, want_fp32=True):
-    """linear() on the bf16 matrix cores with fp32 accuracy; `planes` comes from split_weight().
-    x_planes / x2_planes: the activations pre-split (split_weight layout, [3, K/16, M, 16]) instead of
-    x / x2; out_planes: a [3, N/16, M, 16] bf16 tensor that receives the exact split of the result."""
+def linear_x3(x, planes, bias=None, act=0, residual=None, x2=None, n_split=0, out=None):
+    """linear() on the bf16 matrix cores with fp32 accuracy; `planes` comes from split_weight()."""
     _check_planes(planes, "planes")
-    d = _L.GemmX3Desc()
     N, K = planes.size(2), planes.size(1) * 16
-    if x_planes is not None:
-        _check_planes(x_planes, "x_planes")
-        if x_planes.size(1) * 16 != K:
-            raise ValueError("linear_x3: x_planes has K=%d, the weight K=%d" % (x_planes.size(1) * 16, K))
-        M = x_planes.size(2)
-        d.A_planes, d.a_rows, d.a_plane_stride = x_planes.data_ptr(), M, x_planes.stride(0)
-        if x2_planes is not None:
-            _check_planes(x2_planes, "x2_planes")
-            if x2_planes.shape != x_planes.shape:
-                raise ValueError("linear_x3: x2_planes must match x_planes")
-            d.A2_planes = x2_planes.data_ptr()
-        dev = x_planes.device
-    else:
-        x, lda = _rows(x, "x")
-        M = x.size(0)
-        if x.size(1) != K:
-            raise ValueError("linear_x3: x is [%d,%d] but the weight is [%d,%d]" % (M, x.size(1), N, K))
-        d.A, d.lda = _p(x), lda
-        if x2 is not None:
-            x2, lda2 = _rows(x2, "x2")
-            if x2.shape != x.shape or lda2 != lda:
-                raise ValueError("linear_x3: x2 must match x")
-            d.A2 = _p(x2)
-        dev = x.device
-    d.n_split, d.w_planes = n_split, planes.data_ptr()
-    if out is None and want_fp32:
-        out = torch.empty((M, N), device=dev, dtype=torch.float32)
-    if out is not None:
-        out, ldc = _rows(out, "out")
-        d.C, d.ldc = _p(out), ldc
-    if out_planes is not None:
-        _check_planes(out_planes, "out_planes")
-        if tuple(out_planes.shape) != (3, N // 16, M, 16):
-            raise ValueError("linear_x3: out_planes must be [3, %d, %d, 16]" % (N // 16, M))
-        d.C_planes, d.c_rows, d.c_plane_stride = out_planes.data_ptr(), M, out_planes.stride(0)
+    x, lda = _rows(x, "x")
+    M = x.size(0)
+    if x.size(1) != K:
+        raise ValueError("linear_x3: x is [%d,%d] but the weight is [%d,%d]" % (M, x.size(1), N, K))
+    if x2 is not None:
+        x2, lda2 = _rows(x2, "x2")
+        if x2.shape != x.shape or lda2 != lda:
+            raise ValueError("linear_x3: x2 must match x")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    out, ldc = _rows(out, "out")
+    ldr = 0
     if residual is not None:
         residual, ldr = _rows(residual, "residual")
-        d.residual, d.ldr = _p(residual), ldr
     if bias is not None:
         _dev(bias, "bias")
-        d.bias = _p(bias)
-    d.M, d.N, d.K, d.act = M, N, K, act
-    _L.check(_L.load().ff_gemm_x3_ex(C.byref(d), _stream()), "ff_gemm_x3")
+    _L.check(_L.load().ff_gemm_x3(_p(x), lda, _p(x2), n_split, planes.data_ptr(), _p(bias), _p(residual), ldr,
+                                  _p(out), ldc, M, N, K, act, _stream()), "ff_gemm_x3")
     return out
-
-
-@_on_tensor_device
-def layernorm_planes(x, gamma, beta, eps=1e-5, pos=None, pos_div=1, pos_mod=1, want_y=True):
-    """LayerNorm whose result is written as bf16 planes for linear_x3: returns (y_planes, ypos_planes),
-    each [3, E/16, rows, 16] bf16 or None."""
-    x, ldx = _rows(x, "x")
-    rows, E = x.shape
-    _dev(gamma, "gamma"), _dev(beta, "beta")
-    yp = torch.empty((3, E // 16, rows, 16), device=x.device, dtype=torch.bfloat16) if want_y else None
-    yqp, ldpos = None, 0
-    if pos is not None:
-        pos, ldpos = _rows(pos, "pos")
-        yqp = torch.empty((3, E // 16, rows, 16), device=x.device, dtype=torch.bfloat16)
-    stride = (E // 16) * rows * 16
-    _L.check(_L.load().ff_layernorm_planes(_p(x), ldx, _p(gamma), _p(beta), eps,
-                                           yp.data_ptr() if yp is not None else None,
-                                           yqp.data_ptr() if yqp is not None else None, rows, stride,
-                                           _p(pos), ldpos, pos_div, pos_mod, rows, E, _stream()),
-             "ff_layernorm_planes")
-    return yp, yqp

@@ -68,14 +68,6 @@ int ff_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
                  const float* pos, int ldpos, int pos_div, int pos_mod,
                  int rows, int E, ff_stream_t stream);
 
-/* Same LayerNorm, result written pre-split for ff_gemm_x3_ex: y_planes / ypos_planes receive the exact
- * three-term bf16 split of LN(x) / LN(x)+pos in the K-blocked plane layout [3][E/16][plane_rows][16]
- * (planes plane_stride elements apart).  E % 16 == 0.  Experimental, with ff_gemm_x3. */
-int ff_layernorm_planes(const float* x, int ldx, const float* gamma, const float* beta, float eps,
-                        void* y_planes, void* ypos_planes, int plane_rows, long long plane_stride,
-                        const float* pos, int ldpos, int pos_div, int pos_mod,
-                        int rows, int E, ff_stream_t stream);
-
 /* out[r,:] = x[r,:] + pos[((r / pos_div) % pos_mod), :]   (`memory + pos`, transformer.py:249) */
 int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div, int pos_mod,
                float* out, int ldout, int rows, int E, ff_stream_t stream);
@@ -157,29 +149,13 @@ int ff_fold_layernorm_linear(const float* W, int ldw, int N, int K, const float*
  * W is given pre-split: ff_split_weight_bf16x3 writes its three planes once per weight tensor
  * (ff_split_weight_bytes(N, K) bytes; layout [3][K/16][N][16] bf16, i.e. a 16-wide K slice of 32 rows is
  * one contiguous 1 KB block); activations are split inside the kernel.  K % 32 == 0, K >= 64; n_split % 128 == 0.  Keeps an internal 32 MB partial-tile workspace per
- * (device, stream).  Same replaced call sites as ff_gemm_f32. */
+ * (device, stream) (ff_gemm_prepare_stream allocates it ahead of time).  Same replaced call sites as ff_gemm_f32;
+ * ff_decode uses it for the decoder projections of launches with at least ff_decode_params.x3_min_rows rows. */
 size_t ff_split_weight_bytes(int N, int K);
 int ff_split_weight_bf16x3(const float* W, int ldw, int N, int K, void* planes, ff_stream_t stream);
 int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
                const float* bias, const float* residual, int ldr, float* C, int ldc,
                int M, int N, int K, int act, ff_stream_t stream);
-
-/* Full form.  The activations may arrive pre-split as well (A_planes: [3][K/16][a_rows][16] bf16, planes
- * a_plane_stride elements apart -- what ff_layernorm / ff_attention / this function write when asked to):
- * then nothing passes through registers, all operand bytes reach LDS by global_load_lds DMA.  The result
- * can be written as fp32 (C), as three planes for the next product (C_planes), or both. */
-typedef struct ff_gemm_x3_desc {
-  const float* A; const float* A2; int lda;           /* fp32 activations, split inside the kernel ... */
-  const void* A_planes; const void* A2_planes;        /* ... or pre-split ones (take precedence)       */
-  int a_rows; long long a_plane_stride;
-  int n_split;                                        /* columns >= n_split use A2 / A2_planes          */
-  const void* w_planes;                               /* ff_split_weight_bf16x3 output                  */
-  const float* bias; const float* residual; int ldr;  /* optional                                       */
-  float* C; int ldc;                                  /* optional fp32 output                           */
-  void* C_planes; int c_rows; long long c_plane_stride; /* optional pre-split output, [3][N/16][c_rows][16] */
-  int M, N, K, act;
-} ff_gemm_x3_desc;
-int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream);
 
 /* Launch-shape tuning of the stream-K kernel (process-wide; tests and tools/): a block is never handed
  * fewer than `min_units` K units (of 64); launches with at least `two_per_cu_units` units use 512
@@ -188,7 +164,7 @@ int ff_gemm_x3_ex(const ff_gemm_x3_desc* desc, ff_stream_t stream);
  * batched call together) go to the unstaged split-K kernel (0: never). */
 int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_tenths, int small_max_rows);
 
-/* Allocate the partial-tile exchange buffer of the stream-K kernels for (current device, stream) now
+/* Allocate the partial-tile exchange buffers of the stream-K kernels (f32 and 3 x bf16) for (current device, stream) now
  * instead of at the first launch (hipMalloc + device synchronisation: keep it out of timed or captured
  * regions).  ff_decode calls it for the caller's stream and its internal streams before enqueuing. */
 int ff_gemm_prepare_stream(ff_stream_t stream);

@@ -179,8 +179,8 @@ def test_struct_layouts_match_the_header(hip_lib):
 #include "faceformer_hip.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ff_attn_desc), sizeof(ff_mha_weights), sizeof(ff_layer_weights),
-         sizeof(ff_model), sizeof(ff_decode_params), offsetof(ff_model, dec), sizeof(ff_gemm_x3_desc),
-         offsetof(ff_gemm_x3_desc, M));
+         sizeof(ff_model), sizeof(ff_decode_params), offsetof(ff_model, dec), sizeof(ff_gemm_ln_desc),
+         offsetof(ff_gemm_ln_desc, ln_stats_out));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -190,7 +190,7 @@ int main(void) {
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     got = [ctypes.sizeof(lib.AttnDesc), ctypes.sizeof(lib.MhaWeights), ctypes.sizeof(lib.LayerWeights),
            ctypes.sizeof(lib.Model), ctypes.sizeof(lib.DecodeParams), lib.Model.dec.offset,
-           ctypes.sizeof(lib.GemmX3Desc), lib.GemmX3Desc.M.offset]
+           ctypes.sizeof(lib.GemmLnDesc), lib.GemmLnDesc.ln_stats_out.offset]
     assert [int(x) for x in out] == got
 
 
@@ -216,8 +216,13 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device(hip_lib):
     assert hip_lib.ff_attention(ctypes.byref(d), None) == FF_ERR_ARG
     assert hip_lib.ff_attention(None, None) == FF_ERR_ARG
     # the bf16-split product: K must be a multiple of 32 and at least 64
-    x = lib.GemmX3Desc()
-    x.A, x.lda, x.w_planes, x.C, x.ldc, x.M, x.N, x.K = p, 48, p, p, 8, 2, 2, 48
-    assert hip_lib.ff_gemm_x3_ex(ctypes.byref(x), None) == FF_ERR_ARG
+    assert hip_lib.ff_gemm_x3(p, 48, None, 0, p, None, None, 0, p, 8, 2, 2, 48, 0, None) == FF_ERR_ARG
     assert b"K" in hip_lib.ff_last_error()
+    # the LayerNorm-fused form: statistics must describe whole rows, a row table needs statistics
+    g = lib.GemmLnDesc()
+    g.A, g.lda, g.W, g.ldw, g.C, g.ldc, g.M, g.N, g.K = p, 512, p, 512, p, 512, 64, 512, 512
+    g.ln_stats_in, g.ln_nseg = p, 8
+    assert hip_lib.ff_gemm_f32_ln(ctypes.byref(g), None) == FF_ERR_ARG
+    g.ln_stats_in, g.ln_nseg, g.row_table, g.row_div, g.row_cols, g.ld_row_table = None, 0, p, 4, 512, 512
+    assert hip_lib.ff_gemm_f32_ln(ctypes.byref(g), None) == FF_ERR_ARG
     assert hip_lib.ff_set_gemm_tuning(0, 1, 1, 1) == FF_ERR_ARG

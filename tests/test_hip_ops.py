@@ -199,35 +199,6 @@ def test_gemm_x3_matches_fp64_like_fp32(ops, M, N, K):
     assert torch.equal(x, y)  # deterministic
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
-                                   (4100, 1024, 512), (130, 96, 64), (2304, 512, 512), (9216, 1536, 512)])
-def test_gemm_x3_presplit_activations_and_plane_output(ops, M, N, K):
-    """All-DMA kernel: A given as planes; result also written as planes whose sum is the fp32 result."""
-    a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
-    planes, ap = ops.split_weight(w.cuda()), ops.split_weight(a.cuda())
-    ref = torch.relu(a.double() @ w.double().t() + bias.double()) + res.double()
-    x = res.cuda()
-    if N % 16:
-        pytest.skip("plane output needs N % 16 == 0")
-    op = torch.zeros((3, N // 16, M, 16), device="cuda", dtype=torch.bfloat16)
-    ops.linear_x3(None, planes, bias.cuda(), act=1, residual=x, out=x, x_planes=ap, out_planes=op)
-    assert rel_err(x, ref) < 3e-6
-    assert float((ops.planes_to_matrix(op) - x.double()).abs().max()) == 0.0
-    y = res.cuda()
-    ops.linear_x3(a.cuda(), planes, bias.cuda(), act=1, residual=y, out=y)
-    assert float((x - y).abs().max()) <= 2e-6 * float(ref.abs().max())  # same products, different split of A
-
-
-def test_layernorm_planes_equal_the_fp32_layernorm(ops):
-    """The plane-writing LayerNorm must reproduce the fp32 LayerNorm output bit for bit (exact split)."""
-    rows, E = 77, 512
-    x, g, b, pos = rnd(rows, E, seed=1), rnd(E, seed=2), rnd(E, seed=3), rnd(10, E, seed=4)
-    y, yq = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), pos=pos.cuda(), pos_div=7, pos_mod=10)
-    yp, yqp = ops.layernorm_planes(x.cuda(), g.cuda(), b.cuda(), pos=pos.cuda(), pos_div=7, pos_mod=10)
-    assert float((ops.planes_to_matrix(yp) - y.double()).abs().max()) == 0.0
-    assert float((ops.planes_to_matrix(yqp) - yq.double()).abs().max()) == 0.0
-
-
 def test_gemm_x3_split_a(ops):
     M, E = 300, 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
