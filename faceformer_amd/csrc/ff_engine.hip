@@ -439,6 +439,9 @@ struct StreamPool {
 constexpr int FF_MAX_DEVICES = 16;
 StreamPool g_pools[FF_MAX_DEVICES];
 std::mutex g_pool_mu;
+// The pool's side streams, events and pinned counters belong to ONE decode at a time: host threads that
+// decode on the same device take turns (different devices run concurrently).
+std::mutex g_pool_busy[FF_MAX_DEVICES];
 
 int pool_get(int n, StreamPool** out) {
   int dev = 0;
@@ -463,6 +466,12 @@ int pool_get(int n, StreamPool** out) {
   }
   *out = &pool;
   return FF_OK;
+}
+
+std::mutex* pool_busy_mutex() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FF_MAX_DEVICES) return nullptr;
+  return &g_pool_busy[dev];
 }
 
 }  // namespace
@@ -584,6 +593,9 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   sts[0] = main_st;
   StreamPool* pool = nullptr;
   FF_RETURN_IF(ff_gemm_prepare_stream(main_st));
+  std::mutex* busy = pool_busy_mutex();
+  FF_CHECK_ARG(busy, "ff_decode: no current device");
+  std::lock_guard<std::mutex> one_decode_per_device(*busy);
   FF_RETURN_IF(pool_get(ns > 1 ? ns : 0, &pool));   // (also owns the pinned counter buffer / events of the stop check)
   if (ns > 1)
     for (int s = 0; s < ns; ++s) sts[s] = pool->side[s];
