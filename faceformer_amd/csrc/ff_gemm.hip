@@ -55,25 +55,8 @@ struct GemmArgs {
 
 // Row statistics of a LayerNorm input from the per-32-column (mean, M2) partials its producer left behind:
 // Chan's parallel update for equal-sized parts (no E[x^2] - mean^2 cancellation).  -> (mean, 1/sqrt(var + eps)).
-// One lane merges a whole row (small-M kernel): all segment loads are issued before the first use (nseg <= 16).
-__device__ __forceinline__ void ff_merge_ln_stats(const float* __restrict__ st, int nseg, float eps, float& mean,
-                                                  float& rstd) {
-  f32x4 v[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(st + 4 * (2 * q < nseg ? q : 0));
-  float sm = 0.f, m2 = 0.f;
-#pragma unroll
-  for (int q = 0; q < 8; ++q)
-    if (2 * q < nseg) { sm += v[q].x + v[q].z; m2 += v[q].y + v[q].w; }
-  mean = sm / (float)nseg;
-  float dev = 0.f;
-#pragma unroll
-  for (int q = 0; q < 8; ++q)
-    if (2 * q < nseg) { const float d0 = v[q].x - mean, d1 = v[q].z - mean; dev += d0 * d0 + d1 * d1; }
-  const float var = (m2 + 32.f * dev) / (32.f * (float)nseg);
-  rstd = 1.0f / sqrtf(var + eps);
-}
-
+// (The small-M kernel merges a block's 32 rows once, eight lanes per row, and shares them through LDS.)
+//
 // Staging side of the persistent kernels: the 8 lanes that stage one A row (lane & 7 = 16-byte column of the
 // slice) share the work of merging its segment statistics: lane c takes segments c, c + 8, ... (K <= 1024:
 // at most 4), the partial sums meet through DPP moves inside the group of 8 lanes.  The raw loads are issued
@@ -1142,9 +1125,15 @@ int sk_acquire(hipStream_t st, StreamK* out) {
 // global memory (row = lane & 31, four consecutive k per 16-byte load; lane half h takes k = 8j + 4h .. +3 of
 // every 8-wide group, the same for A and W), each wave accumulates a quarter of K for the same 32x32 tile,
 // and the four partial tiles meet in 16 KB of LDS; every wave finishes four of the sixteen accumulator rows.
-template <int KQ, int MODE>  // KQ = K / 4 (per-wave K range), a multiple of 8; MODE as gemm_persist_kernel
-__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64 + (MODE == 2 ? 32 * 33 : 0)];
+// NW waves share the K range of one 32x32 tile (KQ = K / NW each, a multiple of 32).  Four waves when the launch has
+// enough tiles to fill the chip; EIGHT when it has at most one tile per CU anyway (the single-sequence decode, the
+// last-layer / last-row launches): the dependent MFMA chain of a wave -- the longest serial piece of such a
+// launch -- halves (K = 512: 64 -> 32 MFMAs, 1.7 -> 0.85 us).
+template <int KQ, int MODE, int NW>  // MODE as gemm_persist_kernel
+__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int RPW = 16 / NW;  // accumulator registers (tile rows x 2 halves) a wave finishes
+  __shared__ __attribute__((aligned(16))) float red[NW * 16 * 64 + (MODE == 2 ? 32 * 33 : 0) + (MODE == 1 ? 64 : 0)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int m0 = (blockIdx.x / g.tiles_n) * 32, n0 = (blockIdx.x % g.tiles_n) * 32;
   const long long bz = blockIdx.y;
@@ -1154,59 +1143,108 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   col = col < g.N ? col : g.N - 1;
   const float* ap = Asrc + (size_t)row * g.lda + wave * KQ + half * 4;
   const float* wp = g.W + bz * g.batch_stride_w + (size_t)col * g.ldw + wave * KQ + half * 4;
-  float mu = 0.f, rs = 1.f;
-  if (MODE == 1) ff_merge_ln_stats(g.ln_in + (size_t)row * g.ln_nseg * 2, g.ln_nseg, g.ln_eps, mu, rs);
-  constexpr int NG = KQ / 8;  // 8-wide k groups per wave
-  f32x16 acc;
+  // Loads first: the wave's first operand groups, bias and the epilogue's residual / table values are in flight
+  // before anything is waited for; the row statistics (MODE 1) are merged ONCE per block -- wave w takes 32 / NW rows,
+  // eight lanes per row, one 16-byte load each -- and handed round through LDS (every wave loading every row's
+  // segments itself was half of the kernel's load requests).
+#ifndef FF_SMALL_V
+#define FF_SMALL_V 2
+#endif
+  constexpr int V = FF_SMALL_V;            // 1: all operand loads before the first MFMA; 2: groups of 4 k-groups, pipelined
+  constexpr int NG = KQ / 8;               // 8-wide k groups per wave
+  constexpr int GB = (V == 1) ? (NG < 16 ? NG : 16) : (NG < 4 ? NG : 4);   // groups per batch
+  f32x4 a[2][GB], b[2][GB];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  // groups of 8 loads in flight (64 VGPRs) before their MFMAs
-#pragma unroll
-  for (int g0 = 0; g0 < NG; g0 += 4) {
-    f32x4 a[4], b[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      a[j] = *reinterpret_cast<const f32x4*>(ap + (g0 + j) * 8);
-      b[j] = *reinterpret_cast<const f32x4*>(wp + (g0 + j) * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (MODE == 1) a[j] = (a[j] - mu) * rs;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][c], b[j][c], acc, 0, 0, 0);
-    }
+  for (int j = 0; j < GB; ++j) {
+    a[0][j] = *reinterpret_cast<const f32x4*>(ap + j * 8);
+    b[0][j] = *reinterpret_cast<const f32x4*>(wp + j * 8);
   }
-  // partial tiles -> LDS [wave][reg][lane]; wave w then owns registers 4w .. 4w+3 (rows 8w + 0..3 + 4*half)
-#pragma unroll
-  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
-  __syncthreads();
+  float* lnrow = red + NW * 16 * 64 + (MODE == 2 ? 32 * 33 : 0);   // MODE 1: [32][2] (mean, rstd)
+  f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+  const int spart = lane & 7, srow = wave * (32 / NW) + ((lane >> 3) % (32 / NW));
+  if (MODE == 1) {
+    int r = m0 + srow;
+    r = r < g.M ? r : g.M - 1;
+    if (2 * spart < g.ln_nseg) sv = *reinterpret_cast<const f32x4*>(g.ln_in + ((size_t)r * g.ln_nseg + 2 * spart) * 2);
+  }
   const int ocol = n0 + l32;
   const bool colok = ocol < g.N;
   const float bv = (g.bias && colok) ? g.bias[ocol] : 0.f;
-  float* Cout = g.C + bz * g.batch_stride_c;
-  float v[4], rv[4];
-  int orow[4];
+  const bool tab = MODE == 1 && g.rowtab != nullptr && !g.res;
+  float rv[RPW];
+  int orow[RPW], prow[RPW];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int e = wave * 4 + q;
-    v[q] = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
-           (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
-    orow[q] = m0 + 8 * wave + q + 4 * half;
+  for (int q = 0; q < RPW; ++q) {
+    const int e = wave * RPW + q;
+    prow[q] = (e & 3) + 8 * (e >> 2) + 4 * half;
+    orow[q] = m0 + prow[q];
     const bool ok = colok && orow[q] < g.M;
     rv[q] = 0.f;
     if (g.res) { if (ok) rv[q] = g.res[bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol]; }
-    else if (MODE == 1 && g.rowtab && ok && ocol < g.rowtab_cols)
+    else if (tab && ok && ocol < g.rowtab_cols)
       rv[q] = g.rowtab[(size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol];
   }
-  float* patch = red + 4 * 16 * 64;
+  __builtin_amdgcn_sched_barrier(0);
+  float mu = 0.f, rs = 1.f;
+  if (MODE == 1) {
+    // Chan's update over the row's 32-column segments, two per lane, eight lanes per row (ln_nseg even, <= 16)
+    const bool sok = 2 * spart < g.ln_nseg;
+    const float fn = (float)g.ln_nseg;
+    const float mean = ff_sum8(sok ? sv.x + sv.z : 0.f) / fn;
+    const float m2 = ff_sum8(sok ? sv.y + sv.w : 0.f);
+    const float d0 = sv.x - mean, d1 = sv.z - mean;
+    const float dev = ff_sum8(sok ? d0 * d0 + d1 * d1 : 0.f);
+    const float var = (m2 + 32.f * dev) / (32.f * fn);
+    if (spart == 0 && lane < 8 * (32 / NW)) *reinterpret_cast<f32x2*>(lnrow + 2 * srow) = f32x2{mean, 1.0f / sqrtf(var + g.ln_eps)};
+    __syncthreads();
+    const f32x2 ms = *reinterpret_cast<const f32x2*>(lnrow + 2 * l32);
+    mu = ms.x;
+    rs = ms.y;
+  }
+  f32x16 acc;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool tab = MODE == 1 && g.rowtab != nullptr && !g.res;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int g0 = 0; g0 < NG; g0 += GB) {
+    const int cur = (g0 / GB) & 1;
+    if (g0 + GB < NG) {
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        a[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(ap + (g0 + GB + j) * 8);
+        b[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(wp + (g0 + GB + j) * 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      f32x4 av = a[cur][j];
+      if (MODE == 1) av = (av - mu) * rs;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], b[cur][j][c], acc, 0, 0, 0);
+    }
+  }
+  // partial tiles -> LDS [wave][reg][lane]; wave w then finishes registers RPW*w .. RPW*w + RPW-1
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
+  __syncthreads();
+  float* Cout = g.C + bz * g.batch_stride_c;
+  float v[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int e = wave * RPW + q;
+    v[q] = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
+           (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
+    if (NW == 8)
+      v[q] += (red[(4 * 16 + e) * 64 + lane] + red[(5 * 16 + e) * 64 + lane]) +
+              (red[(6 * 16 + e) * 64 + lane] + red[(7 * 16 + e) * 64 + lane]);
+  }
+  float* patch = red + NW * 16 * 64;
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
     float o = v[q] + bv + (tab ? rv[q] : 0.f);
     if (g.act == 1) o = fmaxf(o, 0.f);
     if (!tab) o += rv[q];
     if (colok && orow[q] < g.M) Cout[(size_t)orow[q] * g.ldc + ocol] = o;
-    if (MODE == 2) patch[(8 * wave + q + 4 * half) * 33 + l32] = o;
+    if (MODE == 2) patch[prow[q] * 33 + l32] = o;
   }
   if (MODE == 2) {  // row statistics of the finished 32x32 tile: 64 threads, (row, column half) each
     __syncthreads();
@@ -1228,13 +1266,28 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   }
 }
 
+#ifndef FF_SMALL_WIDE_BLOCKS
+#define FF_SMALL_WIDE_BLOCKS 256
+#endif
+int g_small_wide_blocks = FF_SMALL_WIDE_BLOCKS;  // launches with at most this many tiles split K over eight waves instead of four
+
 template <int MODE>
 int launch_small_mode(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  const bool wide = (long)grid.x * grid.y <= g_small_wide_blocks;
   switch (g.K) {
-    case 512: hipLaunchKernelGGL((gemm_small_kernel<128, MODE>), grid, dim3(256), 0, st, g); break;
-    case 1024: hipLaunchKernelGGL((gemm_small_kernel<256, MODE>), grid, dim3(256), 0, st, g); break;
-    case 128: hipLaunchKernelGGL((gemm_small_kernel<32, MODE>), grid, dim3(256), 0, st, g); break;
-    case 256: hipLaunchKernelGGL((gemm_small_kernel<64, MODE>), grid, dim3(256), 0, st, g); break;
+    case 512:
+      if (wide) hipLaunchKernelGGL((gemm_small_kernel<64, MODE, 8>), grid, dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((gemm_small_kernel<128, MODE, 4>), grid, dim3(256), 0, st, g);
+      break;
+    case 1024:
+      if (wide) hipLaunchKernelGGL((gemm_small_kernel<128, MODE, 8>), grid, dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((gemm_small_kernel<256, MODE, 4>), grid, dim3(256), 0, st, g);
+      break;
+    case 128: hipLaunchKernelGGL((gemm_small_kernel<32, MODE, 4>), grid, dim3(256), 0, st, g); break;
+    case 256:
+      if (wide) hipLaunchKernelGGL((gemm_small_kernel<32, MODE, 8>), grid, dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((gemm_small_kernel<64, MODE, 4>), grid, dim3(256), 0, st, g);
+      break;
     default: ff_set_error("ff_gemm_f32: small-M kernel supports K in {128, 256, 512, 1024}"); return FF_ERR_ARG;
   }
   FF_CHECK_LAUNCH();
