@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
 // the launch then has ks x more independent units, which is what the small-t steps of the decode
 // need (a (wireframe, head) pair offers only F*t/32 query tiles; at t = 1 that is 64 units on 1024 SIMDs).
 template <int NWAVES>
-__global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_desc d, int q_tiles, int ks,
+__global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_wave_kernel(ff_attn_desc d, int q_tiles, int ks,
                                                                       long total_units) {
   constexpr int PATCH = 32 * K_LD;  // 2176 floats per wave: K tile, later the combine record
   __shared__ __attribute__((aligned(16))) float lds[NWAVES * PATCH + NWAVES * 32];
@@ -300,12 +300,6 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_
       qreg[c * 4 + 3] = t.w * qscale;
     }
   }
-  int nk = d.nk;
-  if (d.kv_len) {
-    const int kl = d.kv_len[g];
-    nk = kl < nk ? kl : nk;
-  }
-  const int ntiles = (nk + 31) >> 5;
   const float* kbase = d.k + (size_t)g * d.k_group_stride * d.ldk + h * FF_HEAD_DIM;
   const float* vbase = d.v + (size_t)g * d.k_group_stride * d.ldv + h * FF_HEAD_DIM;
   const unsigned char* mrow = d.key_mask ? d.key_mask + (size_t)g * d.mask_stride : nullptr;
@@ -315,16 +309,35 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_
 #pragma unroll
   for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
 
-  // K staging: lane -> (row = lane/16 + 4p, 16-byte column lane%16): 4 full 256-byte rows per instruction
+  // K staging: lane -> (row = lane/16 + 4p, 16-byte column lane%16): 4 full 256-byte rows per instruction.
+  // Addresses are clamped with the STATIC key count (rows up to d.nk exist), the group's own length only masks:
+  // the first K and V tiles are requested together with kv_len and the queries -- one round trip, not three.
   const int srow = lane >> 4, sc4 = lane & 15;
+  const int nk_s = d.nk;
+  const int tiles_s = (nk_s + 31) >> 5;
   f32x4 kst[8];
+  float v0[16], v1[16];
+  unsigned char mbyte = 0;   // key-mask byte of key (tile, lane), lanes 0..31: travels with the K tile
   auto load_k = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int key = kt * 32 + srow + 4 * p;
-      const int kc = key < nk ? key : (nk > 0 ? nk - 1 : 0);
-      f32x4 v = *reinterpret_cast<const f32x4*>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
-      kst[p] = key < nk ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
+      kst[p] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
+    }
+    if (mrow && lane < 32) {
+      const int key = kt * 32 + lane;
+      mbyte = key < nk_s ? mrow[key] : (unsigned char)1;
+    }
+  };
+  auto load_v = [&](int kt) {   // V fragments straight to registers (each load instruction reads two full 128-byte row segments)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
+      const float* vp = vbase + (size_t)kc * d.k_stride * d.ldv + l32;
+      v0[r] = vp[0];
+      v1[r] = vp[32];
     }
   };
   auto wave_fence = [&]() {
@@ -334,15 +347,24 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_
   };
 
   int kt = kg;
-  if (kt < ntiles) load_k(kt);
+  if (kt < tiles_s) { load_k(kt); load_v(kt); }
+  int nk = nk_s;
+  if (d.kv_len) {
+    const int kl = d.kv_len[g];
+    nk = kl < nk ? kl : nk;
+  }
+  const int ntiles = (nk + 31) >> 5;
   for (; kt < ntiles; kt += ks) {
     // ---- K tile: registers -> private LDS patch -> MFMA fragments ----
 #pragma unroll
-    for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(Kw + (srow + 4 * p) * K_LD + sc4 * 4) = kst[p];
+    for (int p = 0; p < 8; ++p) {
+      const int key = kt * 32 + srow + 4 * p;
+      *reinterpret_cast<f32x4*>(Kw + (srow + 4 * p) * K_LD + sc4 * 4) = key < nk ? kst[p] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (mrow) {
       if (lane < 32) {
         const int key = kt * 32 + lane;
-        Mw[lane] = (key < nk && mrow[key] == 0) ? 0.f : -INFINITY;
+        Mw[lane] = (key < nk && mbyte == 0) ? 0.f : -INFINITY;
       }
     }
     wave_fence();
@@ -350,18 +372,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_
 #pragma unroll
     for (int cg = 0; cg < 8; ++cg) kf[cg] = *reinterpret_cast<const f32x4*>(Kw + l32 * K_LD + half * 32 + cg * 4);
     wave_fence();  // fragments are in registers: the K patch may be overwritten (Mw stays valid)
-    // ---- V fragments of this tile straight to registers; next K tile in flight ----
-    float v0[16], v1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int kc = key < nk ? key : (nk > 0 ? nk - 1 : 0);
-      const float* vp = vbase + (size_t)kc * d.k_stride * d.ldv + l32;
-      const float a = vp[0], b = vp[32];
-      v0[r] = key < nk ? a : 0.f;
-      v1[r] = key < nk ? b : 0.f;
-    }
-    if (kt + ks < ntiles) load_k(kt + ks);
+    // (V rows past the group's length are finite values of real rows; their softmax weight is exactly 0)
+    if (kt + ks < ntiles) load_k(kt + ks);   // next K tile in flight under the MFMA chains
     // ---- S^T tile ----
     f32x16 s;
 #pragma unroll
@@ -408,40 +420,55 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void attention_wave_kernel(ff_attn_
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
     }
+    if (kt + ks < ntiles) load_v(kt + ks);
   }
 
+  float* const op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
   if (ks > 1) {
-    // ---- combine the ks key groups of a unit through LDS (record: O[32 regs][64 lanes], m, l) ----
+    // ---- combine the ks key groups of a unit through LDS (record: O[32 regs][64 lanes], m, l).  Every wave of the
+    //      unit takes 32 / ks of the output registers and sums them over the records in ascending key-group order.
     wave_fence();
 #pragma unroll
     for (int e = 0; e < 16; ++e) { Kw[e * 64 + lane] = o0[e]; Kw[(16 + e) * 64 + lane] = o1[e]; }
     Kw[32 * 64 + lane] = m_run;   // 2048 + 64 + 64 = 2176 = PATCH exactly
     Kw[33 * 64 + lane] = l_run;
     __syncthreads();
-    if (kg != 0) return;
-    float m_star = m_run;
-    for (int j = 1; j < ks; ++j) m_star = fmaxf(m_star, lds[(wave + j) * PATCH + 32 * 64 + lane]);
+    const float* rec0 = lds + (wave - kg) * PATCH;
+    float sc[8];
+    float m_star = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < ks) { sc[j] = rec0[j * PATCH + 32 * 64 + lane]; m_star = fmaxf(m_star, sc[j]); }
     const float ms = (m_star == -INFINITY) ? 0.f : m_star;
-    const float sc0 = ff_exp2(m_run - ms);
-    l_run *= sc0;
+    float l_sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { o0[e] *= sc0; o1[e] *= sc0; }
-    for (int j = 1; j < ks; ++j) {
-      const float* rec = lds + (wave + j) * PATCH;
-      const float scj = ff_exp2(rec[32 * 64 + lane] - ms);
-      l_run += rec[33 * 64 + lane] * scj;
+    for (int j = 0; j < 8; ++j)
+      if (j < ks) { sc[j] = ff_exp2(sc[j] - ms); l_sum += rec0[j * PATCH + 33 * 64 + lane] * sc[j]; }
+    const float l_all = l_sum + __shfl_xor(l_sum, 32, FF_WAVE);
+    const float inv_c = l_all > 0.f ? 1.0f / l_all : 0.f;
+    if (!q_valid) return;
+    const int quads = 8 / ks;                 // groups of four output registers per wave (ks = 2, 4, 8)
+    for (int qd = 0; qd < quads; ++qd) {
+      const int e0 = (kg * quads + qd) * 4;   // registers e0 .. e0+3: o0 for e0 < 16, else o1
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        o0[e] += rec[e * 64 + lane] * scj;
-        o1[e] += rec[(16 + e) * 64 + lane] * scj;
-      }
+      for (int j = 0; j < 8; ++j)
+        if (j < ks) {
+          const float* r = rec0 + j * PATCH + e0 * 64 + lane;
+          acc.x += r[0] * sc[j];
+          acc.y += r[64] * sc[j];
+          acc.z += r[128] * sc[j];
+          acc.w += r[192] * sc[j];
+        }
+      acc.x *= inv_c; acc.y *= inv_c; acc.z *= inv_c; acc.w *= inv_c;
+      *reinterpret_cast<f32x4*>(op + (e0 < 16 ? 2 * e0 : 32 + 2 * (e0 - 16))) = acc;
     }
+    return;
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, FF_WAVE);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (q_valid) {
-    float* op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 a = {o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv, o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv};
@@ -763,8 +790,10 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   // K/V-resident kernel: key sets of at most 288 rows shared by several query tiles (decoder cross-attention of the
   // 64..256-edge configurations, encoder); not for the per-sequence self-attention (2048+ tiny key sets)
   const int qt32 = ff_cdiv(d.nq, 32);
+  // (the pair's K/V load is a fixed cost of every block: it pays from ~2 query tiles per CU on -- measured: config B
+  //  from t = 8, never for the single-sequence decode, whose 8 pairs have at most 9 query tiles each)
   const bool resident_ok = d.nk <= RK_KEYS && d.nk > 0;
-  if (g_attention_algo == 3 ? resident_ok : (g_attention_algo == 0 && resident_ok && qt32 >= 4)) {
+  if (g_attention_algo == 3 ? resident_ok : (g_attention_algo == 0 && resident_ok && qt32 >= 4 && gh * qt32 >= 512)) {
     static bool attr_done[16] = {};
     int dev = 0;
     FF_CHECK_HIP(hipGetDevice(&dev));
@@ -786,16 +815,22 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   const bool use_wave = g_attention_algo == 2 ||
                         (g_attention_algo == 0 && (gh * ff_cdiv(d.nq, 32) < 1536 || d.nq <= 64));
   if (use_wave) {
-    // wave-independent kernel: units = (group, head, 32-query tile); split the key tiles over ks waves
-    // when the launch would otherwise leave SIMDs idle (ks | 4, at most one key tile per wave).
+    // wave-independent kernel: units = (group, head, 32-query tile); the key tiles are dealt round-robin to ks waves
+    // (ks = 1, 2, 4, 8: a power of two up to the tile count, idle waves allowed) while the launch would otherwise
+    // leave SIMDs idle -- a wave's tiles are a serial chain of memory round trips.
     const int qt = ff_cdiv(d.nq, 32);
     const long units = gh * qt;
     const int key_tiles = ff_cdiv(d.nk, 32);
     int ks = 1;
-    while (ks < 4 && units * ks < 2048 && key_tiles >= 2 * ks) ks *= 2;
-    const long nblocks = (units + (4 / ks) - 1) / (4 / ks);
-    FF_CHECK_ARG(nblocks < 2147483647L, "ff_attention: grid too large");
-    hipLaunchKernelGGL((attention_wave_kernel<4>), dim3((unsigned)nblocks), dim3(256), 0, st, d, qt, ks, units);
+    while (ks < 8 && units * ks * 2 <= 2048 && ks < key_tiles) ks *= 2;
+    if (ks == 8) {
+      FF_CHECK_ARG(units < 2147483647L, "ff_attention: grid too large");
+      hipLaunchKernelGGL((attention_wave_kernel<8>), dim3((unsigned)units), dim3(512), 0, st, d, qt, ks, units);
+    } else {
+      const long nblocks = (units + (4 / ks) - 1) / (4 / ks);
+      FF_CHECK_ARG(nblocks < 2147483647L, "ff_attention: grid too large");
+      hipLaunchKernelGGL((attention_wave_kernel<4>), dim3((unsigned)nblocks), dim3(256), 0, st, d, qt, ks, units);
+    }
     FF_CHECK_LAUNCH();
     return FF_OK;
   }

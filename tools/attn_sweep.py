@@ -14,7 +14,7 @@ lib = L.load()
 F, H, E = 256, 8, 512
 
 
-def run(t, S, algo, iters=30):
+def run(t, S, algo, iters=30, F=F):
     ops.set_attention_algo(algo)
     q = torch.randn(t * F, E, device="cuda")
     kv = torch.randn(S, 2 * E, device="cuda")
@@ -38,6 +38,15 @@ def run(t, S, algo, iters=30):
     return a.elapsed_time(b) / iters * 1e3
 
 
+if "--seq" in sys.argv:   # single-sequence decode (seq2seq variant): t queries; cross key sets 68 / 220, self S = t
+    print("%4s %5s | %8s %8s %8s %8s" % ("t", "S", "lds(1)", "wave(2)", "resid(3)", "auto(0)"))
+    for S in (68, 220, 0):
+        for t in (16, 32, 64, 96, 128, 192, 258):
+            k = S if S else t
+            print("%4d %5d | %8.1f %8.1f %8.1f %8.1f" % (t, k, run(t, k, 1, F=1), run(t, k, 2, F=1), run(t, k, 3, F=1),
+                                                       run(t, k, 0, F=1)))
+    ops.set_attention_algo(0)
+    sys.exit(0)
 print("%4s %5s | %8s %8s %8s" % ("t", "S", "lds(1)", "wave(2)", "resid(3)"))
 for S in (32, 64, 132, 260):
     for t in (1, 4, 8, 16, 24, 32, 36):
