@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--ts", default="1,2,4,8,12,16,24,36")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--tiles", default="3,7,8")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "ones"],
+                    help="operand values (the chip clocks to its power budget: zeros show the issue-bound rate)")
     args = ap.parse_args()
     dev = "cuda"
     shapes = [(512, 1536), (512, 512), (512, 1024), (1024, 512)]
@@ -40,6 +42,9 @@ def main():
             a = torch.randn(M, K, device=dev)
             w = torch.randn(N, K, device=dev) * 0.05
             b = torch.randn(N, device=dev)
+            if args.data != "randn":
+                val = 0.0 if args.data == "zeros" else 1.0
+                a.fill_(val); w.fill_(val); b.fill_(val)
             out = torch.empty(M, N, device=dev)
             flops = 2.0 * M * N * K
             iters = max(3, min(50, int(2e11 / flops)))
