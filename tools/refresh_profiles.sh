@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): regenerate every file of profiles/<tag>/ with the current build --
 # kernel trace + PMC passes (collect_profiles.sh), per-step breakdown, the bench lines of configs B / C / E,
-# the seq2seq timings and the cross-attention sweep.  Results land in gpurun_out/profiles_<tag>/.
+# the seq2seq timings, the attention sweeps, the projection-kernel tables (tile variants vs the vendor library, zero-filled
+# operands, LayerNorm-fused forms), the vendor kernel names and the MFMA micro-benchmarks.  Results land in gpurun_out/profiles_<tag>/.
 set -u
 TAG=${1:-r02}
 cd "$GRAFT_REPO_ROOT"
@@ -17,5 +18,15 @@ timeout 600 python bench.py --config E --steps 3 --warmup 1 --no-cpu-baseline > 
 timeout 600 python bench.py --config E --steps 2 --warmup 1 --no-cpu-baseline --no-dedup --no-x3-line > $OUT/bench_${TAG}_E32_nodedup.json 2>> $OUT/bench_B.err
 timeout 600 python tools/time_seq2seq.py > $OUT/seq2seq.txt 2>&1
 timeout 600 python tools/attn_sweep.py > $OUT/attention_sweep.txt 2>&1
+timeout 600 python tools/attn_sweep.py --seq > $OUT/attention_sweep_seq2seq.txt 2>&1
+timeout 900 python tools/bench_gemm.py --ts 16,36,64,128 --tiles 2,3,4,5,7 > $OUT/gemm_tiles_vs_vendor.txt 2>&1
+timeout 900 python tools/bench_gemm.py --ts 36,128 --tiles 3,7 --data zeros > $OUT/gemm_zero_operands.txt 2>&1
+timeout 600 python tools/bench_gemm_ln.py > $OUT/gemm_ln_fusion.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && rm -rf /tmp/vn &&
+  rocprofv3 --kernel-trace --stats -d /tmp/vn -o v -- python tools/vendor_names.py > /dev/null 2>&1 &&
+  python tools/rocpd_stats.py /tmp/vn/v_results.db $OUT/vendor_kernels.md > /dev/null 2>&1; rm -rf /tmp/vn )
+for u in mfma_chain mfma_lds; do
+  hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o /tmp/$u 2>/dev/null && /tmp/$u > $OUT/ubench_$u.txt 2>&1
+done
 ls -la $OUT
 tail -c 1500 $OUT/bench_${TAG}_B.json
