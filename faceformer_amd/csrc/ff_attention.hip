@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
 // need (a (wireframe, head) pair offers only F*t/32 query tiles; at t = 1 that is 64 units on 1024 SIMDs).
 template <int NWAVES>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_wave_kernel(ff_attn_desc d, int q_tiles, int ks,
-                                                                      long total_units) {
+                                                                      long total_units, int tail_ok, int qtail) {
   constexpr int PATCH = 32 * K_LD;  // 2176 floats per wave: K tile, later the combine record
   __shared__ __attribute__((aligned(16))) float lds[NWAVES * PATCH + NWAVES * 32];
   const int tid = threadIdx.x;
@@ -353,7 +353,12 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_
     const int kl = d.kv_len[g];
     nk = kl < nk ? kl : nk;
   }
-  const int ntiles = (nk + 31) >> 5;
+  // Short tails (per-sequence self-attention one to four positions past a multiple of 32: t = 33..36 of the 37-token
+  // configurations) do not get a 32-wide MFMA tile of their own: <= 4 extra KEYS are folded into the running softmax
+  // on the VALU (lane = query), <= 4 extra QUERIES are evaluated after the unit's own tile (lane = key, then lane =
+  // head dimension).  36 x 36 scores then cost one tile step + ~3 us instead of four tile steps.
+  const int ktail = (tail_ok && nk > 32 && (nk & 31) >= 1 && (nk & 31) <= 4) ? (nk & 31) : 0;
+  const int ntiles = ktail ? (nk >> 5) : ((nk + 31) >> 5);
   for (; kt < ntiles; kt += ks) {
     // ---- K tile: registers -> private LDS patch -> MFMA fragments ----
 #pragma unroll
@@ -423,6 +428,51 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_
     if (kt + ks < ntiles) load_v(kt + ks);
   }
 
+  if (ktail) {   // (ks == 1) keys 32 * ntiles .. nk-1 for this wave's 32 queries
+    float sj[4];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int key = ntiles * 32 + jj;
+      const int kc = key < nk ? key : nk - 1;
+      const float* kp = kbase + (size_t)kc * d.k_stride * d.ldk + half * 32;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + c * 4);
+        dot += kv.x * qreg[c * 4 + 0] + kv.y * qreg[c * 4 + 1] + kv.z * qreg[c * 4 + 2] + kv.w * qreg[c * 4 + 3];
+      }
+      dot += __shfl_xor(dot, 32, FF_WAVE);
+      bool ok = key < nk && (!mrow || mrow[kc] == 0);
+      if (d.causal && key > qi) ok = false;
+      sj[jj] = ok ? dot : -INFINITY;
+      tmax = fmaxf(tmax, sj[jj]);
+    }
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = ff_exp2(m_run - m_safe);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    float psum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float pj = ff_exp2(sj[jj] - m_safe);   // 0 for masked / absent keys
+      psum += pj;
+      const int key = ntiles * 32 + jj;
+      const int kc = key < nk ? key : nk - 1;
+      const float* vp = vbase + (size_t)kc * d.k_stride * d.ldv + 4 * half;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(vp + 8 * g4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(vp + 32 + 8 * g4);
+        o0[g4 * 4 + 0] += pj * a.x; o0[g4 * 4 + 1] += pj * a.y; o0[g4 * 4 + 2] += pj * a.z; o0[g4 * 4 + 3] += pj * a.w;
+        o1[g4 * 4 + 0] += pj * b.x; o1[g4 * 4 + 1] += pj * b.y; o1[g4 * 4 + 2] += pj * b.z; o1[g4 * 4 + 3] += pj * b.w;
+      }
+    }
+    l_run = l_run * alpha + (half == 0 ? psum : 0.f);   // both halves hold the same weights: count them once
+    m_run = m_new;
+  }
+
   float* const op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
   if (ks > 1) {
     // ---- combine the ks key groups of a unit through LDS (record: O[32 regs][64 lanes], m, l).  Every wave of the
@@ -476,6 +526,52 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_
       *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
       *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = b;
     }
+  }
+
+  if (qtail > 0 && unit_valid && qt == q_tiles - 1) {   // (ks == 1, nk <= 64) queries 32 * q_tiles .. nq-1 of this (group, head)
+    // scores: lane = key
+    const int kc = lane < nk ? lane : (nk > 0 ? nk - 1 : 0);
+    bool kok = lane < nk;
+    if (mrow && kok) kok = mrow[kc] == 0;
+    f32x4 kr[16];
+    {
+      const float* kp = kbase + (size_t)kc * d.k_stride * d.ldk;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) kr[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
+    }
+    wave_fence();   // the K patch is free (ks == 1: no record in it)
+    size_t orow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qx = q_tiles * 32 + (i < qtail ? i : qtail - 1);
+      orow[i] = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
+      const float* qp = d.q + orow[i] * d.ldq + h * FF_HEAD_DIM;   // wave-uniform address
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + c * 4);
+        dot += kr[c].x * qv.x + kr[c].y * qv.y + kr[c].z * qv.z + kr[c].w * qv.w;
+      }
+      const bool ok = kok && !(d.causal && lane > qx);
+      const float sv = ok ? dot * qscale : -INFINITY;
+      const float mx = ff_wave_max(sv);
+      const float pe = ok ? ff_exp2(sv - mx) : 0.f;
+      const float ls = ff_wave_sum(pe);
+      Kw[lane * 4 + i] = ls > 0.f ? pe / ls : 0.f;   // normalised weights, [key][query]
+    }
+    wave_fence();
+    // values: lane = head dimension; one coalesced 256-byte row of V per key
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nk; ++j) {
+      const float vv = vbase[(size_t)j * d.k_stride * d.ldv + lane];
+      const f32x4 pw = *reinterpret_cast<const f32x4*>(Kw + j * 4);
+      acc.x += pw.x * vv; acc.y += pw.y * vv; acc.z += pw.z * vv; acc.w += pw.w * vv;
+    }
+    float* ob = d.o + h * FF_HEAD_DIM + lane;
+    ob[orow[0] * d.ldo] = acc.x;
+    if (qtail > 1) ob[orow[1] * d.ldo] = acc.y;
+    if (qtail > 2) ob[orow[2] * d.ldo] = acc.z;
+    if (qtail > 3) ob[orow[3] * d.ldo] = acc.w;
   }
 }
 
@@ -818,18 +914,25 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     // wave-independent kernel: units = (group, head, 32-query tile); the key tiles are dealt round-robin to ks waves
     // (ks = 1, 2, 4, 8: a power of two up to the tile count, idle waves allowed) while the launch would otherwise
     // leave SIMDs idle -- a wave's tiles are a serial chain of memory round trips.
-    const int qt = ff_cdiv(d.nq, 32);
+    // short tails (see the kernel): keys / queries 1..4 past a multiple of 32 ride along with the last full tile when
+    // every unit is one wave anyway (ks == 1) and a key set fits the lanes of a wave
+    const bool tails = d.nk <= 64 && gh * (d.nq / 32) * 2 > 2048;
+    const int qrem = d.nq & 31;
+    const int qtail = (tails && d.nq > 32 && qrem >= 1 && qrem <= 4) ? qrem : 0;
+    const int qt = qtail ? d.nq / 32 : ff_cdiv(d.nq, 32);
     const long units = gh * qt;
     const int key_tiles = ff_cdiv(d.nk, 32);
     int ks = 1;
     while (ks < 8 && units * ks * 2 <= 2048 && ks < key_tiles) ks *= 2;
+    const int tail_ok = (tails && ks == 1) ? 1 : 0;
     if (ks == 8) {
       FF_CHECK_ARG(units < 2147483647L, "ff_attention: grid too large");
-      hipLaunchKernelGGL((attention_wave_kernel<8>), dim3((unsigned)units), dim3(512), 0, st, d, qt, ks, units);
+      hipLaunchKernelGGL((attention_wave_kernel<8>), dim3((unsigned)units), dim3(512), 0, st, d, qt, ks, units, 0, 0);
     } else {
       const long nblocks = (units + (4 / ks) - 1) / (4 / ks);
       FF_CHECK_ARG(nblocks < 2147483647L, "ff_attention: grid too large");
-      hipLaunchKernelGGL((attention_wave_kernel<4>), dim3((unsigned)nblocks), dim3(256), 0, st, d, qt, ks, units);
+      hipLaunchKernelGGL((attention_wave_kernel<4>), dim3((unsigned)nblocks), dim3(256), 0, st, d, qt, ks, units, tail_ok,
+                         qtail);
     }
     FF_CHECK_LAUNCH();
     return FF_OK;
