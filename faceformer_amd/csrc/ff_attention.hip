@@ -266,12 +266,20 @@ template <int NWAVES>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_wave_kernel(ff_attn_desc d, int q_tiles, int ks,
                                                                       long total_units, int tail_ok, int qtail) {
   constexpr int PATCH = 32 * K_LD;  // 2176 floats per wave: K tile, later the combine record
-  __shared__ __attribute__((aligned(16))) float lds[NWAVES * PATCH + NWAVES * 32];
+  // short-tail mode (four-wave blocks only): rows of up to 8 extra keys (K, V), up to 8 extra queries, their weights
+  constexpr int TAILF = NWAVES == 4 ? (3 * 8 * 64 + 40 * 8 + 8) : 0;
+  __shared__ __attribute__((aligned(16))) float lds[NWAVES * PATCH + NWAVES * 32 + NWAVES * TAILF];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, l32 = lane & 31;
   float* Kw = lds + wave * PATCH;
   float* Mw = lds + NWAVES * PATCH + wave * 32;
+  float* const Kt = lds + NWAVES * (PATCH + 32) + wave * TAILF;   // [8][64] keys 32..39
+  float* const Vt = Kt + 512;                                     // [8][64]
+  float* const Qt = Kt + 1024;                                    // [8][64] queries 32 * q_tiles ..
+  float* const Pw = Kt + 1536;                                    // [40][8] softmax weights of the extra queries
+  float* const Mt = Kt + 1856;                                    // [8] additive mask of the extra keys
+  const bool tails = NWAVES == 4 && tail_ok != 0;                 // block-uniform
 
   const int units_per_block = NWAVES / ks;
   const long unit = (long)blockIdx.x * units_per_block + wave / ks;
@@ -348,16 +356,47 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_
 
   int kt = kg;
   if (kt < tiles_s) { load_k(kt); load_v(kt); }
+  const bool q_extra = tails && qtail > 0 && unit_valid && qt == q_tiles - 1;   // this wave also serves the extra queries
+  f32x4 tk[2], tv[2], tq[2];
+  unsigned char tmb = 0;
+  if (tails) {   // the extra rows are requested in the same round trip as everything else
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int key = 32 + srow + 4 * p;
+      const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
+      tk[p] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
+      tv[p] = *reinterpret_cast<const f32x4*>(vbase + (size_t)kc * d.k_stride * d.ldv + sc4 * 4);
+      if (q_extra) {
+        const int r = srow + 4 * p;
+        const int qx = q_tiles * 32 + (r < qtail ? r : qtail - 1);
+        const size_t xr = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
+        tq[p] = *reinterpret_cast<const f32x4*>(d.q + xr * d.ldq + h * FF_HEAD_DIM + sc4 * 4);
+      }
+    }
+    if (mrow && lane < 8) tmb = (32 + lane) < nk_s ? mrow[32 + lane] : (unsigned char)1;
+  }
   int nk = nk_s;
   if (d.kv_len) {
     const int kl = d.kv_len[g];
     nk = kl < nk ? kl : nk;
   }
-  // Short tails (per-sequence self-attention one to four positions past a multiple of 32: t = 33..36 of the 37-token
-  // configurations) do not get a 32-wide MFMA tile of their own: <= 4 extra KEYS are folded into the running softmax
-  // on the VALU (lane = query), <= 4 extra QUERIES are evaluated after the unit's own tile (lane = key, then lane =
-  // head dimension).  36 x 36 scores then cost one tile step + ~3 us instead of four tile steps.
-  const int ktail = (tail_ok && nk > 32 && (nk & 31) >= 1 && (nk & 31) <= 4) ? (nk & 31) : 0;
+  if (tails) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<f32x4*>(Kt + (srow + 4 * p) * 64 + sc4 * 4) = tk[p];
+      *reinterpret_cast<f32x4*>(Vt + (srow + 4 * p) * 64 + sc4 * 4) = tv[p];
+      if (q_extra) *reinterpret_cast<f32x4*>(Qt + (srow + 4 * p) * 64 + sc4 * 4) = tq[p];
+    }
+    if (lane < 8) Mt[lane] = ((32 + lane) < nk && tmb == 0) ? 0.f : -INFINITY;
+    wave_fence();
+  }
+  // Short tails (per-sequence self-attention one to eight positions past a multiple of 32: t = 33..37 of the 37- / 38-
+  // token configurations) do not get 32-wide MFMA tiles of their own: the extra KEYS are folded into the running
+  // softmax on the VALU (lane = query), the extra QUERIES are evaluated after the unit's own tile (lane = key for
+  // the scores, lane = head dimension for the values).  Their rows wait in LDS since the first round trip; the main
+  // tile's K patch and V fragments are reused -- no further memory request.  36 x 36 scores cost one tile step plus
+  // ~3 us instead of four tile steps.
+  const int ktail = (tails && nk > 32 && nk <= 40) ? nk - 32 : 0;
   const int ntiles = ktail ? (nk >> 5) : ((nk + 31) >> 5);
   for (; kt < ntiles; kt += ks) {
     // ---- K tile: registers -> private LDS patch -> MFMA fragments ----
@@ -428,25 +467,26 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_
     if (kt + ks < ntiles) load_v(kt + ks);
   }
 
-  if (ktail) {   // (ks == 1) keys 32 * ntiles .. nk-1 for this wave's 32 queries
-    float sj[4];
+  if (ktail) {   // (ks == 1, one main tile) keys 32 .. nk-1 for this wave's 32 queries
+    float sj[8];
     float tmax = -INFINITY;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int key = ntiles * 32 + jj;
-      const int kc = key < nk ? key : nk - 1;
-      const float* kp = kbase + (size_t)kc * d.k_stride * d.ldk + half * 32;
-      float dot = 0.f;
+    for (int jj = 0; jj < 8; ++jj) {
+      sj[jj] = -INFINITY;
+      if (jj < ktail) {   // wave-uniform
+        const float* kp = Kt + jj * 64 + half * 32;
+        float dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + c * 4);
-        dot += kv.x * qreg[c * 4 + 0] + kv.y * qreg[c * 4 + 1] + kv.z * qreg[c * 4 + 2] + kv.w * qreg[c * 4 + 3];
+        for (int c = 0; c < 8; ++c) {
+          const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + c * 4);
+          dot += kv.x * qreg[c * 4 + 0] + kv.y * qreg[c * 4 + 1] + kv.z * qreg[c * 4 + 2] + kv.w * qreg[c * 4 + 3];
+        }
+        dot += __shfl_xor(dot, 32, FF_WAVE);
+        float sv = dot + Mt[jj];
+        if (d.causal && (32 + jj) > qi) sv = -INFINITY;
+        sj[jj] = sv;
+        tmax = fmaxf(tmax, sv);
       }
-      dot += __shfl_xor(dot, 32, FF_WAVE);
-      bool ok = key < nk && (!mrow || mrow[kc] == 0);
-      if (d.causal && key > qi) ok = false;
-      sj[jj] = ok ? dot : -INFINITY;
-      tmax = fmaxf(tmax, sj[jj]);
     }
     const float m_new = fmaxf(m_run, tmax);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
@@ -455,18 +495,18 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_
     for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
     float psum = 0.f;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const float pj = ff_exp2(sj[jj] - m_safe);   // 0 for masked / absent keys
-      psum += pj;
-      const int key = ntiles * 32 + jj;
-      const int kc = key < nk ? key : nk - 1;
-      const float* vp = vbase + (size_t)kc * d.k_stride * d.ldv + 4 * half;
+    for (int jj = 0; jj < 8; ++jj) {
+      if (jj < ktail) {
+        const float pj = ff_exp2(sj[jj] - m_safe);   // 0 for masked keys
+        psum += pj;
+        const float* vp = Vt + jj * 64 + 4 * half;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(vp + 8 * g4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(vp + 32 + 8 * g4);
-        o0[g4 * 4 + 0] += pj * a.x; o0[g4 * 4 + 1] += pj * a.y; o0[g4 * 4 + 2] += pj * a.z; o0[g4 * 4 + 3] += pj * a.w;
-        o1[g4 * 4 + 0] += pj * b.x; o1[g4 * 4 + 1] += pj * b.y; o1[g4 * 4 + 2] += pj * b.z; o1[g4 * 4 + 3] += pj * b.w;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(vp + 8 * g4);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(vp + 32 + 8 * g4);
+          o0[g4 * 4 + 0] += pj * a.x; o0[g4 * 4 + 1] += pj * a.y; o0[g4 * 4 + 2] += pj * a.z; o0[g4 * 4 + 3] += pj * a.w;
+          o1[g4 * 4 + 0] += pj * b.x; o1[g4 * 4 + 1] += pj * b.y; o1[g4 * 4 + 2] += pj * b.z; o1[g4 * 4 + 3] += pj * b.w;
+        }
       }
     }
     l_run = l_run * alpha + (half == 0 ? psum : 0.f);   // both halves hold the same weights: count them once
@@ -528,50 +568,79 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_
     }
   }
 
-  if (qtail > 0 && unit_valid && qt == q_tiles - 1) {   // (ks == 1, nk <= 64) queries 32 * q_tiles .. nq-1 of this (group, head)
-    // scores: lane = key
-    const int kc = lane < nk ? lane : (nk > 0 ? nk - 1 : 0);
-    bool kok = lane < nk;
-    if (mrow && kok) kok = mrow[kc] == 0;
+  if (q_extra) {   // (ks == 1, nk <= 40) queries 32 * q_tiles .. nq-1 of this (group, head)
+    // scores: lane = key; K rows 0..31 are still in the patch (one main tile), rows 32.. in Kt
+    const int lk = lane < 40 ? lane : 39;
+    const float* krp = lane < 32 ? Kw + lane * K_LD : Kt + (lk - 32) * 64;
     f32x4 kr[16];
-    {
-      const float* kp = kbase + (size_t)kc * d.k_stride * d.ldk;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) kr[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
-    }
-    wave_fence();   // the K patch is free (ks == 1: no record in it)
-    size_t orow[4];
+    for (int c = 0; c < 16; ++c) kr[c] = *reinterpret_cast<const f32x4*>(krp + c * 4);
+    bool kok = lane < nk;
+    if (mrow && kok) kok = (lane < 32 ? Mw[lane] : Mt[lk - 32]) == 0.f;
+    f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int qx = q_tiles * 32 + (i < qtail ? i : qtail - 1);
-      orow[i] = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
-      const float* qp = d.q + orow[i] * d.ldq + h * FF_HEAD_DIM;   // wave-uniform address
-      float dot = 0.f;
+    for (int i = 0; i < 8; ++i) {
+      if (i < qtail) {   // wave-uniform
+        const float* qp = Qt + i * 64;
+        float dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + c * 4);
-        dot += kr[c].x * qv.x + kr[c].y * qv.y + kr[c].z * qv.z + kr[c].w * qv.w;
+        for (int c = 0; c < 16; ++c) {
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + c * 4);
+          dot += kr[c].x * qv.x + kr[c].y * qv.y + kr[c].z * qv.z + kr[c].w * qv.w;
+        }
+        const bool ok = kok && !(d.causal && lane > q_tiles * 32 + i);
+        const float sv = ok ? dot * qscale : -INFINITY;
+        const float mx = ff_wave_max(sv);
+        const float pe = ok ? ff_exp2(sv - mx) : 0.f;
+        const float ls = ff_wave_sum(pe);
+        const float pn = ls > 0.f ? pe / ls : 0.f;   // normalised weight of (query i, key lane)
+        if (i < 4) pa[i & 3] = pn; else pb[i & 3] = pn;
       }
-      const bool ok = kok && !(d.causal && lane > qx);
-      const float sv = ok ? dot * qscale : -INFINITY;
-      const float mx = ff_wave_max(sv);
-      const float pe = ok ? ff_exp2(sv - mx) : 0.f;
-      const float ls = ff_wave_sum(pe);
-      Kw[lane * 4 + i] = ls > 0.f ? pe / ls : 0.f;   // normalised weights, [key][query]
+    }
+    if (lane < 40) {
+      *reinterpret_cast<f32x4*>(Pw + lane * 8) = pa;
+      *reinterpret_cast<f32x4*>(Pw + lane * 8 + 4) = pb;
     }
     wave_fence();
-    // values: lane = head dimension; one coalesced 256-byte row of V per key
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < nk; ++j) {
-      const float vv = vbase[(size_t)j * d.k_stride * d.ldv + lane];
-      const f32x4 pw = *reinterpret_cast<const f32x4*>(Kw + j * 4);
-      acc.x += pw.x * vv; acc.y += pw.y * vv; acc.z += pw.z * vv; acc.w += pw.w * vv;
+    // values: lane = (head dimension l32 | 32 + l32, key half); the main tile's V fragments are still in v0 / v1
+    float a0[8], a1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(Pw + key * 8);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(Pw + key * 8 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a0[i] += wa[i] * v0[r]; a1[i] += wa[i] * v1[r];
+        a0[4 + i] += wb[i] * v0[r]; a1[4 + i] += wb[i] * v1[r];
+      }
     }
-    float* ob = d.o + h * FF_HEAD_DIM + lane;
-    ob[orow[0] * d.ldo] = acc.x;
-    if (qtail > 1) ob[orow[1] * d.ldo] = acc.y;
-    if (qtail > 2) ob[orow[2] * d.ldo] = acc.z;
-    if (qtail > 3) ob[orow[3] * d.ldo] = acc.w;
+    const float once = half == 0 ? 1.f : 0.f;   // the extra keys are not split between the halves
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      if (jj < ktail) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(Pw + (32 + jj) * 8);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(Pw + (32 + jj) * 8 + 4);
+        const float x0 = Vt[jj * 64 + l32] * once, x1 = Vt[jj * 64 + 32 + l32] * once;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a0[i] += wa[i] * x0; a1[i] += wa[i] * x1;
+          a0[4 + i] += wb[i] * x0; a1[4 + i] += wb[i] * x1;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < qtail) {
+        const float s0 = a0[i] + __shfl_xor(a0[i], 32, FF_WAVE);
+        const float s1 = a1[i] + __shfl_xor(a1[i], 32, FF_WAVE);
+        const int qx = q_tiles * 32 + i;
+        const size_t xr = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
+        d.o[xr * d.ldo + h * FF_HEAD_DIM + 32 * half + l32] = half ? s1 : s0;
+      }
+    }
   }
 }
 
@@ -914,11 +983,11 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     // wave-independent kernel: units = (group, head, 32-query tile); the key tiles are dealt round-robin to ks waves
     // (ks = 1, 2, 4, 8: a power of two up to the tile count, idle waves allowed) while the launch would otherwise
     // leave SIMDs idle -- a wave's tiles are a serial chain of memory round trips.
-    // short tails (see the kernel): keys / queries 1..4 past a multiple of 32 ride along with the last full tile when
-    // every unit is one wave anyway (ks == 1) and a key set fits the lanes of a wave
-    const bool tails = d.nk <= 64 && gh * (d.nq / 32) * 2 > 2048;
+    // short tails (see the kernel): keys / queries 1..8 past a multiple of 32 ride along with the full tile when every
+    // unit is one wave anyway (ks == 1) and the key set is one tile plus the tail
+    const bool tails = d.nk <= 40 && gh * (d.nq / 32) * 2 > 2048;
     const int qrem = d.nq & 31;
-    const int qtail = (tails && d.nq > 32 && qrem >= 1 && qrem <= 4) ? qrem : 0;
+    const int qtail = (tails && d.nq > 32 && qrem >= 1 && qrem <= 8) ? qrem : 0;
     const int qt = qtail ? d.nq / 32 : ff_cdiv(d.nq, 32);
     const long units = gh * qt;
     const int key_tiles = ff_cdiv(d.nk, 32);

@@ -229,7 +229,7 @@ def ref_attention(q, k, v, mask=None, causal=False):
 
 @pytest.mark.parametrize("G,H,nq,nk", [(2, 2, 33, 33), (1, 8, 260, 260), (3, 2, 5, 100), (4, 1, 1, 1),
                                        (2, 8, 140, 70), (1, 2, 64, 64), (1, 1, 65, 129),
-                                       (600, 2, 35, 36), (530, 2, 36, 64), (515, 2, 68, 40)])   # short-tail paths
+                                       (600, 2, 35, 36), (530, 2, 36, 64), (515, 2, 68, 40), (520, 2, 40, 40), (513, 2, 37, 33)])   # short-tail paths
 def test_attention_group_major_with_mask(ops, attn_algo, G, H, nq, nk):
     """Encoder-style layout: rows = g*len + i; padding mask + kv_len."""
     E = H * 64
@@ -255,7 +255,8 @@ def test_attention_group_major_with_mask(ops, attn_algo, G, H, nq, nk):
 @pytest.mark.parametrize("t,B,H,causal", [(1, 5, 2, False), (7, 40, 8, False), (36, 24, 8, False),
                                           (70, 3, 2, False), (9, 4, 2, True), (258, 2, 8, False),
                                           (33, 140, 8, False), (34, 130, 8, False), (36, 256, 8, False),
-                                          (37, 129, 8, False), (35, 140, 8, True)])   # keys / queries 1..5 past 32
+                                          (37, 129, 8, False), (35, 140, 8, True), (40, 129, 8, False), (41, 129, 8, False),
+                                          (38, 129, 8, True)])   # keys / queries 1..9 past 32
 def test_attention_position_major_self(ops, attn_algo, t, B, H, causal):
     """Decoder self-attention layout: rows = j*B + b, packed q|k|v buffer (ld = 3E)."""
     E = H * 64
