@@ -1388,8 +1388,20 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
       // (wide outputs leave it earlier: at 1024 rows the persistent kernel is 8 % / 22 % faster for N = 1536 / 1024)
       if ((long)M * batch <= (N <= 512 ? g_small_max_rows : (g_small_max_rows * 3) / 4) && K >= 512 && small_ok(g))
         return launch_small(g, batch, st);
+      // Plain projections of the large steps: 128x64 block tiles with 64x32 wave tiles and 16-wide slices (two
+      // accumulators share every W fragment: 6 instead of 8 fragment reads per 16 MFMAs, half the global -> LDS
+      // traffic per flop, still two blocks per CU) run 5-10 % faster than the 64x64 stream-K kernel -- as plain
+      // one-tile blocks (a stream-K form of the same geometry was built and measured: no faster than the 64x64 one),
+      // so only when the tile count fills the 512 resident block slots evenly (measured crossover: ~0.9).
+      if (batch == 1 && M >= 4096 && (K & 15) == 0 && gemm_mode(g) == 0 && (!g.A2 || (g.n_split & 63) == 0)) {
+        const long t9 = (long)ff_cdiv(M, 128) * ff_cdiv(N, 64);
+        const long rounds = (t9 + 511) / 512;
+        if (10 * t9 >= 9 * rounds * 512) return launch_pipe<128, 64, 64, 32, 16>(g, batch, st);
+      }
       return launch_streamk(g, batch, st, 0);
     case 8: FF_CHECK_ARG(small_ok(g), "ff_gemm_f32: tile 8 needs K in {128,256,512,1024}"); return launch_small(g, batch, st);
+    case 9: return launch_pipe<128, 64, 64, 32, 16>(g, batch, st);
+    case 10: return launch_pipe<128, 128, 64, 64, 16>(g, batch, st);
     default: return launch_pipe<128, 128, 64, 64>(g, batch, st);
   }
 }
@@ -1409,7 +1421,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 8, "ff_gemm_f32: tile must be 0..8");
+  FF_CHECK_ARG(tile >= 0 && tile <= 10, "ff_gemm_f32: tile must be 0..10");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");

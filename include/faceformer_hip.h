@@ -86,7 +86,10 @@ int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div
  * owning block in a fixed order, so results are run-to-run deterministic), 7 = the stream-K kernel
  * with the launch shape (whole tiles or equal unit ranges) chosen per problem by a cost model: the
  * default on the path; 8 = unstaged split-K kernel for launches with few rows (one 32x32 tile per block,
- * K in {128, 256, 512, 1024} split over the four waves; 7 hands it every launch of at most 1024 rows).
+ * K in {128, 256, 512, 1024} split over four or eight waves; 7 hands it every launch of at most 1024 rows);
+ * 9 = pipelined 128x64 with 16-wide K slices (two blocks per CU; 7 hands it the plain projections of at
+ * least 4096 rows whose tile count fills the resident block slots evenly), 10 = pipelined 128x128 with
+ * 16-wide slices (measurement only).
  * Kernels 6/7 keep an internal 8 MB workspace per (device, stream), allocated at the first launch on
  * that stream.
  * ------------------------------------------------------------------------------------------- */

@@ -64,9 +64,10 @@ def test_add_pos_and_gather(ops):
 
 
 # ---- GEMM -------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10])
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
-                                   (520, 512, 100), (4100, 1024, 512), (64, 260, 512), (130, 96, 36)])
+                                   (520, 512, 100), (4100, 1024, 512), (64, 260, 512), (130, 96, 36),
+                                   (7680, 512, 512), (8192, 1024, 512)])
 def test_gemm_bias_act_residual(ops, M, N, K, tile):
     a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
     # asymmetric operands: a transposed C-write or swapped operand cannot pass
@@ -84,14 +85,15 @@ def test_gemm_identity_layout(ops):
     K = 64
     eye = torch.eye(K)
     w = rnd(96, K, seed=9)
-    for tile in (1, 2, 3, 4, 5, 6, 7):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 9, 10):
         out = ops.linear(eye.cuda(), w.cuda(), None, tile=tile)
         assert torch.equal(out.cpu(), w.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
-def test_gemm_split_a_and_inplace_residual(ops, tile):
-    M, E = 300, 512
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10])
+@pytest.mark.parametrize("M", [300, 5120])
+def test_gemm_split_a_and_inplace_residual(ops, tile, M):
+    E = 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
     out = ops.linear(yq.cuda(), w.cuda(), b.cuda(), x2=y.cuda(), n_split=2 * E, tile=tile)
     ref = torch.cat([yq.double() @ w[: 2 * E].double().t(), y.double() @ w[2 * E:].double().t()], 1) + b.double()
