@@ -6,21 +6,33 @@
 
 Metric (BASELINE.json): decoded edges/s = pointer selections per second on 256-edge wireframes.
 One "step" = one pass of the hot path over one batch per GPU: encoder + all greedy decode steps +
-output packing (+ the RCCL all-gather of the predicted loops when N > 1).  Default workload =
-BASELINE config B: configs/ours.yml with model.num_lines=256, ONE synthetic 256-edge wireframe per
-GPU (F=256 anchor sequences x 36 steps = 9216 selections), default-xavier synthetic weights (never
-stops early), fp32.  `--wireframes-per-gpu 128` gives config C's per-GPU batch.  `--config E` is
-BASELINE config 5: configs/ours-perspective.yml with model.num_lines=1024 and a seed-listed ragged mix
-of 64..1024-edge wireframes (32 per GPU by default = 256 over 8 GPUs).
+output packing (+ the RCCL all-gather of the predicted loops when N > 1).
+
+N = 1 (the headline): BASELINE config 2 ("B"): configs/ours.yml with model.num_lines=256, ONE synthetic 256-edge
+wireframe (F=256 anchor sequences x 36 steps = 9216 selections), default-xavier synthetic weights (never stops early),
+fp32, every product on the f32 matrix cores.  The same run also measures, with a few timed passes each, the other
+BASELINE configurations that fit one GPU and reports them under `other_configs` (each with its own roofline):
+    C128  config 3's per-GPU share: 128 of the 1024 256-edge wireframes                    (configs/ours.yml)
+    E32   config 5's per-GPU share: 32 ragged 64..1024-edge wireframes                     (configs/ours-perspective.yml)
+    D     config 4: seq2seq+coedge.yml, one 216-edge wireframe, extra pointer mask operand (SurfaceFormer, 258 steps)
+    A     config 1's sizes: seq2seq.yml, one 64-edge wireframe                             (SurfaceFormer, 258 steps)
+
+N > 1: BASELINE config 3 itself: every rank decodes its share of the 1024-wireframe batch -- 1024/8 = 128 wireframes per
+GPU (at N < 8 the batch is 128 N wireframes: weak scaling of config 3's per-GPU workload) -- through
+`faceformer_amd.dist.decode_sharded(local_shard=True)`: batch-global F, no local stop, all-reduced stop counters, the
+GLOBAL stop rule, RCCL all-gather of the int32 tokens inside the timed step.  The N = 1 reference of that series is
+`other_configs.C128` of the N = 1 line.  `weak_one_wireframe_per_gpu` carries the one-wireframe-per-GPU line as well.
 
 The JSON line also carries
-  roofline     : the dominant kernel (the f32-MFMA GEMM): algorithmic flops (2MNK summed over its
-                 launches of one step) / its summed duration, measured with HIP events on the launch
-                 stream by the library's profiling hooks, against the 157.3 TF/s f32 matrix peak;
-  cpu_baseline : the CPU oracle (op-for-op restatement of the reference, oracle/refpath.py) timed on the
-                 host's physical cores on ONE FULL wireframe of the workload (all anchor sequences, all
-                 steps); if that does not finish within --cpu-timeout, a 32-anchor sample of the same
-                 wireframe (sequences are independent, so the sample is faithful) -- `sample` says which.
+  roofline     : the dominant kernel family (the f32-MFMA GEMM): algorithmic flops (2MNK summed over its launches of one
+                 step) / its summed duration, measured with HIP events on the launch stream by the library's profiling
+                 hooks, NET of the event bracket (ff_profile_bracket_us: the interval an event pair reports around an
+                 empty kernel), against the 157.3 TF/s f32 matrix peak;
+  cpu_baseline : the CPU oracle (op-for-op restatement of the reference, oracle/refpath.py) timed on the host's physical
+                 cores on ONE FULL wireframe of the workload (all anchor sequences, all steps); if that does not finish
+                 within --cpu-timeout, a 32-anchor sample of the same wireframe (sequences are independent, so the
+                 sample is faithful) -- `sample` says which; `first_divergence` names the first (sequence, step) at
+                 which the GPU's tokens leave the oracle's, with the oracle's own top-2 margin there and the tolerance.
 """
 import argparse
 import ctypes
@@ -35,12 +47,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 E_SIZES, E_PROBS, E_SEED = (64, 128, 256, 512, 1024), (.3, .3, .2, .1, .1), 2024
+CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops"]
 
 
-def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100):
-    """algorithmic flops of one wireframe of the parallel model (F = n sequences)."""
-    S, steps, F = n + 4, T - 1, n
+def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100, F=None):
+    """algorithmic flops of one wireframe (parallel model: F = n sequences; seq2seq: F = 1)."""
+    S, steps = n + 4, T - 1
+    F = n if F is None else F
     st = steps * (steps + 1) // 2
     st2 = steps * (steps + 1) * (2 * steps + 1) // 6
     embed = n * 2 * (in_dim * E + E * E)
@@ -51,6 +66,12 @@ def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100):
     dec_cross = layers * F * 4 * S * E * st
     ptr = F * steps * (2 * E * E + 2 * S * E)
     return embed + enc + cross_kv + dec_lin + dec_self + dec_cross + ptr
+
+
+def decoder_weight_bytes(E=512, FF=1024, layers=6):
+    """fp32 bytes of the decoder stack + project (what a seq2seq decode step streams, SURVEY 8d: 76.8 MB)."""
+    per_layer = 2 * (3 * E * E + 3 * E + E * E + E) + 2 * E * FF + FF + E + 6 * E
+    return 4 * (layers * per_layer + 2 * E + E * E + E)
 
 
 def physical_cores():
@@ -77,6 +98,71 @@ def run_cpu_child(code, timeout, threads):
     return json.loads(cp.stdout.strip().splitlines()[-1])
 
 
+def timed(step_fn, fence, warmup, steps):
+    for _ in range(warmup):
+        step_fn()
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step_fn()
+    fence()
+    return time.perf_counter() - t0, out
+
+
+def profile_once(lib, L, run_once):
+    """One pass under the library's event hooks -> (ms, work, launches, algorithmic bytes) per category."""
+    ncat = len(CAT_NAMES)
+    ms, work, cnt = (ctypes.c_double * ncat)(), (ctypes.c_double * ncat)(), (ctypes.c_longlong * ncat)()
+    torch.cuda.synchronize()
+    lib.ff_profile_begin()
+    run_once()
+    L.check(lib.ff_profile_end(ms, work, cnt, ncat), "ff_profile_end")
+    alg_bytes = (ctypes.c_double * ncat)()
+    L.check(lib.ff_profile_bytes(alg_bytes, ncat), "ff_profile_bytes")
+    return list(ms), list(work), [int(c) for c in cnt], list(alg_bytes)
+
+
+def gemm_roofline(prof, wall_ms, empty_us, traffic=None, traffic_src=None):
+    """`roofline` object of the dominant kernel family from one profiled pass.  The event bracket inflates every measured
+    interval; it is calibrated PER CONFIGURATION as (sum of the bracketed intervals - un-instrumented wall time of one pass)
+    / launches: the decode queue never drains (kernel trace under profiles/), so the kernels' own durations sum to the wall
+    time.  Times reported are net of it; the raw event sums are kept beside them."""
+    ms, work, cnt, alg_bytes = prof
+    nl = max(1, sum(cnt))
+    bracket_us = max(0.0, (sum(ms) - wall_ms) / nl * 1e3)
+    net = [max(0.0, ms[i] - cnt[i] * bracket_us * 1e-3) for i in range(len(ms))]
+    total_net = sum(net)
+    ach = work[0] / (net[0] * 1e-3) / 1e12 if net[0] > 0 else 0.0
+    ach_gross = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+    roof = {
+        "kernel": "f32-MFMA GEMM (ff_gemm.hip; all launch shapes of one tiling family)",
+        "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+        "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+        "alg_bytes_per_launch": alg_bytes[0] / max(1, cnt[0]), "launches_per_step": cnt[0],
+        "avg_launch_us": 1e3 * net[0] / max(1, cnt[0]), "alg_flop_per_launch": work[0] / max(1, cnt[0]),
+        "share_of_kernel_time": net[0] / total_net if total_net > 0 else None,
+        "event_bracket_us_per_launch": bracket_us, "event_interval_of_an_empty_kernel_us": empty_us,
+        "achieved_with_bracket": ach_gross, "frac_with_bracket": ach_gross / PEAK_F32_MFMA_TFLOPS,
+        "note": "achieved / avg_launch_us are NET of the event bracket = (sum of bracketed intervals - un-instrumented pass time) / "
+                "launches of this configuration (the queue never drains, so kernel durations sum to the pass time); "
+                "*_with_bracket are the raw event sums; the rocprofv3 kernel trace under profiles/ is the bracket-free figure",
+    }
+    extra = {
+        "kernel_time_ms_per_step": {CAT_NAMES[i]: net[i] for i in range(len(ms))},
+        "kernel_time_ms_per_step_with_bracket": {CAT_NAMES[i]: ms[i] for i in range(len(ms))},
+        "kernel_launches_per_step": {CAT_NAMES[i]: cnt[i] for i in range(len(ms))},
+    }
+    if net[1] > 0:
+        extra["attention_tflops"] = work[1] / (net[1] * 1e-3) / 1e12
+    return roof, extra
+
+
+def path_roofline(falg, sec_per_step):
+    return {"alg_tflop_per_gpu_step": falg / 1e12, "achieved_tflops_per_gpu": falg / sec_per_step / 1e12,
+            "frac_of_f32_mfma_peak": falg / sec_per_step / 1e12 / PEAK_F32_MFMA_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,7 +171,8 @@ def main():
     ap.add_argument("--config", default="B", choices=["B", "E"],
                     help="B: 256-edge wireframes (BASELINE configs 2/3, the headline); E: ours-perspective.yml with "
                          "num_lines=1024, ragged 64..1024-edge wireframes (BASELINE config 5)")
-    ap.add_argument("--wireframes-per-gpu", type=int, default=0, help="0 = 1 (config B) / 32 (config E)")
+    ap.add_argument("--wireframes-per-gpu", type=int, default=0,
+                    help="0 = 1 (config B at N = 1) / 128 (config B at N > 1: config 3's share) / 32 (config E)")
     ap.add_argument("--edges", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=16, help="wireframes per micro-batch (0 = all)")
     ap.add_argument("--chunk-max-seqs", type=int, default=8192, help="sequences per micro-batch of several wireframes")
@@ -107,6 +194,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-x3-line", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C128 / E32 / D / A lines of the N = 1 run")
+    ap.add_argument("--other-steps", type=int, default=2, help="timed passes of each `other_configs` entry")
+    ap.add_argument("--plain-multi", action="store_true",
+                    help="N > 1: time the plain per-rank model(batch) + all-gather (the round-2 form) instead of decode_sharded")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,36 +216,62 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from faceformer_amd.config import load_cfg
-    from faceformer_amd.dist import gather_predictions
+    from faceformer_amd.dist import decode_sharded, gather_predictions
     from faceformer_amd.hip import lib as L
-    from faceformer_amd.hip.engine import DEFAULT_FLAGS
-    from faceformer_amd.models import SurfaceFormer_Parallel
-    from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec
-
-    cfgE = args.config == "E"
-    W = args.wireframes_per_gpu or (32 if cfgE else 1)
-    L_lines = 1024 if cfgE else args.edges
-    cfg = load_cfg(os.path.join(ROOT, "configs", "ours-perspective.yml" if cfgE else "ours.yml"),
-                   ["model.num_lines", str(L_lines)])
-    T = cfg.model.max_face_length
-    model = SurfaceFormer_Parallel(**cfg.model)
-    spec = state_dict_spec("parallel", L_lines, T, cfg.model.num_model, cfg.model.num_feedforward,
-                           cfg.model.num_encoder_layers, cfg.model.num_decoder_layers)
-    sd = make_state_dict(spec, "default", 0)
-    model.load_state_dict(sd)
-    model = model.eval().to(dev)
-    model.chunk_wireframes, model.chunk_max_seqs = args.chunk, args.chunk_max_seqs
-    model.chunk_seqs, model.num_streams = args.chunk_seqs, args.streams
-    model.sync_every = args.sync_every
-    model.x3_min_rows = args.x3_min_rows
-    if args.no_dedup:
-        model.decode_flags = model.decode_flags & ~L.FF_DEDUP_PAD_ANCHORS
-    if args.no_fuse_ln:
-        model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
     from faceformer_amd.hip import ops as _ops
+    from faceformer_amd.models import SurfaceFormer, SurfaceFormer_Parallel
+    from faceformer_amd.synth import make_extra_mask, make_state_dict, make_wireframes, state_dict_spec
+
+    lib = L.load()
     _ops.set_attention_algo(args.attn_algo)
     if args.gemm_tuning:
         _ops.set_gemm_tuning(*[int(v) for v in args.gemm_tuning.split(",")])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def to_dev(b):
+        return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+    def parallel_model(cfg_file, L_lines, recipe="default", wseed=0):
+        cfg = load_cfg(os.path.join(ROOT, "configs", cfg_file), ["model.num_lines", str(L_lines)])
+        T = cfg.model.max_face_length
+        model = SurfaceFormer_Parallel(**cfg.model)
+        spec = state_dict_spec("parallel", L_lines, T, cfg.model.num_model, cfg.model.num_feedforward,
+                               cfg.model.num_encoder_layers, cfg.model.num_decoder_layers)
+        model.load_state_dict(make_state_dict(spec, recipe, wseed))
+        model = model.eval().to(dev)
+        model.chunk_wireframes, model.chunk_max_seqs = args.chunk, args.chunk_max_seqs
+        model.chunk_seqs, model.num_streams = args.chunk_seqs, args.streams
+        model.sync_every = args.sync_every
+        model.x3_min_rows = args.x3_min_rows
+        if args.no_dedup:
+            model.decode_flags = model.decode_flags & ~L.FF_DEDUP_PAD_ANCHORS
+        if args.no_fuse_ln:
+            model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
+        return model, cfg, T
+
+    def steps_executed(pred):   # pred [N, F, T] or [N, T]
+        p = pred.reshape(-1, pred.size(-1))
+        nz = (p[:, 1:] != 0).any(dim=0)
+        return int(nz.nonzero().max().item()) + 1 if bool(nz.any()) else 0
+
+    bracket_us = 0.0
+    if rank == 0 and not args.no_roofline:
+        b = ctypes.c_double(0.0)
+        L.check(lib.ff_profile_bracket_us(512, ctypes.byref(b), torch.cuda.current_stream().cuda_stream), "ff_profile_bracket_us")
+        bracket_us = float(b.value)
+
+    # ================================================================================================================
+    # main line
+    # ================================================================================================================
+    cfgE = args.config == "E"
+    sharded_c = world > 1 and not cfgE and not args.plain_multi
+    W = args.wireframes_per_gpu or (32 if cfgE else (min(128, max(1, 1024 // world)) if sharded_c else 1))
+    L_lines = 1024 if cfgE else args.edges
+    model, cfg, T = parallel_model("ours-perspective.yml" if cfgE else "ours.yml", L_lines)
     seeds = [rank * W + i for i in range(W)]
     if cfgE:
         all_n = config_e_edge_counts(world * W)
@@ -162,11 +279,10 @@ def main():
     else:
         all_n = [args.edges] * (world * W)
         n_local = [args.edges] * W
-    batch_cpu = make_wireframes(n_local, L_lines, T, "parallel", seeds=seeds)
-    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
+    batch = to_dev(make_wireframes(n_local, L_lines, T, "parallel", seeds=seeds))
     F_local = max(n_local)
 
-    def step():
+    def step_plain():
         with torch.no_grad():
             out = model(dict(batch))
         pred = out["predict"]
@@ -177,19 +293,12 @@ def main():
             pred = gather_predictions(pred, dist)
         return pred
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step_sharded():   # every rank holds ONLY its own wireframes; result = the whole batch on every rank
+        with torch.no_grad():
+            return decode_sharded(model, dict(batch), dist, local_shard=True)["predict"]
 
-    for _ in range(args.warmup):
-        pred = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pred = step()
-    fence()
-    dt = time.perf_counter() - t0
+    step = step_sharded if (world > 1 and not args.plain_multi) else step_plain
+    dt, pred = timed(step, fence, args.warmup, args.steps)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -197,8 +306,7 @@ def main():
 
     # decode steps actually executed (the reference semantics run T-1 with these weights)
     local = pred[rank * W:(rank + 1) * W] if world > 1 else pred
-    nz = (local[:, :, 1:] != 0).any(dim=1).any(dim=0)
-    steps_done = int(nz.nonzero().max().item()) + 1 if bool(nz.any()) else 0
+    steps_done = steps_executed(local)
     # decoded edges = pointer selections of the REAL anchor sequences (n_w per wireframe); the reference
     # additionally decodes F - n_w identical padding-anchor rows per wireframe, reported separately
     sel_per_step = sum(all_n) * steps_done
@@ -207,11 +315,18 @@ def main():
 
     if cfgE:
         hist = {str(k): all_n.count(k) for k in E_SIZES}
-        workload = ("configs/ours-perspective.yml model.num_lines=1024: %d synthetic wireframes per GPU with edge counts "
-                    "drawn from %s p=%s (numpy default_rng(%d); this run: %s), F=max n anchor rows per wireframe x %d greedy "
+        workload = ("BASELINE config 5: configs/ours-perspective.yml model.num_lines=1024: %d synthetic wireframes per GPU with edge "
+                    "counts drawn from %s p=%s (numpy default_rng(%d); this run: %s), F=max n anchor rows per wireframe x %d greedy "
                     "steps, default-xavier synthetic weights" % (W, list(E_SIZES), list(E_PROBS), E_SEED, hist, steps_done))
+    elif sharded_c:
+        workload = ("BASELINE config 3: configs/ours.yml model.num_lines=%d, synthetic %d-edge wireframes sharded by wireframe: "
+                    "%d per GPU x %d GPUs = %d in the batch (config 3 is 1024 over 8 GPUs = 128 per GPU; this series keeps 128 per "
+                    "GPU), F=%d anchor sequences x %d greedy steps each, default-xavier synthetic weights; every rank passes only "
+                    "its own wireframes to dist.decode_sharded(local_shard=True): batch-global F, all-reduced stop counters, global "
+                    "stop rule, RCCL all-gather of the int32 tokens inside the timed step"
+                    % (args.edges, args.edges, W, world, W * world, args.edges, steps_done))
     else:
-        workload = ("configs/ours.yml model.num_lines=%d: %d synthetic %d-edge wireframe(s) per GPU, "
+        workload = ("BASELINE config 2: configs/ours.yml model.num_lines=%d: %d synthetic %d-edge wireframe(s) per GPU, "
                     "F=%d anchor sequences x %d greedy steps, default-xavier synthetic weights"
                     % (args.edges, W, args.edges, args.edges, steps_done))
     result = {
@@ -224,7 +339,14 @@ def main():
                    "max_face_length": T, "decode_steps": steps_done,
                    "parallelism": "wireframe-sharded x%d, RCCL all-gather of predictions" % world},
         "wireframes_per_s": world * W * args.steps / dt,
+        "ms_per_wireframe_per_gpu": 1e3 * dt / args.steps / W,
     }
+    if sharded_c:
+        result["scaling_series"] = {
+            "per_gpu_workload": "%d wireframes of %d edges (config 3's per-GPU share)" % (W, args.edges),
+            "n1_reference": "other_configs.C128 of the N = 1 line (same per-GPU workload on one GPU, no collective)",
+            "note": "the N = 1 line's own `value` is BASELINE config 2 (ONE wireframe per call), a different workload: a batch of "
+                    "128 wireframes fills the per-kernel latency of the single-wireframe decode (DESIGN.md 5)"}
     if cfgE:
         rows = W * F_local
         result["sequence_rows"] = {
@@ -234,21 +356,28 @@ def main():
             "note": "rows f >= n_w of a wireframe are identical padding-anchor sequences (reference model_para.py:204-205); "
                     "one is decoded per wireframe and copied"}
     falg = sum(alg_flops_per_wireframe(n, T) for n in n_local)
-    result["path_roofline"] = {"alg_tflop_per_gpu_step": falg / 1e12,
-                               "achieved_tflops_per_gpu": falg * args.steps / dt / 1e12,
-                               "frac_of_f32_mfma_peak": falg * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    result["path_roofline"] = path_roofline(falg, dt / args.steps)
+
+    if world > 1 and sharded_c:
+        # the one-wireframe-per-GPU weak line (what N = 1 measures as its headline), plain model(batch) + all-gather
+        one = to_dev(make_wireframes([args.edges], L_lines, T, "parallel", seeds=[rank]))
+
+        def step_one():
+            with torch.no_grad():
+                return gather_predictions(model(dict(one))["predict"], dist)
+        dt1, p1 = timed(step_one, fence, 1, 3)
+        tt = torch.tensor([dt1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt1 = float(tt.item())
+        result["weak_one_wireframe_per_gpu"] = {
+            "value": world * args.edges * steps_executed(p1[rank:rank + 1]) * 3 / dt1, "unit": "edges/s", "ms_per_step": 1e3 * dt1 / 3,
+            "steps": 3, "warmup": 1, "workload": "ONE %d-edge wireframe per GPU (BASELINE config 2 on every GPU), local stop rule, "
+                                                 "all-gather of the predictions" % args.edges}
 
     if world == 1 and args.x3_min_rows == 0 and not args.no_x3_line:
         # second line: the package default (large decoder projections as fp32-accurate 3 x bf16 products)
         model.x3_min_rows = 4096
-        for _ in range(max(1, args.warmup)):
-            step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt3 = time.perf_counter() - t1
+        dt3, _ = timed(step, fence, max(1, args.warmup), args.steps)
         model.x3_min_rows = 0
         step()      # (re-binds the engine without the bf16 planes for the profiling leg below)
         fence()
@@ -259,19 +388,10 @@ def main():
                     "1.5x / 2x / 4x that) as 3 x bf16 split products on the bf16 matrix cores, fp32-accurate; NOT the headline"}
 
     if rank == 0 and not args.no_roofline:
-        lib = L.load()
-        ncat = 5
-        ms, work, cnt = (ctypes.c_double * ncat)(), (ctypes.c_double * ncat)(), (ctypes.c_longlong * ncat)()
-        torch.cuda.synchronize()
-        lib.ff_profile_begin()
-        with torch.no_grad():
-            model(dict(batch))
-        L.check(lib.ff_profile_end(ms, work, cnt, ncat), "ff_profile_end")
-        alg_bytes = (ctypes.c_double * ncat)()
-        L.check(lib.ff_profile_bytes(alg_bytes, ncat), "ff_profile_bytes")
-        names = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops"]
-        total_ms = sum(ms)
-        ach = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        def once():
+            with torch.no_grad():
+                model(dict(batch))
+        prof = profile_once(lib, L, once)
         # HBM bytes per launch of the dominant kernel come from the committed PMC passes
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 fetch correction):
         # bench.py cannot run the profiler around itself.
@@ -282,20 +402,101 @@ def main():
             with open(cands[-1]) as f:
                 tj = json.load(f)
             traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
-        result["roofline"] = {
-            "kernel": "f32-MFMA GEMM (ff_gemm.hip; all launch shapes of one tiling family)",
-            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-            "alg_bytes_per_launch": alg_bytes[0] / max(1, cnt[0]),
-            "launches_per_step": int(cnt[0]), "avg_launch_us": 1e3 * ms[0] / max(1, cnt[0]),
-            "alg_flop_per_launch": work[0] / max(1, cnt[0]),
-            "share_of_kernel_time": ms[0] / total_ms if total_ms > 0 else None,
-        }
-        result["kernel_time_ms_per_step"] = {names[i]: ms[i] for i in range(ncat)}
-        result["kernel_launches_per_step"] = {names[i]: int(cnt[i]) for i in range(ncat)}
-        if ms[1] > 0:
-            result["attention_tflops"] = work[1] / (ms[1] * 1e-3) / 1e12
+        result["roofline"], extra = gemm_roofline(prof, 1e3 * dt / args.steps, bracket_us, traffic, traffic_src)
+        result.update(extra)
+
+    # ================================================================================================================
+    # N = 1: the other BASELINE configurations in the same run (a few timed passes each)
+    # ================================================================================================================
+    if world == 1 and not cfgE and W == 1 and not args.no_other_configs:
+        other = {}
+        K2 = max(1, args.other_steps)
+
+        def par_entry(name, m2, b2, n2, T2, what):
+            def st():
+                with torch.no_grad():
+                    return m2(dict(b2))["predict"]
+            d2, p2 = timed(st, fence, 1, K2)
+            sd2 = steps_executed(p2)
+            ent = {"workload": what, "value": sum(n2) * sd2 * K2 / d2, "unit": "edges/s", "ms_per_step": 1e3 * d2 / K2,
+                   "ms_per_wireframe": 1e3 * d2 / K2 / len(n2), "wireframes_per_s": len(n2) * K2 / d2, "steps": K2, "warmup": 1,
+                   "decode_steps": sd2, "dtype": "f32",
+                   "path_roofline": path_roofline(sum(alg_flops_per_wireframe(n, T2) for n in n2), d2 / K2)}
+            if not args.no_roofline:
+                roof, ex = gemm_roofline(profile_once(lib, L, st), 1e3 * d2 / K2, bracket_us)
+                ent["roofline"] = roof
+                ent.update(ex)
+            if not args.no_x3_line:
+                m2.x3_min_rows = 4096
+                d3, _ = timed(st, fence, 1, K2)
+                m2.x3_min_rows = 0
+                ent["bf16x3_projections"] = {"value": sum(n2) * sd2 * K2 / d3, "unit": "edges/s", "ms_per_step": 1e3 * d3 / K2,
+                                             "note": "package default (x3_min_rows = 4096), fp32-accurate; not the headline form"}
+            other[name] = ent
+
+        # C128: config 3's per-GPU share on this GPU (the model of the main line, a batch of 128 wireframes)
+        bC = to_dev(make_wireframes([args.edges] * 128, L_lines, T, "parallel", seeds=list(range(128))))
+        par_entry("C128", model, bC, [args.edges] * 128, T,
+                  "BASELINE config 3's per-GPU share: 128 synthetic %d-edge wireframes in one call (configs/ours.yml, "
+                  "model.num_lines=%d), micro-batches of %d wireframes, default-xavier weights" % (args.edges, L_lines, args.chunk))
+        del bC
+        # E32: config 5's per-GPU share
+        mE, cE, TE = parallel_model("ours-perspective.yml", 1024)
+        nE = config_e_edge_counts(8 * 32)[:32]
+        bE = to_dev(make_wireframes(nE, 1024, TE, "parallel", seeds=list(range(32))))
+        par_entry("E32", mE, bE, nE, TE,
+                  "BASELINE config 5's per-GPU share: 32 ragged wireframes, edge counts %s (configs/ours-perspective.yml, "
+                  "model.num_lines=1024, max_face_length %d), padding anchors de-duplicated, width-bucketed micro-batches"
+                  % ({str(k): nE.count(k) for k in E_SIZES}, TE))
+        other["E32"]["decoded_sequences"] = (getattr(mE, "last_decode_stats", None) or {}).get("decoded_seqs")
+        del mE, bE
+
+        # D / A: the single-sequence model (SurfaceFormer), one wireframe, 258 steps with the gain-4 parity weights
+        wbytes = decoder_weight_bytes()
+        for name, cfg_file, n1, wseed, wfseed, mask_seed, what in (
+                ("D", "seq2seq+coedge.yml", 216, 1, 5, 11,
+                 "BASELINE config 4: configs/seq2seq+coedge.yml (num_lines 216, label_seq_length 259), one 216-edge synthetic "
+                 "wireframe, extra pointer mask (co-edge style, ~20 %% of the edges) OR-ed into the padding mask inside the pointer "
+                 "kernel, gain-4 synthetic weights (the weights / wireframe / mask of golden seq_full_D216_extramask)"),
+                ("A", "seq2seq.yml", 64, 0, 3, None,
+                 "BASELINE config 1's sizes on the GPU: configs/seq2seq.yml (num_lines 110, label_seq_length 259), one 64-edge "
+                 "synthetic wireframe, gain-4 synthetic weights (golden seq_full_A64_gain4)")):
+            c1 = load_cfg(os.path.join(ROOT, "configs", cfg_file))
+            L1, T1 = c1.model.num_lines, c1.model.label_seq_length
+            m1 = SurfaceFormer(**c1.model)
+            m1.load_state_dict(make_state_dict(state_dict_spec("seq2seq", L1, T1), "gain4", wseed))
+            m1 = m1.eval().to(dev)
+            m1.x3_min_rows = 0
+            b1 = make_wireframes([n1], L1, T1, "seq2seq", seeds=[wfseed])
+            if mask_seed is not None:
+                b1["extra_mask"] = make_extra_mask(dict(kind="seq2seq", extra_mask_seed=mask_seed), b1)
+            b1 = to_dev(b1)
+
+            def st1():
+                with torch.no_grad():
+                    return m1(dict(b1))["predict"]
+            K1 = max(3, K2)
+            d1, p1 = timed(st1, fence, 1, K1)
+            sd1 = steps_executed(p1)
+            sec = d1 / K1
+            fa = alg_flops_per_wireframe(n1, T1, F=1)
+            ent = {"workload": what, "value": sd1 / sec, "unit": "edges/s", "ms_per_step": 1e3 * sec, "ms_per_wireframe": 1e3 * sec,
+                   "steps": K1, "warmup": 1, "decode_steps": sd1, "dtype": "f32", "path_roofline": path_roofline(fa, sec),
+                   "bounds": {
+                       "mfma": {"alg_tflop": fa / 1e12, "bound_ms": 1e3 * fa / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                                "frac": fa / (PEAK_F32_MFMA_TFLOPS * 1e12) / sec},
+                       "weight_stream": {"bytes_per_wireframe": sd1 * wbytes, "bound_ms": 1e3 * sd1 * wbytes / (PEAK_HBM_TBS * 1e12),
+                                         "frac": sd1 * wbytes / (PEAK_HBM_TBS * 1e12) / sec,
+                                         "note": "decoder + project weights (%.1f MB fp32) streamed once per decode step at the %.0f TB/s "
+                                                 "HBM rate (SURVEY 8d; they also fit the 256 MB Infinity Cache)" % (wbytes / 1e6, PEAK_HBM_TBS)}}}
+            if not args.no_roofline:
+                roof, ex = gemm_roofline(profile_once(lib, L, st1), 1e3 * sec, bracket_us)
+                ent["roofline"] = roof
+                ent.update(ex)
+                ent["launches_per_decode_step"] = sum(ex["kernel_launches_per_step"].values()) / max(1, sd1)
+            other[name] = ent
+            del m1, b1
+        result["other_configs"] = other
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The oracle runs in a child process with a hard wall-clock cap.  Threads = the host's physical cores
@@ -320,10 +521,16 @@ def main():
                 "spec = state_dict_spec('parallel', %d, %d, %d, %d, %d, %d)\n"
                 "sd = make_state_dict(spec, 'default', 0)\n"
                 "one = make_wireframes(%d, %d, %d, 'parallel', seeds=[%d])\n"
+                "trace = {}\n"
                 "t0 = time.perf_counter()\n"
-                "ref = refpath.parallel_forward_eval(sd, one, num_head=%d, anchor_limit=%s)\n"
+                "ref = refpath.parallel_forward_eval(sd, one, num_head=%d, anchor_limit=%s, trace=trace)\n"
                 "tc = time.perf_counter() - t0\n"
-                "print(json.dumps({'t': tc, 'predict': ref['predict'][0].tolist()}))\n"
+                "lg = torch.stack(trace['logits'])\n"                       # steps x B x S masked logits of the oracle
+                "v = torch.sort(lg, dim=2, descending=True).values\n"
+                "live = lg > torch.finfo(torch.float32).min\n"
+                "scale = (lg.abs() * live).amax(dim=(1, 2))\n"
+                "print(json.dumps({'t': tc, 'predict': ref['predict'][0].tolist(), 'margin': (v[:, :, 0] - v[:, :, 1]).tolist(), "
+                "'scale': scale.tolist()}))\n"
                 % (ROOT, threads, L_lines, T, cfg.model.num_model, cfg.model.num_feedforward,
                    cfg.model.num_encoder_layers, cfg.model.num_decoder_layers, n_cpu, L_lines, T, seed_cpu,
                    cfg.model.num_head, "None" if k >= n_cpu else str(k)))
@@ -343,9 +550,19 @@ def main():
             # default-init weights give the reference EXACT logit ties in a few sequences (tests/golden:
             # 174 of 9216 selections); a tie may legitimately resolve differently under another fp32
             # summation order, after which that sequence's later tokens differ too
-            eq = (ref_pred[:k].to(dev) == wf_local[:k])
+            eq = (ref_pred[:k].to(dev) == wf_local[:k]).cpu()
             same = bool(eq.all())
             seq_same = float(eq.all(dim=1).float().mean())
+            # where the GPU's tokens first leave the oracle's: (sequence, step), the ORACLE's own top-2 margin there and
+            # the parity tolerance of that step (tests/test_parity_golden.py: 1e-3 * max(1, max|logit| / 40))
+            div = []
+            for s_ in (~eq.all(dim=1)).nonzero().flatten().tolist():
+                j = int((~eq[s_]).nonzero().min().item())            # token index; decode step = j - 1
+                step_ = j - 1
+                tol = 1e-3 * max(1.0, rec["scale"][step_] / 40.0)
+                div.append({"seq": s_, "step": step_, "ref_margin": rec["margin"][step_][s_], "tol": tol,
+                            "ref_token": int(ref_pred[s_, j]), "gpu_token": int(wf_local[s_, j])})
+            div.sort(key=lambda d: (d["step"], d["seq"]))
             what = ("all %d anchor sequences" % k) if k >= n_cpu else ("first %d of %d anchor sequences" % (k, n_cpu))
             result["cpu_baseline"] = {
                 "value": k * ref_steps / tc, "unit": "edges/s", "cores": threads, "kind": "port",
@@ -354,6 +571,13 @@ def main():
                           % (what, n_cpu, ref_steps, torch.__version__, threads, phys, os.cpu_count() or 1, tc,
                              ("; earlier attempts: " + "; ".join(tried)) if tried else ""),
                 "parallel_info": pinfo, "tokens_identical_to_gpu": same, "sequences_identical_to_gpu": seq_same,
+                "divergent_sequences": len(div),
+                "first_divergence": div[0] if div else None,
+                "every_first_divergence_within_2tol_of_a_tie": all(d["ref_margin"] <= 2 * d["tol"] for d in div),
+                "first_divergences": div[:8],
+                "note": "a sequence may leave the oracle's tokens only where the oracle's own top-2 margin is below the parity "
+                        "tolerance (an exact or near tie resolved under another fp32 summation order); the parity tests require "
+                        "equality wherever the margin exceeds 2 x tol",
             }
             result["speedup_vs_cpu"] = value / result["cpu_baseline"]["value"]
             break
@@ -368,7 +592,7 @@ def main():
                 "torch.set_num_threads(%d)\n"
                 "from oracle import refpath\n"
                 "from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec\n"
-                "sd = make_state_dict(state_dict_spec('seq2seq', 110, 259), 'default', 0)\n"
+                "sd = make_state_dict(state_dict_spec('seq2seq', 110, 259), 'gain4', 0)\n"
                 "one = make_wireframes(64, 110, 259, 'seq2seq', seeds=[3])\n"
                 "t0 = time.perf_counter()\n"
                 "ref = refpath.seq2seq_forward_eval(sd, one, num_head=8)\n"
@@ -379,8 +603,8 @@ def main():
                 rec = run_cpu_child(code_a, 120, min(threads, 8))
                 result["cpu_baseline_config_a"] = {
                     "value": rec["steps"] / rec["t"], "unit": "edges/s", "cores": min(threads, 8), "kind": "port",
-                    "sample": "configs/seq2seq.yml sizes (L=110, T=259), one 64-edge wireframe, all %d executed steps: %.1f s"
-                              % (rec["steps"], rec["t"])}
+                    "sample": "configs/seq2seq.yml sizes (L=110, T=259), one 64-edge wireframe, gain-4 weights (the workload of "
+                              "other_configs.A), all %d executed steps: %.1f s" % (rec["steps"], rec["t"])}
             except (subprocess.TimeoutExpired, ValueError, IndexError):
                 pass
 

@@ -16,7 +16,9 @@ from .config import CfgNode
 __all__ = ["load_lightning_checkpoint", "model_from_checkpoint", "strip_prefix"]
 
 _CFG_CLASSES = {("fvcore.common.config", "CfgNode"), ("yacs.config", "CfgNode"),
-                ("detectron2.config.config", "CfgNode")}
+                ("detectron2.config.config", "CfgNode"),
+                # checkpoints written with THIS package's own node (or through the `faceformer` alias package)
+                ("faceformer_amd.config", "CfgNode"), ("faceformer.config", "CfgNode")}
 
 
 class _Inert(dict):
@@ -34,6 +36,12 @@ _BUILTINS_OK = {"dict", "list", "set", "frozenset", "tuple", "int", "float", "co
                 "bool", "slice", "range", "object"}
 _GLOBALS_OK = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "deque"),
                ("_codecs", "encode"), ("argparse", "Namespace"), ("copyreg", "_reconstructor")}
+
+
+# numpy: exactly what an ndarray / numpy scalar pickle needs (both module spellings of numpy 1.x / 2.x) -- not the
+# rest of numpy.core.multiarray (fromfile, frombuffer, copyto, ... are callables a crafted pickle could drive)
+_NUMPY_OK = {(m, n) for m in ("numpy.core.multiarray", "numpy._core.multiarray") for n in ("_reconstruct", "scalar")} | \
+            {("numpy", "ndarray"), ("numpy", "dtype")}
 
 
 def _torch_global_ok(obj):
@@ -67,13 +75,11 @@ class _Unpickler(pickle.Unpickler):
             except (ImportError, AttributeError):
                 return _Inert
             return obj if _torch_global_ok(obj) else _Inert
-        if top == "numpy":
-            if name in ("_reconstruct", "ndarray", "dtype", "scalar") or module.endswith("multiarray"):
-                try:
-                    return super().find_class(module, name)
-                except (ImportError, AttributeError):
-                    return _Inert
-            return _Inert
+        if (module, name) in _NUMPY_OK:
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return _Inert
         return _Inert
 
 

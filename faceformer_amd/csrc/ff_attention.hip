@@ -16,6 +16,8 @@
 // a query; they exchange only the tile max (one __shfl_xor 32) and add their partial sums at the end.
 #include <math.h>
 
+#include <atomic>
+
 #include "ff_common.h"
 
 namespace {
@@ -959,14 +961,14 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   //  from t = 8, never for the single-sequence decode, whose 8 pairs have at most 9 query tiles each)
   const bool resident_ok = d.nk <= RK_KEYS && d.nk > 0;
   if (g_attention_algo == 3 ? resident_ok : (g_attention_algo == 0 && resident_ok && qt32 >= 4 && gh * qt32 >= 512)) {
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16] = {};   // idempotent per-device attribute; host threads may race here
     int dev = 0;
     FF_CHECK_HIP(hipGetDevice(&dev));
     constexpr int lds_bytes = RK_LDS_FLOATS * (int)sizeof(float);
-    if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+    if (dev < 0 || dev >= 16 || !attr_done[dev].load(std::memory_order_acquire)) {
       FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_resident_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      if (dev >= 0 && dev < 16) attr_done[dev] = true;
+      if (dev >= 0 && dev < 16) attr_done[dev].store(true, std::memory_order_release);
     }
     const int P = (int)gh;
     int c = P <= 256 ? 256 / P : 1;

@@ -720,36 +720,49 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     }
   }
 
-  hipLaunchKernelGGL(steps_kernel, dim3(1), dim3(64), 0, main_st, buf.cnt_ge, buf.cnt_eq, p->variant, N, enq,
-                     (p->flags & FF_NO_STOP) ? 1 : 0, buf.steps_dev);
-  FF_CHECK_LAUNCH();
-  for (const Chunk& c : chunks) {
-    const long total = (long)c.nw * F * T;
-    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    hipLaunchKernelGGL(finalize_chunk_kernel, dim3(grid), dim3(256), 0, main_st, buf.tok_all, Btot, T, buf.steps_dev,
-                       num_input, dedup ? 1 : 0, F, c.w0, c.nw, c.Fc, c.f0, c.b0, predict, seq_of_row);
+  // Everything after the greedy loop (stop step, packing, the optional return-pointer pass) enqueues work that reads the
+  // caller's workspace as well: same rule as above -- on any failure the streams are drained before the error goes back.
+  auto finish = [&]() -> int {
+    hipLaunchKernelGGL(steps_kernel, dim3(1), dim3(64), 0, main_st, buf.cnt_ge, buf.cnt_eq, p->variant, N, enq,
+                       (p->flags & FF_NO_STOP) ? 1 : 0, buf.steps_dev);
     FF_CHECK_LAUNCH();
-  }
-  int steps = 0;
-  FF_CHECK_HIP(hipMemcpyAsync(&steps, buf.steps_dev, sizeof(int), hipMemcpyDeviceToHost, main_st));
-  if (step_counts && enq > 0)
-    FF_CHECK_HIP(hipMemcpyAsync(step_counts, (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
-                                sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
-  FF_CHECK_HIP(hipStreamSynchronize(main_st));
-  if (steps_done) *steps_done = steps;
-
-  // ---- optional: project(decoder(...)) of every prefix row at the last executed step
-  //      (SurfaceFormer returns it as inputs['pointer'], reference model.py:217) --------------------
-  if ((p->flags & FF_RETURN_POINTER) && steps > 0) {
-    FF_CHECK_ARG(m->FF >= m->E, "ff_decode: FF_RETURN_POINTER needs FF >= E");
-    FF_CHECK_ARG(Btot == N * F, "ff_decode: FF_RETURN_POINTER is not available with de-duplicated sequences");
     for (const Chunk& c : chunks) {
-      const Scratch& sc = buf.scr[0];
-      float* proj_all = sc.h;  // [steps*Bc, E] fits in the FF-wide scratch
-      FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, steps, true, proj_all, main_st));
-      for (int j = 0; j < steps; ++j)
-        FF_CHECK_HIP(hipMemcpyAsync(pointer_out + ((size_t)j * Btot + c.b0) * E, proj_all + (size_t)j * c.Bc * E,
-                                    sizeof(float) * c.Bc * E, hipMemcpyDeviceToDevice, main_st));
+      const long total = (long)c.nw * F * T;
+      const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+      hipLaunchKernelGGL(finalize_chunk_kernel, dim3(grid), dim3(256), 0, main_st, buf.tok_all, Btot, T, buf.steps_dev,
+                         num_input, dedup ? 1 : 0, F, c.w0, c.nw, c.Fc, c.f0, c.b0, predict, seq_of_row);
+      FF_CHECK_LAUNCH();
+    }
+    int steps = 0;
+    FF_CHECK_HIP(hipMemcpyAsync(&steps, buf.steps_dev, sizeof(int), hipMemcpyDeviceToHost, main_st));
+    if (step_counts && enq > 0)
+      FF_CHECK_HIP(hipMemcpyAsync(step_counts, (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
+                                  sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+    FF_CHECK_HIP(hipStreamSynchronize(main_st));
+    if (steps_done) *steps_done = steps;
+
+    // ---- optional: project(decoder(...)) of every prefix row at the last executed step
+    //      (SurfaceFormer returns it as inputs['pointer'], reference model.py:217) --------------------
+    if ((p->flags & FF_RETURN_POINTER) && steps > 0) {
+      FF_CHECK_ARG(m->FF >= m->E, "ff_decode: FF_RETURN_POINTER needs FF >= E");
+      FF_CHECK_ARG(Btot == N * F, "ff_decode: FF_RETURN_POINTER is not available with de-duplicated sequences");
+      for (const Chunk& c : chunks) {
+        const Scratch& sc = buf.scr[0];
+        float* proj_all = sc.h;  // [steps*Bc, E] fits in the FF-wide scratch
+        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, steps, true, proj_all, main_st));
+        for (int j = 0; j < steps; ++j)
+          FF_CHECK_HIP(hipMemcpyAsync(pointer_out + ((size_t)j * Btot + c.b0) * E, proj_all + (size_t)j * c.Bc * E,
+                                      sizeof(float) * c.Bc * E, hipMemcpyDeviceToDevice, main_st));
+      }
+    }
+    return FF_OK;
+  };
+  {
+    const int rc = finish();
+    if (rc != FF_OK) {
+      for (int s = 0; s < ns; ++s) (void)hipStreamSynchronize(sts[s]);
+      (void)hipStreamSynchronize(main_st);
+      return rc;
     }
   }
   return FF_OK;

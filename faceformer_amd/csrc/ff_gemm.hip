@@ -25,6 +25,7 @@
 // CU; wave-private tiles (no barrier, 2x the L2 traffic) and in-block split-K lost; barriers and the
 // phase of co-resident blocks do not matter; unpadded XOR-swizzled LDS rows (48 KB per block) with THREE
 // blocks per CU instead of two: 116.6 vs 115.4 TF/s at 8192x1536x512 -- occupancy is not the limit.
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -1012,16 +1013,16 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
 
 // hipFuncSetAttribute is per device: one flag per (kernel, device)
 constexpr int FF_MAX_DEV = 16;
-struct AttrFlags { bool done[FF_MAX_DEV]; };
+struct AttrFlags { std::atomic<bool> done[FF_MAX_DEV]; };   // idempotent attribute: host threads may race here
 template <typename K>
 int set_lds_limit(K kernel, int bytes, AttrFlags* fl) {
   int dev = 0;
   FF_CHECK_HIP(hipGetDevice(&dev));
   const bool track = dev >= 0 && dev < FF_MAX_DEV;
-  if (!track || !fl->done[dev]) {
+  if (!track || !fl->done[dev].load(std::memory_order_acquire)) {
     FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    if (track) fl->done[dev] = true;
+    if (track) fl->done[dev].store(true, std::memory_order_release);
   }
   return FF_OK;
 }

@@ -90,6 +90,33 @@ extern "C" int ff_profile_end(double* ms, double* work, long long* launches, int
   return FF_OK;
 }
 
+// What the event bracket adds to a measured interval: `launches` empty kernels are queued back to back, each between
+// its own event pair exactly like ff_prof_open / ff_prof_close do; the mean (b - a) interval of an EMPTY kernel is what
+// a category time of ff_profile_end carries per launch on top of the kernel's own duration.
+__global__ void ff_empty_kernel() {}
+extern "C" int ff_profile_bracket_us(int launches, double* us_per_launch, ff_stream_t stream) {
+  FF_CHECK_ARG(launches > 0 && launches <= 4096 && us_per_launch, "ff_profile_bracket_us: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(2 * (size_t)launches);
+  for (hipEvent_t& e : ev) FF_CHECK_HIP(hipEventCreate(&e));
+  for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(ff_empty_kernel, dim3(1), dim3(64), 0, st);   // warm
+  for (int i = 0; i < launches; ++i) {
+    FF_CHECK_HIP(hipEventRecord(ev[2 * i], st));
+    hipLaunchKernelGGL(ff_empty_kernel, dim3(1), dim3(64), 0, st);
+    FF_CHECK_HIP(hipEventRecord(ev[2 * i + 1], st));
+  }
+  FF_CHECK_HIP(hipStreamSynchronize(st));
+  double tot = 0;
+  for (int i = 0; i < launches; ++i) {
+    float t = 0.f;
+    FF_CHECK_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    tot += t;
+  }
+  for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
+  *us_per_launch = 1e3 * tot / launches;
+  return FF_OK;
+}
+
 // ---- LayerNorm (+pos) --------------------------------------------------------------------------
 // NV = float4 chunks per lane (E <= 256*NV).  Two-pass statistics in registers (mean, then the
 // centred second moment) -- the same formula torch's CPU kernel evaluates, biased variance.

@@ -136,12 +136,19 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
     extra = model._extra_mask(inputs) if hasattr(model, "_extra_mask") else None   # [n*F or n, S] uint8
 
     if local_shard:
-        meta = torch.tensor([max(num_input) if (parallel and num_input) else 1, n_here], dtype=torch.int64, device=dev)
-        allmeta = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        meta = torch.tensor([max(num_input) if (parallel and num_input) else 1, n_here, inputs["input"].size(1)],
+                            dtype=torch.int64, device=dev)
+        allmeta = torch.empty(3 * world, dtype=torch.int64, device=dev)
         dist_mod.all_gather_into_tensor(allmeta, meta, group=group)
-        allmeta = allmeta.view(world, 2).tolist()
+        allmeta = allmeta.view(world, 3).tolist()
         F = max(m[0] for m in allmeta) if parallel else 1
         sizes = [int(m[1]) for m in allmeta]
+        # every rank pads its wireframes to the SAME num_lines: F is the batch-global anchor count and a rank whose own
+        # padded width were smaller than another rank's widest wireframe could not hold F anchors (ff_decode: F <= S)
+        widths = sorted({int(m[2]) for m in allmeta if m[1] > 0})
+        if len(widths) > 1:
+            raise ValueError("decode_sharded(local_shard=True): ranks padded their wireframes to different num_lines %s; "
+                             "pad every shard to the same width (cfg.model.num_lines)" % widths)
         mine = list(range(n_here))
         N = sum(sizes)
         if extra is not None and parallel and extra.size(0) != n_here * F:

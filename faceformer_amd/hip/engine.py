@@ -29,6 +29,7 @@ class PathEngine:
         self._lib = _L.load()
         self._keep = {}
         self._planes = {}
+        self._want_planes = bool(bf16_split_planes)
         self._folded = {}
         m = _L.Model()
         get = self._get
@@ -86,6 +87,8 @@ class PathEngine:
                     wt = tensors["decoder.layers.%d.%s" % (i, name)]
                     if field == "cross_q_planes":
                         wt = wt[:E_]  # q rows only: k|v of the cross attention are projected once per batch
+                    if wt.shape[1] % 32 or wt.shape[1] < 64:
+                        continue      # the bf16-split kernel needs K % 32 == 0: this weight stays f32-only (null planes)
                     pl = split_weight(wt)
                     self._planes[(i, field)] = pl
                     setattr(m.dec[i], field, pl.data_ptr())
@@ -154,7 +157,8 @@ class PathEngine:
 
     @property
     def has_planes(self):
-        return bool(self._planes)
+        """True when the engine was bound WITH the bf16 planes (weights whose K the split kernel cannot take have none)."""
+        return self._want_planes
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:

@@ -104,6 +104,7 @@ SIGNATURES = {
     "ff_profile_begin": (C.c_int, []),
     "ff_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "ff_profile_bytes": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "ff_profile_bracket_us": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
                                fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,

@@ -7,7 +7,7 @@ from ..embedding import PositionEmbeddingLearned, VanillaEmedding
 from ..hip import lib as _L
 from ..hip import ops
 from ..hip.engine import DEFAULT_FLAGS, PathEngine
-from ..transformer import (TransformerDecoder, TransformerDecoderLayer, TransformerEncoder,
+from ..transformer import (HipLinear, TransformerDecoder, TransformerDecoderLayer, TransformerEncoder,
                            TransformerEncoderLayer)
 from ..utils import min_value_of_dtype
 
@@ -40,7 +40,7 @@ class SurfaceFormerBase(nn.Module):
         dec_layer = TransformerDecoderLayer(num_model, num_head, num_feedforward, dropout, activation,
                                             normalize_before)
         self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, nn.LayerNorm(num_model))
-        self.project = nn.Linear(num_model, num_model)
+        self.project = HipLinear(num_model, num_model)
         self._reset_parameters()
 
         # engine knobs (not part of the reference surface)

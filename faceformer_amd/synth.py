@@ -164,3 +164,33 @@ def make_extra_mask(case, batch):
     n_wf, L = batch["input"].shape[0], batch["input"].shape[1]
     B = n_wf * max(batch["num_input"]) if case["kind"] == "parallel" else n_wf
     return torch.from_numpy(g.random((B, L)) < 0.2)
+
+
+def make_module_state(shapes, seed=0, gain=2.0):
+    """Name-keyed synthetic parameters for an arbitrary sub-module (the sub-module-surface goldens):
+    `shapes` maps parameter name -> shape (e.g. from `module.state_dict()`); matrices are xavier-uniform x `gain`,
+    LayerNorm weights (`norm*.weight`) 1 + 0.3 N(0,1), every other vector 0.3 N(0,1); integer buffers
+    (`position`) count from 0.  Depends on names, shapes and the seed only."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(int(s) for s in shape)
+        g = _rng("module:" + name, seed)
+        leaf = name.split(".")[-1]
+        if leaf == "position":
+            out[name] = torch.arange(shape[-1], dtype=torch.long).reshape(shape)
+            continue
+        if len(shape) >= 2:
+            bound = np.sqrt(6.0 / (shape[0] + shape[1]))
+            w = g.uniform(-bound, bound, size=shape) * gain
+        elif "norm" in name and leaf == "weight":
+            w = 1.0 + 0.3 * g.standard_normal(shape)
+        else:
+            w = 0.3 * g.standard_normal(shape)
+        out[name] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+    return out
+
+
+def make_named_tensor(name, shape, seed=0, scale=1.0):
+    """Seeded N(0, scale) float32 tensor keyed by `name` (inputs of the sub-module-surface goldens)."""
+    g = _rng("input:" + name, seed)
+    return torch.from_numpy(np.ascontiguousarray(scale * g.standard_normal(tuple(shape)), dtype=np.float32))

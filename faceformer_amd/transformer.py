@@ -24,7 +24,7 @@ from .hip import ops
 from .hip.lib import FF_HEAD_DIM, HipExtensionError
 
 __all__ = ["Transformer", "TransformerEncoder", "TransformerDecoder", "TransformerEncoderLayer",
-           "TransformerDecoderLayer", "MultiheadAttention"]
+           "TransformerDecoderLayer", "MultiheadAttention", "HipLinear"]
 
 
 def _eval_only(mod):
@@ -140,6 +140,16 @@ class MultiheadAttention(nn.Module):
         o = self.attend(q, kv[:, :E], kv[:, E:], lq, lk, batch, kpm, causal)
         out = ops.linear(o, self.out_proj.weight, self.out_proj.bias)
         return out.view(lq, batch, E), None
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose forward runs on the f32-MFMA projection kernel: the
+    models' `project` head (reference model_para.py:46,225) when an external caller drives the blocks itself."""
+
+    def forward(self, x):
+        _eval_only(self)
+        out = ops.linear(x.reshape(-1, x.size(-1)), self.weight, self.bias)
+        return out.view(*x.shape[:-1], self.out_features)
 
 
 def _activation_code(name):
@@ -379,7 +389,7 @@ class Transformer(nn.Module):
     (transformer.py:18-59) that neither model class instantiates; it exists here only so that
     `faceformer.transformer.Transformer(...)` keeps its constructor arguments and call contract:
     (src N x C x H x W, mask N x H x W, query_embed Q x C, pos_embed N x C x H x W) ->
-    (decoder states [layers or 1] x N x Q x C, memory N x C x H x W)."""
+    (decoder states transposed like the reference does, memory N x C x H x W)."""
 
     def __init__(self, num_model=512, num_head=8, num_encoder_layers=6, num_decoder_layers=6,
                  num_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
@@ -406,5 +416,6 @@ class Transformer(nn.Module):
         memory = self.encoder(self._as_tokens(src), src_key_padding_mask=key_pad, pos=pos)
         states = self.decoder(queries.new_zeros(queries.shape), memory, memory_key_padding_mask=key_pad,
                               pos=pos, query_pos=queries)
-        states = states if states.dim() == 4 else states[None]
+        # (the reference transposes dims 1 and 2 of WHATEVER the decoder returns, transformer.py:59: [layers, Q, N, C] ->
+        #  [layers, N, Q, C] with return_intermediate_dec, [Q, N, C] -> [Q, C, N] without; kept as is)
         return states.transpose(1, 2), memory.permute(1, 2, 0).reshape(n, c, h, w)

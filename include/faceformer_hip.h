@@ -54,6 +54,9 @@ int ff_profile_end(double* ms_by_cat, double* work_by_cat, long long* launches_b
 /* Algorithmic bytes (operands read once + results written once) summed per category since the last
  * ff_profile_begin (only the GEMM category is filled in). */
 int ff_profile_bytes(double* bytes_by_cat, int ncat);
+/* Mean event-pair interval [us] around an EMPTY kernel, `launches` of them queued back to back on `stream`: what the
+ * event bracket adds per launch to the category times of ff_profile_end (bench.py reports times net of it). */
+int ff_profile_bracket_us(int launches, double* us_per_launch, ff_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * G2  LayerNorm (+ positional add).  Replaces nn.LayerNorm followed by `with_pos_embed`

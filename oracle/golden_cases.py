@@ -77,4 +77,11 @@ CASES = [
     dict(name="par_full_E1024_gain4", kind="parallel", model=_m(FULL, 1024, 4), recipe="gain4",
          wseed=0, n_edges=[1024, 64, 300], seeds=[31, 32, 33],
          keep_logit_rows=[0, 1, 500, 1023, 1024, 1060, 1087, 1088, 2047, 2048, 2200, 2347, 2348, 3071], slow=True),
+    # --- round 3: a LONG prefix at config-E key counts -------------------------------------------------------
+    # ours-perspective.yml sizes (max_face_length 38) with num_lines=512: a 512-edge and a 64-edge wireframe, all 37
+    # decode steps -- the block-shared cross-attention (S = 516 > 288 keys) and the padding-anchor de-duplication
+    # (448 padding anchors in the short wireframe) with t*F query rows for every t up to 37
+    dict(name="par_full_E512_T38_gain4", kind="parallel", model=_m(FULL, 512, 38), recipe="gain4",
+         wseed=0, n_edges=[512, 64], seeds=[41, 42],
+         keep_logit_rows=[0, 1, 300, 511, 512, 540, 575, 576, 800, 1023], slow=True),
 ]

@@ -103,6 +103,79 @@ def decoder_layer(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, n
     return tgt + y
 
 
+def encoder_layer_post(sd, p, src, key_padding_mask, pos, num_head):
+    """reference transformer.py:148-162 (forward_post; unused by the reference's configs, part of the module
+    surface)."""
+    q = k = src if pos is None else src + pos
+    src = src + _mha(q, k, src, sd, p + ".self_attn", num_head, key_padding_mask)
+    src = _ln(src, sd, p + ".norm1")
+    y = F.linear(F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return _ln(src + y, sd, p + ".norm2")
+
+
+def decoder_layer_post(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, num_head, tgt_mask=None,
+                       tgt_key_padding_mask=None):
+    """reference transformer.py:211-233 (forward_post)."""
+    q = k = tgt if query_pos is None else tgt + query_pos
+    tgt = tgt + _mha(q, k, tgt, sd, p + ".self_attn", num_head, tgt_key_padding_mask, tgt_mask)
+    tgt = _ln(tgt, sd, p + ".norm1")
+    tgt = tgt + _mha(tgt if query_pos is None else tgt + query_pos, memory if pos is None else memory + pos, memory,
+                     sd, p + ".multihead_attn", num_head, memory_key_padding_mask)
+    tgt = _ln(tgt, sd, p + ".norm2")
+    y = F.linear(F.relu(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return _ln(tgt + y, sd, p + ".norm3")
+
+
+def decoder_layer_pre_kpm(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, num_head, tgt_mask=None,
+                          tgt_key_padding_mask=None):
+    """reference transformer.py:235-256 with EVERY keyword of the layer (the eval loop passes no tgt masks; the
+    teacher-forced caller model_para.py:162-163 passes tgt_mask and tgt_key_padding_mask)."""
+    y = _ln(tgt, sd, p + ".norm1")
+    q = k = y if query_pos is None else y + query_pos
+    tgt = tgt + _mha(q, k, y, sd, p + ".self_attn", num_head, tgt_key_padding_mask, tgt_mask)
+    y = _ln(tgt, sd, p + ".norm2")
+    tgt = tgt + _mha(y if query_pos is None else y + query_pos, memory if pos is None else memory + pos, memory, sd,
+                     p + ".multihead_attn", num_head, memory_key_padding_mask)
+    y = _ln(tgt, sd, p + ".norm3")
+    y = F.linear(F.relu(F.linear(y, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return tgt + y
+
+
+def decoder_stack(sd, prefix, tgt, memory, num_head, num_layers, normalize_before=True, final_norm=True,
+                  return_intermediate=False, tgt_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None,
+                  pos=None, query_pos=None):
+    """reference transformer.py:95-124 over a state_dict with keys `<prefix>layers.<i>.*`, `<prefix>norm.*`: both
+    layer forms and the `return_intermediate` stack."""
+    layer = decoder_layer_pre_kpm if normalize_before else decoder_layer_post
+    out, inter = tgt, []
+    for i in range(num_layers):
+        out = layer(sd, "%slayers.%d" % (prefix, i), out, memory, memory_key_padding_mask, pos, query_pos, num_head,
+                    tgt_mask, tgt_key_padding_mask)
+        if return_intermediate:
+            inter.append(_ln(out, sd, prefix + "norm"))
+    if final_norm:
+        out = _ln(out, sd, prefix + "norm")
+        if return_intermediate:
+            inter[-1] = out
+    return torch.stack(inter) if return_intermediate else out
+
+
+def encoder_stack(sd, prefix, src, num_head, num_layers, normalize_before=True, final_norm=True,
+                  src_key_padding_mask=None, pos=None):
+    """reference transformer.py:70-83 with either layer form."""
+    out = src
+    for i in range(num_layers):
+        p = "%slayers.%d" % (prefix, i)
+        if normalize_before:
+            out = encoder_layer(sd, p, out, src_key_padding_mask, 0 if pos is None else pos, num_head)
+        else:
+            out = encoder_layer_post(sd, p, out, src_key_padding_mask, pos, num_head)
+    return _ln(out, sd, prefix + "norm") if final_norm else out
+
+
 def decoder(sd, tgt, memory, memory_key_padding_mask, pos, query_pos, num_head, num_layers,
             tgt_mask=None):
     """reference transformer.py:95-124 (return_intermediate=False)."""

@@ -95,3 +95,51 @@ def test_checkpoint_unpickler_refuses_arbitrary_globals(tmp_path):
     sd, hp = load_lightning_checkpoint(path)
     assert not (tmp_path / "pwned").exists()
     assert torch.equal(sd["w"], torch.ones(2)) and hp["x"] == 1
+
+
+def test_checkpoint_with_this_packages_own_cfgnode_round_trips(tmp_path):
+    """hyper_parameters pickled as faceformer_amd.config.CfgNode (a checkpoint written with THIS package, also
+    through the `faceformer` alias) must come back as a CfgNode, not as an inert placeholder."""
+    from faceformer_amd.checkpoint import load_lightning_checkpoint, model_from_checkpoint
+    from faceformer_amd.config import CfgNode
+    from faceformer_amd.models import SurfaceFormer
+    tok = dict(PAD=0, SOS=1, SEP=2, EOS=3, DIR0=4, DIR1=5, len=4, face_type_offset=1)
+    mcfg = dict(num_model=128, num_head=2, num_feedforward=256, num_encoder_layers=1, num_decoder_layers=1,
+                num_points_per_line=50, num_lines=10, point_dim=2, label_seq_length=9, token=tok)
+    model = SurfaceFormer(**{**mcfg, "token": token_ns()})
+    hp = CfgNode({"model_class": "SurfaceFormer", "model": mcfg})
+    hp.freeze()
+    path = str(tmp_path / "own.ckpt")
+    torch.save({"state_dict": {"model." + k: v for k, v in model.state_dict().items()}, "hyper_parameters": hp}, path)
+    sd, hp2 = load_lightning_checkpoint(path)
+    assert type(hp2) is CfgNode and hp2.is_frozen() and hp2.model.token.EOS == 3 and hp2["model_class"] == "SurfaceFormer"
+    m2 = model_from_checkpoint(path)
+    assert isinstance(m2, SurfaceFormer)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+
+
+def test_checkpoint_numpy_allow_list_is_narrow(tmp_path):
+    """ndarrays / numpy scalars inside a checkpoint are rebuilt; any other numpy callable (fromfile, frombuffer,
+    ...) is NOT imported."""
+    import numpy as np
+    from faceformer_amd.checkpoint import _Inert, _Unpickler, load_lightning_checkpoint
+    path = str(tmp_path / "np.ckpt")
+    torch.save({"state_dict": {"model.w": torch.ones(2)}, "hyper_parameters": {"x": 1},
+                "arr": np.arange(6, dtype=np.float32).reshape(2, 3), "scalar": np.float64(2.5)}, path)
+    import pickle, zipfile
+    with zipfile.ZipFile(path) as z:
+        name = [n for n in z.namelist() if n.endswith("data.pkl")][0]
+        raw = z.read(name)
+    assert b"numpy" in raw
+    ck = torch.load(path, map_location="cpu", weights_only=False,
+                    pickle_module=__import__("faceformer_amd.checkpoint", fromlist=["_pickle_module"])._pickle_module)
+    assert isinstance(ck["arr"], np.ndarray) and ck["arr"].shape == (2, 3) and float(ck["scalar"]) == 2.5
+    import io
+    up = _Unpickler(io.BytesIO(b""))
+    for mod in ("numpy.core.multiarray", "numpy._core.multiarray", "numpy"):
+        for bad in ("fromfile", "frombuffer", "copyto", "fromstring", "load"):
+            assert up.find_class(mod, bad) is _Inert, (mod, bad)
+    assert up.find_class("numpy", "ndarray") is np.ndarray
+    sd, _ = load_lightning_checkpoint(path)
+    assert torch.equal(sd["w"], torch.ones(2))

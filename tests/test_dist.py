@@ -65,6 +65,17 @@ def _worker(rank, world, port, name, ret, local=False):
         lo, hi = (0, 1) if rank == 0 else (1, N)
         mine = {"input": batch["input"][lo:hi], "input_mask": batch["input_mask"][lo:hi],
                 "label": batch["label"][lo:hi], "num_input": batch["num_input"][lo:hi]}
+        if local == "mismatch":
+            # rank 1 padded its wireframes to a narrower num_lines: must be refused on EVERY rank, before any decode
+            if rank == 1:
+                mine = dict(mine, input=mine["input"][:, :-2], input_mask=mine["input_mask"][:, :-2])
+            try:
+                ffd.decode_sharded(model, mine, dist, local_shard=True)
+                ret[rank] = False
+            except ValueError as e:
+                ret[rank] = "different num_lines" in str(e)
+            dist.destroy_process_group()
+            return
         out = ffd.decode_sharded(model, mine, dist, local_shard=True)
         ret[rank] = bool(np.array_equal(out["predict"].numpy(), z["predict"]) and out["shard_sizes"] == [1, N - 1])
         dist.destroy_process_group()
@@ -106,6 +117,20 @@ def test_sharded_decode_with_shard_local_inputs_gloo(name):
     ret = ctx.Manager().dict()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_local_inputs_of_different_padded_width_are_refused_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "par_small_ragged", ret, "mismatch")) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

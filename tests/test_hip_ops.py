@@ -272,7 +272,11 @@ def test_attention_position_major_self(ops, attn_algo, t, B, H, causal):
     assert rel_err(out, ref) < 5e-6
 
 
-@pytest.mark.parametrize("t,F,W,S", [(1, 3, 2, 30), (5, 7, 3, 50), (12, 40, 1, 44), (36, 33, 2, 260)])
+@pytest.mark.parametrize("t,F,W,S", [(1, 3, 2, 30), (5, 7, 3, 50), (12, 40, 1, 44), (36, 33, 2, 260),
+                                     # config-E key counts (S > 288: the block-shared kernel) with LONG prefixes: t*F query rows
+                                     # per wireframe for t up to 37, F = the 512 anchors of the wide wireframe / 65 = the compact
+                                     # width of a 64-edge one, and a 1028-key wireframe
+                                     (36, 512, 1, 516), (37, 65, 2, 516), (33, 129, 2, 1028), (36, 40, 1, 1028), (9, 513, 1, 516)])
 def test_attention_cross_shared_kv(ops, attn_algo, t, F, W, S):
     """Decoder cross-attention: F sequences of a wireframe share its K/V; queries position-major."""
     H, E = 8, 512

@@ -10,12 +10,12 @@ OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1
 ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && rm -rf /tmp/prof_trace2 &&
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_trace2 -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-x3-line > /dev/null 2>&1 &&
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_trace2 -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-x3-line --no-other-configs > /dev/null 2>&1 &&
   python tools/step_breakdown.py /tmp/prof_trace2/t_results.db 4,8,20,36 > $OUT/steps.txt 2>&1; rm -rf /tmp/prof_trace2 )
 timeout 900 python bench.py > $OUT/bench_${TAG}_B.json 2> $OUT/bench_B.err
-timeout 600 python bench.py --wireframes-per-gpu 128 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_${TAG}_C128.json 2>> $OUT/bench_B.err
-timeout 600 python bench.py --config E --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_${TAG}_E32.json 2>> $OUT/bench_B.err
-timeout 600 python bench.py --config E --steps 2 --warmup 1 --no-cpu-baseline --no-dedup --no-x3-line > $OUT/bench_${TAG}_E32_nodedup.json 2>> $OUT/bench_B.err
+timeout 600 python bench.py --wireframes-per-gpu 128 --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_${TAG}_C128.json 2>> $OUT/bench_B.err
+timeout 600 python bench.py --config E --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_${TAG}_E32.json 2>> $OUT/bench_B.err
+timeout 600 python bench.py --config E --steps 2 --warmup 1 --no-cpu-baseline --no-dedup --no-x3-line --no-other-configs > $OUT/bench_${TAG}_E32_nodedup.json 2>> $OUT/bench_B.err
 timeout 600 python tools/time_seq2seq.py > $OUT/seq2seq.txt 2>&1
 timeout 600 python tools/attn_sweep.py > $OUT/attention_sweep.txt 2>&1
 timeout 600 python tools/attn_sweep.py --seq > $OUT/attention_sweep_seq2seq.txt 2>&1

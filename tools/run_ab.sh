@@ -3,7 +3,7 @@
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/ab
 timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -q -x -k "${FF_AB_TESTS:-gemm or linear}" > gpurun_out/ab/pytest.log 2>&1; tail -2 gpurun_out/ab/pytest.log
-runb() { timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-x3-line --steps 8 --warmup 2 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('%.2f' % d['ms_per_step'])"; }
+runb() { timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-x3-line --no-other-configs --steps 8 --warmup 2 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('%.2f' % d['ms_per_step'])"; }
 runs() { FF_SEQ_ONLY_A=1 timeout 300 python tools/time_seq2seq.py 2>&1 | grep seq2seq | awk '{print $5}'; }
 for i in 1 2; do
   echo "in-tree: B $(runb) ms  seq2seq $(runs) ms"
