@@ -19,15 +19,14 @@
 #include <atomic>
 
 #include "ff_common.h"
+#include "ff_device.h"
+#include "ff_chain.h"
 
 namespace {
 
-// 2^x on the transcendental unit (v_exp_f32) without the subnormal-range fix-up of exp2f: softmax
-// terms below 2^-126 are irrelevant next to a maximum term of 1.
-__device__ __forceinline__ float ff_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 constexpr int KC = 64;     // keys per LDS chunk
-constexpr int K_LD = 68;   // padded K row (floats)
+constexpr int K_LD = FF_ATTN_K_LD;   // padded K row (floats)
 constexpr int V_LD = 64;
 
 template <int NW, bool DB>
@@ -267,383 +266,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
 template <int NWAVES>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_wave_kernel(ff_attn_desc d, int q_tiles, int ks,
                                                                       long total_units, int tail_ok, int qtail) {
-  constexpr int PATCH = 32 * K_LD;  // 2176 floats per wave: K tile, later the combine record
-  // short-tail mode (four-wave blocks only): rows of up to 8 extra keys (K, V), up to 8 extra queries, their weights
-  constexpr int TAILF = NWAVES == 4 ? (3 * 8 * 64 + 40 * 8 + 8) : 0;
-  __shared__ __attribute__((aligned(16))) float lds[NWAVES * PATCH + NWAVES * 32 + NWAVES * TAILF];
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int half = lane >> 5, l32 = lane & 31;
-  float* Kw = lds + wave * PATCH;
-  float* Mw = lds + NWAVES * PATCH + wave * 32;
-  float* const Kt = lds + NWAVES * (PATCH + 32) + wave * TAILF;   // [8][64] keys 32..39
-  float* const Vt = Kt + 512;                                     // [8][64]
-  float* const Qt = Kt + 1024;                                    // [8][64] queries 32 * q_tiles ..
-  float* const Pw = Kt + 1536;                                    // [40][8] softmax weights of the extra queries
-  float* const Mt = Kt + 1856;                                    // [8] additive mask of the extra keys
-  const bool tails = NWAVES == 4 && tail_ok != 0;                 // block-uniform
-
-  const int units_per_block = NWAVES / ks;
-  const long unit = (long)blockIdx.x * units_per_block + wave / ks;
-  const int kg = wave % ks;
-  const bool unit_valid = unit < total_units;
-  const long uc = unit_valid ? unit : total_units - 1;
-  const int qt = (int)(uc % q_tiles);
-  const int gh_i = (int)(uc / q_tiles);
-  const int g = gh_i / d.num_heads, h = gh_i % d.num_heads;
-
-  const int qi = qt * 32 + l32;
-  const bool q_valid = unit_valid && qi < d.nq;
-  const int qc = qi < d.nq ? qi : d.nq - 1;
-  const size_t qrow = (size_t)g * d.q_group_stride + (size_t)(qc / d.q_inner) * d.q_outer_stride +
-                      (size_t)(qc % d.q_inner);
-  const float qscale = d.scale * 1.4426950408889634f;
-  float qreg[32];
-  {
-    const float* qp = d.q + qrow * d.ldq + h * FF_HEAD_DIM + half * 32;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(qp + c * 4);
-      qreg[c * 4 + 0] = t.x * qscale;
-      qreg[c * 4 + 1] = t.y * qscale;
-      qreg[c * 4 + 2] = t.z * qscale;
-      qreg[c * 4 + 3] = t.w * qscale;
-    }
-  }
-  const float* kbase = d.k + (size_t)g * d.k_group_stride * d.ldk + h * FF_HEAD_DIM;
-  const float* vbase = d.v + (size_t)g * d.k_group_stride * d.ldv + h * FF_HEAD_DIM;
-  const unsigned char* mrow = d.key_mask ? d.key_mask + (size_t)g * d.mask_stride : nullptr;
-
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x16 o0, o1;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
-
-  // K staging: lane -> (row = lane/16 + 4p, 16-byte column lane%16): 4 full 256-byte rows per instruction.
-  // Addresses are clamped with the STATIC key count (rows up to d.nk exist), the group's own length only masks:
-  // the first K and V tiles are requested together with kv_len and the queries -- one round trip, not three.
-  const int srow = lane >> 4, sc4 = lane & 15;
-  const int nk_s = d.nk;
-  const int tiles_s = (nk_s + 31) >> 5;
-  f32x4 kst[8];
-  float v0[16], v1[16];
-  unsigned char mbyte = 0;   // key-mask byte of key (tile, lane), lanes 0..31: travels with the K tile
-  auto load_k = [&](int kt) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int key = kt * 32 + srow + 4 * p;
-      const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
-      kst[p] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
-    }
-    if (mrow && lane < 32) {
-      const int key = kt * 32 + lane;
-      mbyte = key < nk_s ? mrow[key] : (unsigned char)1;
-    }
-  };
-  auto load_v = [&](int kt) {   // V fragments straight to registers (each load instruction reads two full 128-byte row segments)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
-      const float* vp = vbase + (size_t)kc * d.k_stride * d.ldv + l32;
-      v0[r] = vp[0];
-      v1[r] = vp[32];
-    }
-  };
-  auto wave_fence = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-
-  int kt = kg;
-  if (kt < tiles_s) { load_k(kt); load_v(kt); }
-  const bool q_extra = tails && qtail > 0 && unit_valid && qt == q_tiles - 1;   // this wave also serves the extra queries
-  f32x4 tk[2], tv[2], tq[2];
-  unsigned char tmb = 0;
-  if (tails) {   // the extra rows are requested in the same round trip as everything else
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int key = 32 + srow + 4 * p;
-      const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
-      tk[p] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
-      tv[p] = *reinterpret_cast<const f32x4*>(vbase + (size_t)kc * d.k_stride * d.ldv + sc4 * 4);
-      if (q_extra) {
-        const int r = srow + 4 * p;
-        const int qx = q_tiles * 32 + (r < qtail ? r : qtail - 1);
-        const size_t xr = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
-        tq[p] = *reinterpret_cast<const f32x4*>(d.q + xr * d.ldq + h * FF_HEAD_DIM + sc4 * 4);
-      }
-    }
-    if (mrow && lane < 8) tmb = (32 + lane) < nk_s ? mrow[32 + lane] : (unsigned char)1;
-  }
-  int nk = nk_s;
-  if (d.kv_len) {
-    const int kl = d.kv_len[g];
-    nk = kl < nk ? kl : nk;
-  }
-  if (tails) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<f32x4*>(Kt + (srow + 4 * p) * 64 + sc4 * 4) = tk[p];
-      *reinterpret_cast<f32x4*>(Vt + (srow + 4 * p) * 64 + sc4 * 4) = tv[p];
-      if (q_extra) *reinterpret_cast<f32x4*>(Qt + (srow + 4 * p) * 64 + sc4 * 4) = tq[p];
-    }
-    if (lane < 8) Mt[lane] = ((32 + lane) < nk && tmb == 0) ? 0.f : -INFINITY;
-    wave_fence();
-  }
-  // Short tails (per-sequence self-attention one to eight positions past a multiple of 32: t = 33..37 of the 37- / 38-
-  // token configurations) do not get 32-wide MFMA tiles of their own: the extra KEYS are folded into the running
-  // softmax on the VALU (lane = query), the extra QUERIES are evaluated after the unit's own tile (lane = key for
-  // the scores, lane = head dimension for the values).  Their rows wait in LDS since the first round trip; the main
-  // tile's K patch and V fragments are reused -- no further memory request.  36 x 36 scores cost one tile step plus
-  // ~3 us instead of four tile steps.
-  const int ktail = (tails && nk > 32 && nk <= 40) ? nk - 32 : 0;
-  const int ntiles = ktail ? (nk >> 5) : ((nk + 31) >> 5);
-  for (; kt < ntiles; kt += ks) {
-    // ---- K tile: registers -> private LDS patch -> MFMA fragments ----
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int key = kt * 32 + srow + 4 * p;
-      *reinterpret_cast<f32x4*>(Kw + (srow + 4 * p) * K_LD + sc4 * 4) = key < nk ? kst[p] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (mrow) {
-      if (lane < 32) {
-        const int key = kt * 32 + lane;
-        Mw[lane] = (key < nk && mbyte == 0) ? 0.f : -INFINITY;
-      }
-    }
-    wave_fence();
-    f32x4 kf[8];
-#pragma unroll
-    for (int cg = 0; cg < 8; ++cg) kf[cg] = *reinterpret_cast<const f32x4*>(Kw + l32 * K_LD + half * 32 + cg * 4);
-    wave_fence();  // fragments are in registers: the K patch may be overwritten (Mw stays valid)
-    // (V rows past the group's length are finite values of real rows; their softmax weight is exactly 0)
-    if (kt + ks < ntiles) load_k(kt + ks);   // next K tile in flight under the MFMA chains
-    // ---- S^T tile ----
-    f32x16 s;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
-    for (int cg = 0; cg < 8; ++cg) {
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].x, qreg[cg * 4 + 0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].y, qreg[cg * 4 + 1], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].z, qreg[cg * 4 + 2], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg].w, qreg[cg * 4 + 3], s, 0, 0, 0);
-    }
-    // ---- online softmax ----
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int keyl = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int key = kt * 32 + keyl;
-      float mv = mrow ? Mw[keyl] : ((key < nk) ? 0.f : -INFINITY);
-      if (d.causal && key > qi) mv = -INFINITY;
-      const float v = s[r] + mv;
-      s[r] = v;
-      tmax = fmaxf(tmax, v);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
-    const float m_new = fmaxf(m_run, tmax);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = ff_exp2(m_run - m_safe);
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = ff_exp2(s[r] - m_safe);
-      s[r] = p;
-      psum += p;
-    }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    if (!__all(alpha == 1.0f)) {  // the running max moved for some query of this wave
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
-    }
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
-    }
-    if (kt + ks < ntiles) load_v(kt + ks);
-  }
-
-  if (ktail) {   // (ks == 1, one main tile) keys 32 .. nk-1 for this wave's 32 queries
-    float sj[8];
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      sj[jj] = -INFINITY;
-      if (jj < ktail) {   // wave-uniform
-        const float* kp = Kt + jj * 64 + half * 32;
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + c * 4);
-          dot += kv.x * qreg[c * 4 + 0] + kv.y * qreg[c * 4 + 1] + kv.z * qreg[c * 4 + 2] + kv.w * qreg[c * 4 + 3];
-        }
-        dot += __shfl_xor(dot, 32, FF_WAVE);
-        float sv = dot + Mt[jj];
-        if (d.causal && (32 + jj) > qi) sv = -INFINITY;
-        sj[jj] = sv;
-        tmax = fmaxf(tmax, sv);
-      }
-    }
-    const float m_new = fmaxf(m_run, tmax);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = ff_exp2(m_run - m_safe);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
-    float psum = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      if (jj < ktail) {
-        const float pj = ff_exp2(sj[jj] - m_safe);   // 0 for masked keys
-        psum += pj;
-        const float* vp = Vt + jj * 64 + 4 * half;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(vp + 8 * g4);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(vp + 32 + 8 * g4);
-          o0[g4 * 4 + 0] += pj * a.x; o0[g4 * 4 + 1] += pj * a.y; o0[g4 * 4 + 2] += pj * a.z; o0[g4 * 4 + 3] += pj * a.w;
-          o1[g4 * 4 + 0] += pj * b.x; o1[g4 * 4 + 1] += pj * b.y; o1[g4 * 4 + 2] += pj * b.z; o1[g4 * 4 + 3] += pj * b.w;
-        }
-      }
-    }
-    l_run = l_run * alpha + (half == 0 ? psum : 0.f);   // both halves hold the same weights: count them once
-    m_run = m_new;
-  }
-
-  float* const op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
-  if (ks > 1) {
-    // ---- combine the ks key groups of a unit through LDS (record: O[32 regs][64 lanes], m, l).  Every wave of the
-    //      unit takes 32 / ks of the output registers and sums them over the records in ascending key-group order.
-    wave_fence();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { Kw[e * 64 + lane] = o0[e]; Kw[(16 + e) * 64 + lane] = o1[e]; }
-    Kw[32 * 64 + lane] = m_run;   // 2048 + 64 + 64 = 2176 = PATCH exactly
-    Kw[33 * 64 + lane] = l_run;
-    __syncthreads();
-    const float* rec0 = lds + (wave - kg) * PATCH;
-    float sc[8];
-    float m_star = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < ks) { sc[j] = rec0[j * PATCH + 32 * 64 + lane]; m_star = fmaxf(m_star, sc[j]); }
-    const float ms = (m_star == -INFINITY) ? 0.f : m_star;
-    float l_sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < ks) { sc[j] = ff_exp2(sc[j] - ms); l_sum += rec0[j * PATCH + 33 * 64 + lane] * sc[j]; }
-    const float l_all = l_sum + __shfl_xor(l_sum, 32, FF_WAVE);
-    const float inv_c = l_all > 0.f ? 1.0f / l_all : 0.f;
-    if (!q_valid) return;
-    const int quads = 8 / ks;                 // groups of four output registers per wave (ks = 2, 4, 8)
-    for (int qd = 0; qd < quads; ++qd) {
-      const int e0 = (kg * quads + qd) * 4;   // registers e0 .. e0+3: o0 for e0 < 16, else o1
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < ks) {
-          const float* r = rec0 + j * PATCH + e0 * 64 + lane;
-          acc.x += r[0] * sc[j];
-          acc.y += r[64] * sc[j];
-          acc.z += r[128] * sc[j];
-          acc.w += r[192] * sc[j];
-        }
-      acc.x *= inv_c; acc.y *= inv_c; acc.z *= inv_c; acc.w *= inv_c;
-      *reinterpret_cast<f32x4*>(op + (e0 < 16 ? 2 * e0 : 32 + 2 * (e0 - 16))) = acc;
-    }
-    return;
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, FF_WAVE);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_valid) {
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      f32x4 a = {o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv, o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv};
-      f32x4 b = {o1[g4 * 4 + 0] * inv, o1[g4 * 4 + 1] * inv, o1[g4 * 4 + 2] * inv, o1[g4 * 4 + 3] * inv};
-      *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
-      *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = b;
-    }
-  }
-
-  if (q_extra) {   // (ks == 1, nk <= 40) queries 32 * q_tiles .. nq-1 of this (group, head)
-    // scores: lane = key; K rows 0..31 are still in the patch (one main tile), rows 32.. in Kt
-    const int lk = lane < 40 ? lane : 39;
-    const float* krp = lane < 32 ? Kw + lane * K_LD : Kt + (lk - 32) * 64;
-    f32x4 kr[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) kr[c] = *reinterpret_cast<const f32x4*>(krp + c * 4);
-    bool kok = lane < nk;
-    if (mrow && kok) kok = (lane < 32 ? Mw[lane] : Mt[lk - 32]) == 0.f;
-    f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i < qtail) {   // wave-uniform
-        const float* qp = Qt + i * 64;
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + c * 4);
-          dot += kr[c].x * qv.x + kr[c].y * qv.y + kr[c].z * qv.z + kr[c].w * qv.w;
-        }
-        const bool ok = kok && !(d.causal && lane > q_tiles * 32 + i);
-        const float sv = ok ? dot * qscale : -INFINITY;
-        const float mx = ff_wave_max(sv);
-        const float pe = ok ? ff_exp2(sv - mx) : 0.f;
-        const float ls = ff_wave_sum(pe);
-        const float pn = ls > 0.f ? pe / ls : 0.f;   // normalised weight of (query i, key lane)
-        if (i < 4) pa[i & 3] = pn; else pb[i & 3] = pn;
-      }
-    }
-    if (lane < 40) {
-      *reinterpret_cast<f32x4*>(Pw + lane * 8) = pa;
-      *reinterpret_cast<f32x4*>(Pw + lane * 8 + 4) = pb;
-    }
-    wave_fence();
-    // values: lane = (head dimension l32 | 32 + l32, key half); the main tile's V fragments are still in v0 / v1
-    float a0[8], a1[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(Pw + key * 8);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(Pw + key * 8 + 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a0[i] += wa[i] * v0[r]; a1[i] += wa[i] * v1[r];
-        a0[4 + i] += wb[i] * v0[r]; a1[4 + i] += wb[i] * v1[r];
-      }
-    }
-    const float once = half == 0 ? 1.f : 0.f;   // the extra keys are not split between the halves
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      if (jj < ktail) {
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(Pw + (32 + jj) * 8);
-        const f32x4 wb = *reinterpret_cast<const f32x4*>(Pw + (32 + jj) * 8 + 4);
-        const float x0 = Vt[jj * 64 + l32] * once, x1 = Vt[jj * 64 + 32 + l32] * once;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a0[i] += wa[i] * x0; a1[i] += wa[i] * x1;
-          a0[4 + i] += wb[i] * x0; a1[4 + i] += wb[i] * x1;
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i < qtail) {
-        const float s0 = a0[i] + __shfl_xor(a0[i], 32, FF_WAVE);
-        const float s1 = a1[i] + __shfl_xor(a1[i], 32, FF_WAVE);
-        const int qx = q_tiles * 32 + i;
-        const size_t xr = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
-        d.o[xr * d.ldo + h * FF_HEAD_DIM + 32 * half + l32] = half ? s1 : s0;
-      }
-    }
-  }
+  __shared__ __attribute__((aligned(16))) float lds[ff_attention_wave_lds_floats(NWAVES)];
+  ff_attention_wave_block<NWAVES, false>(d, q_tiles, ks, total_units, tail_ok, qtail, (long)blockIdx.x, lds);
 }
 
 // ---- K/V-resident variant ------------------------------------------------------------------------------
@@ -943,6 +567,7 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
                "ff_attention: ld smaller than num_heads*64");
   FF_CHECK_ARG(d.q_inner > 0, "ff_attention: q_inner must be positive");
   hipStream_t st = (hipStream_t)stream;
+  if (ff_chain_recording()) return ff_chain_record_attention(d);   // operator of a chain launch (ff_chain.hip)
   const long gh = (long)d.num_groups * d.num_heads;
   int nw = d.nq > 64 ? 4 : (d.nq > 32 ? 2 : 1);
   const int q_tiles = ff_cdiv(d.nq, 32 * nw);

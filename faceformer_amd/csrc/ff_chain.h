@@ -1,0 +1,35 @@
+// Chain kernel (ff_chain.hip): operator descriptors and the host-side recorder.  While a recording is active on the calling
+// thread, ff_gemm_f32* / ff_gemm_f32_ln / ff_attention / ff_layernorm / ff_pointer_argmax APPEND their operator to the chain
+// instead of launching it; ff_chain_end() then enqueues ONE persistent launch that runs the recorded operators in order.
+#pragma once
+#include "ff_common.h"
+#include "ff_device.h"
+
+enum { FF_CH_GEMM = 1, FF_CH_ATTN = 2, FF_CH_LN = 3, FF_CH_PTR = 4 };
+
+struct ff_chain_op {
+  int kind;
+  int barrier;        // 1: a grid-wide phase boundary follows this operator (0: the next one does not depend on it)
+  int units;          // work items dealt round-robin to the workgroups: 32x32 tiles / attention blocks / rows / sequences
+  int aux0, aux1;     // attention: query tiles per (group, head), key split; LayerNorm: float4 chunks per lane
+  long total_units;   // attention: (group, head, query tile) units
+  union {
+    GemmArgs g;
+    ff_attn_desc a;
+    LnArgs ln;
+    PointerArgs p;
+  } u;
+};
+
+bool ff_chain_recording();
+void ff_chain_next_is_independent();   // hint: the next recorded operator may run in the same phase as the previous one
+bool ff_chain_gemm_ok(const GemmArgs& g, int batch);
+int ff_chain_record_gemm(const GemmArgs& g, int batch);
+int ff_chain_record_attention(const ff_attn_desc& d);
+int ff_chain_record_layernorm(const LnArgs& a);
+int ff_chain_record_pointer(const PointerArgs& a);
+int ff_chain_prepare(size_t ops_needed, hipStream_t st);
+int ff_chain_begin();
+void ff_chain_abort();
+int ff_chain_end(hipStream_t st, int* launched);
+int ff_chain_check(hipStream_t st);

@@ -1,0 +1,364 @@
+// Chain kernel: many operators of a decode step inside ONE persistent launch.
+//
+// The first decode steps of the parallel model, every step of the single-sequence model and the last-layer / last-row
+// tail + pointer head of EVERY step are chains of 15..55 small dependent operators (a few hundred rows each): as
+// separate launches each costs 6..15 us for < 1 us of matrix work -- dispatch, a cold first touch of its operands, a
+// fill and a drain.  Here a fixed grid of co-resident workgroups (one per CU, 8 waves) interprets a list of operator
+// descriptors; consecutive dependent operators are separated by a grid-wide phase boundary instead of a kernel boundary:
+//
+//   * operators  = the SAME device code as the stand-alone kernels (ff_device.h), compiled with COH = true: everything
+//                  another workgroup of this launch may have produced is stored write-through (sc1) and loaded with
+//                  agent-scope (sc1) loads, so a boundary needs no cache write-back / invalidate of its own;
+//   * boundary   = every wave drains its stores (s_waitcnt vmcnt(0)), block barrier, ONE lane publishes the block's epoch
+//                  flag (own 64-byte line); workgroup 0 gathers the G flags with G lanes in parallel and publishes a
+//                  release word; one lane per workgroup polls it (relaxed agent loads + s_sleep).  Measured on MI355X
+//                  (tools/ubench/grid_phase.hip): 1.5 us for 256 workgroups, 2.2-2.7 us including the first dependent
+//                  sc1 load round trip -- against 3.6 us for a single contended atomic counter and 5-8 us for a kernel
+//                  boundary with a cold first touch;
+//   * residency  = the grid never exceeds the CU count and nothing else is queued on the stream, so every workgroup is
+//                  resident; every poll loop is bounded, a timeout poisons the release word (later boundaries fall
+//                  through) and is reported by ff_decode as an error instead of hanging the device.
+#include <mutex>
+#include <vector>
+
+#include "ff_common.h"
+#include "ff_device.h"
+#include "ff_chain.h"
+
+namespace {
+
+constexpr int CHAIN_WAVES = 8;
+constexpr int CHAIN_THREADS = 64 * CHAIN_WAVES;
+constexpr unsigned CHAIN_POISON = 0xFFFFFFFFu;
+constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 21;
+
+__host__ __device__ constexpr int chain_lds_floats() {
+  return ff_attention_wave_lds_floats(CHAIN_WAVES) > ff_gemm_small_lds_floats(2, CHAIN_WAVES) + 64
+             ? ff_attention_wave_lds_floats(CHAIN_WAVES)
+             : ff_gemm_small_lds_floats(2, CHAIN_WAVES) + 64;
+}
+
+struct ChainSync {
+  unsigned* flags;     // [G][16] epoch of workgroup b at flags[16 b]; release word at flags[16 G + 16]; error word at [16 G + 32]
+};
+
+__device__ __forceinline__ unsigned chain_ld(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_st(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// bounded poll: true when *p >= target was observed
+__device__ __forceinline__ bool chain_wait_ge(const unsigned* p, unsigned target) {
+  for (unsigned n = 0; n < CHAIN_SPIN_LIMIT; ++n) {
+    if (chain_ld(p) >= target) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+// grid-wide phase boundary (see the file header); epoch = 1, 2, 3, ... over the life of the sync words
+__device__ __forceinline__ void chain_boundary(const ChainSync& s, int G, unsigned epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have left the CU
+  __syncthreads();
+  unsigned* release = s.flags + 16 * G + 16;
+  unsigned* err = s.flags + 16 * G + 32;
+  if (threadIdx.x == 0) chain_st(s.flags + 16 * blockIdx.x, epoch);
+  if (blockIdx.x == 0) {
+    bool ok = true;
+    if (chain_ld(release) != CHAIN_POISON) {
+      for (int b = threadIdx.x; b < G; b += blockDim.x) ok = chain_wait_ge(s.flags + 16 * b, epoch) && ok;
+    }
+    const int all_ok = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) {
+      if (!all_ok) { chain_st(err, 1u); chain_st(release, CHAIN_POISON); }
+      else if (chain_ld(release) != CHAIN_POISON) chain_st(release, epoch);
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (!chain_wait_ge(release, epoch)) { chain_st(err, 2u); chain_st(release, CHAIN_POISON); }
+  }
+  __syncthreads();
+}
+
+// Every operator is its own (non-inlined) function: the register allocation of the attention unit (218 VGPRs alone) then does
+// not have to carry the interpreter's state and the other operators' descriptors across its body (inlined, the launch
+// spilled 65-96 VGPRs inside the operator bodies; as functions the only scratch traffic is the attention operator's
+// callee-saved registers, once per operator).  The dynamic LDS block is re-declared inside each one, so LDS accesses stay
+// ds_* instructions.
+template <int MODE>
+__device__ __attribute__((noinline)) void chain_op_gemm(const ff_chain_op* __restrict__ opp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GemmArgs g = opp->u.g;
+  const int units = opp->units;
+  const int G = gridDim.x;
+  const int per = g.tiles_m * g.tiles_n;
+  for (int u = blockIdx.x; u < units; u += G) {
+    const int bz = u / per, tile = u - bz * per;
+    switch (g.K) {
+      case 128: ff_gemm_small_tile<16, MODE, CHAIN_WAVES, true>(g, tile, bz, lds); break;
+      case 256: ff_gemm_small_tile<32, MODE, CHAIN_WAVES, true>(g, tile, bz, lds); break;
+      case 512: ff_gemm_small_tile<64, MODE, CHAIN_WAVES, true>(g, tile, bz, lds); break;
+      default: ff_gemm_small_tile<128, MODE, CHAIN_WAVES, true>(g, tile, bz, lds); break;   // 1024 (checked on the host)
+    }
+    __syncthreads();   // the partial-tile area is rewritten by the next tile
+  }
+}
+
+__device__ __attribute__((noinline)) void chain_op_attention(const ff_chain_op* __restrict__ opp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const ff_attn_desc d = opp->u.a;
+  const int units = opp->units, q_tiles = opp->aux0, ks = opp->aux1;
+  const long total_units = opp->total_units;
+  const int G = gridDim.x;
+  for (int vb = blockIdx.x; vb < units; vb += G) {
+    ff_attention_wave_block<CHAIN_WAVES, true>(d, q_tiles, ks, total_units, 0, 0, (long)vb, lds);
+    __syncthreads();   // a wave's K patch doubles as its combine record: all reads done before the next unit writes
+  }
+}
+
+__device__ __attribute__((noinline)) void chain_op_layernorm(const ff_chain_op* __restrict__ opp) {
+  const LnArgs a = opp->u.ln;
+  const int nv = opp->aux0;
+  const int G = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * CHAIN_WAVES + wave; row < a.rows; row += G * CHAIN_WAVES) {
+    if (nv <= 1) ff_layernorm_row<1, true>(a, row, lane);
+    else if (nv <= 2) ff_layernorm_row<2, true>(a, row, lane);
+    else if (nv <= 4) ff_layernorm_row<4, true>(a, row, lane);
+    else ff_layernorm_row<8, true>(a, row, lane);
+  }
+}
+
+__device__ __attribute__((noinline)) void chain_op_pointer(const ff_chain_op* __restrict__ opp) {
+  const PointerArgs a = opp->u.p;
+  const int G = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int b = blockIdx.x * CHAIN_WAVES + wave; b < a.B; b += G * CHAIN_WAVES) ff_pointer_reduce_row<true>(a, b, lane);
+}
+
+__global__ __launch_bounds__(CHAIN_THREADS, 1) void chain_kernel(const ff_chain_op* __restrict__ ops, int nops, ChainSync sync,
+                                                                 unsigned epoch0) {
+  const int G = gridDim.x;
+  unsigned epoch = epoch0;
+  for (int i = 0; i < nops; ++i) {
+    const ff_chain_op* op = ops + i;
+    const int kind = op->kind;
+    if (kind == FF_CH_GEMM) {
+      const int mode = op->u.g.ln_in ? 1 : (op->u.g.ln_out ? 2 : 0);
+      if (mode == 1) chain_op_gemm<1>(op);
+      else if (mode == 2) chain_op_gemm<2>(op);
+      else chain_op_gemm<0>(op);
+    } else if (kind == FF_CH_ATTN) {
+      chain_op_attention(op);
+    } else if (kind == FF_CH_LN) {
+      chain_op_layernorm(op);
+    } else if (kind == FF_CH_PTR) {
+      chain_op_pointer(op);
+    }
+    if (op->barrier && i + 1 < nops) {
+      ++epoch;
+      chain_boundary(sync, G, epoch);
+    }
+  }
+}
+
+// ---- host side: per-device context and the recorder ---------------------------------------------------------------------
+struct ChainCtx {
+  bool ready = false;
+  int G = 0;
+  ff_chain_op* host_ops = nullptr;   // pinned
+  ff_chain_op* dev_ops = nullptr;
+  size_t cap_ops = 0, used_ops = 0;
+  unsigned* flags = nullptr;
+  unsigned epoch = 0;
+  bool attr_done = false;
+};
+constexpr int CHAIN_MAX_DEV = 16;
+ChainCtx g_ctx[CHAIN_MAX_DEV];
+std::mutex g_chain_mu;
+
+struct Recorder {
+  bool active = false;
+  bool failed = false;
+  bool skip_barrier = false;     // hint: the NEXT recorded operator does not depend on the previous one
+  double flops = 0;
+  std::vector<ff_chain_op> ops;
+};
+thread_local Recorder t_rec;
+
+int ctx_get(ChainCtx** out) {
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  FF_CHECK_ARG(dev >= 0 && dev < CHAIN_MAX_DEV, "ff_chain: device index %d out of range", dev);
+  *out = &g_ctx[dev];
+  return FF_OK;
+}
+
+}  // namespace
+
+bool ff_chain_recording() { return t_rec.active; }
+void ff_chain_next_is_independent() { if (t_rec.active) t_rec.skip_barrier = true; }
+
+static void chain_push(ff_chain_op& op, double flops) {
+  op.barrier = 1;
+  if (t_rec.skip_barrier && !t_rec.ops.empty()) t_rec.ops.back().barrier = 0;
+  t_rec.skip_barrier = false;
+  t_rec.flops += flops;
+  t_rec.ops.push_back(op);
+}
+
+bool ff_chain_gemm_ok(const GemmArgs& g, int batch) {
+  const bool k_ok = g.K == 128 || g.K == 256 || g.K == 512 || g.K == 1024;
+  const long tiles = (long)ff_cdiv(g.M, 32) * ff_cdiv(g.N, 32) * batch;
+  return k_ok && (!g.A2 || (g.n_split % 32) == 0) && tiles < (1L << 30) && !(g.ln_in && g.ln_out) &&
+         (!g.ln_in || (g.ln_nseg >= 2 && g.ln_nseg <= 16 && (g.ln_nseg & 1) == 0));
+}
+
+int ff_chain_record_gemm(const GemmArgs& g_in, int batch) {
+  if (!ff_chain_gemm_ok(g_in, batch)) { t_rec.failed = true; return FF_OK; }
+  ff_chain_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = FF_CH_GEMM;
+  op.u.g = g_in;
+  op.u.g.tiles_m = ff_cdiv(g_in.M, 32);
+  op.u.g.tiles_n = ff_cdiv(g_in.N, 32);
+  op.units = op.u.g.tiles_m * op.u.g.tiles_n * batch;
+  chain_push(op, 2.0 * g_in.M * g_in.N * g_in.K * batch);
+  return FF_OK;
+}
+
+int ff_chain_record_attention(const ff_attn_desc& d) {
+  ff_chain_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = FF_CH_ATTN;
+  op.u.a = d;
+  const long gh = (long)d.num_groups * d.num_heads;
+  const int qt = ff_cdiv(d.nq, 32);
+  const long units = gh * qt;
+  const int key_tiles = ff_cdiv(d.nk, 32);
+  // key tiles of a unit are dealt to ks waves while the launch would otherwise leave wave slots idle
+  int ks = 1;
+  while (ks < CHAIN_WAVES && units * ks * 2 <= 2048 && ks < key_tiles) ks *= 2;
+  const long per_block = CHAIN_WAVES / ks;
+  const long nblocks = (units + per_block - 1) / per_block;
+  if (nblocks >= (1L << 30)) { t_rec.failed = true; return FF_OK; }
+  op.aux0 = qt; op.aux1 = ks;
+  op.total_units = units;
+  op.units = (int)nblocks;
+  chain_push(op, 4.0 * FF_HEAD_DIM * (double)gh * d.nq * d.nk);
+  return FF_OK;
+}
+
+int ff_chain_record_layernorm(const LnArgs& a) {
+  ff_chain_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = FF_CH_LN;
+  op.u.ln = a;
+  op.aux0 = ff_cdiv(a.E / 4, 64);
+  op.units = a.rows;
+  chain_push(op, 0.0);
+  return FF_OK;
+}
+
+int ff_chain_record_pointer(const PointerArgs& a) {
+  ff_chain_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = FF_CH_PTR;
+  op.u.p = a;
+  op.units = a.B;
+  chain_push(op, 0.0);
+  return FF_OK;
+}
+
+// Make room for `ops_needed` descriptors in the context of the current device and reset its ring and sync words (called once
+// per decode, before anything is enqueued; the previous decode on this device has been synchronised).
+int ff_chain_prepare(size_t ops_needed, hipStream_t st) {
+  ChainCtx* c;
+  FF_RETURN_IF(ctx_get(&c));
+  std::lock_guard<std::mutex> lock(g_chain_mu);
+  if (!c->ready) {
+    int dev = 0, cus = 0;
+    FF_CHECK_HIP(hipGetDevice(&dev));
+    FF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    c->G = cus < 256 ? (cus > 0 ? cus : 1) : 256;
+    FF_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c->flags), (size_t)(c->G + 4) * 64));
+    c->ready = true;
+  }
+  if (ops_needed > c->cap_ops) {
+    FF_CHECK_HIP(hipDeviceSynchronize());
+    if (c->host_ops) (void)hipHostFree(c->host_ops);
+    if (c->dev_ops) (void)hipFree(c->dev_ops);
+    c->host_ops = nullptr; c->dev_ops = nullptr; c->cap_ops = 0;
+    FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->host_ops), ops_needed * sizeof(ff_chain_op), hipHostMallocDefault));
+    FF_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c->dev_ops), ops_needed * sizeof(ff_chain_op)));
+    c->cap_ops = ops_needed;
+  }
+  c->used_ops = 0;
+  c->epoch = 0;
+  FF_CHECK_HIP(hipMemsetAsync(c->flags, 0, (size_t)(c->G + 4) * 64, st));
+  return FF_OK;
+}
+
+int ff_chain_begin() {
+  t_rec.active = true;
+  t_rec.failed = false;
+  t_rec.skip_barrier = false;
+  t_rec.flops = 0;
+  t_rec.ops.clear();
+  return FF_OK;
+}
+
+void ff_chain_abort() {
+  t_rec.active = false;
+  t_rec.ops.clear();
+}
+
+// Ends the recording and enqueues ONE launch that runs the recorded operators.  *launched = 0 when nothing was launched
+// (an operator did not fit the chain forms, or the ring is full): the caller then enqueues the operators one by one.
+int ff_chain_end(hipStream_t st, int* launched) {
+  *launched = 0;
+  t_rec.active = false;
+  if (t_rec.failed || t_rec.ops.empty()) { t_rec.ops.clear(); return FF_OK; }
+  ChainCtx* c;
+  FF_RETURN_IF(ctx_get(&c));
+  const size_t n = t_rec.ops.size();
+  if (!c->ready || c->used_ops + n > c->cap_ops) { t_rec.ops.clear(); return FF_OK; }
+  if (!c->attr_done) {
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     chain_lds_floats() * (int)sizeof(float)));
+    c->attr_done = true;
+  }
+  ff_chain_op* h = c->host_ops + c->used_ops;
+  ff_chain_op* d = c->dev_ops + c->used_ops;
+  memcpy(h, t_rec.ops.data(), n * sizeof(ff_chain_op));
+  c->used_ops += n;
+  FF_CHECK_HIP(hipMemcpyAsync(d, h, n * sizeof(ff_chain_op), hipMemcpyHostToDevice, st));
+  unsigned barriers = 0;
+  for (size_t i = 0; i + 1 < n; ++i) barriers += t_rec.ops[i].barrier ? 1u : 0u;
+  ChainSync s{c->flags};
+  {
+    FFProfScope prof(FF_CAT_CHAIN, t_rec.flops, st);
+    hipLaunchKernelGGL(chain_kernel, dim3(c->G), dim3(CHAIN_THREADS), chain_lds_floats() * sizeof(float), st, d, (int)n, s,
+                       c->epoch);
+    FF_CHECK_LAUNCH();
+  }
+  c->epoch += barriers;
+  t_rec.ops.clear();
+  *launched = 1;
+  return FF_OK;
+}
+
+// error word of the current device's sync area (0 = no boundary ever timed out); synchronises `st`
+int ff_chain_check(hipStream_t st) {
+  ChainCtx* c;
+  FF_RETURN_IF(ctx_get(&c));
+  if (!c->ready) return FF_OK;
+  unsigned err = 0;
+  FF_CHECK_HIP(hipMemcpyAsync(&err, c->flags + 16 * c->G + 32, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  FF_CHECK_HIP(hipStreamSynchronize(st));
+  if (err != 0) {
+    ff_set_error("ff_decode: a grid-wide phase boundary of the chain kernel timed out (code %u): the workgroups of the launch were "
+                 "not all resident (another process on the device?); re-run without FF_CHAIN", err);
+    return FF_ERR_LAUNCH;
+  }
+  return FF_OK;
+}

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "ff_common.h"
+#include "ff_chain.h"
 
 namespace {
 
@@ -126,7 +127,8 @@ int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, 
   // x3_min_rows is the threshold of the widest product (N >= 1536: 112 vs 104 TF/s at 4096 rows); the K = 1024
   // product needs 1.5x, the N = 1024 one 2x and the N = K = 512 ones 4x as many rows before the larger tiles pay
   const long need = (long)prm->x3_min_rows * (N >= 1536 ? 2 : (K >= 1024 ? 3 : (N >= 1024 ? 4 : 8))) / 2;
-  if (planes && prm->x3_min_rows > 0 && M >= need && (K % 32) == 0 && K >= 64 && (!A2 || (n_split % 128) == 0))
+  if (planes && prm->x3_min_rows > 0 && M >= need && (K % 32) == 0 && K >= 64 && (!A2 || (n_split % 128) == 0) &&
+      !ff_chain_recording())   // (a chain launch runs every projection on the small-M f32 kernel)
     return ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
   return gemm(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, st);
 }
@@ -258,9 +260,12 @@ bool can_fuse_layernorm(const ff_model* m, const ff_decode_params* prm) {
 // by a projection with a residual (out-proj, linear2), which leaves per-row segment statistics in `lnstat`; the
 // projection that consumes LN(x) (+ qpos) reads x and the statistics and applies gamma / beta / qpos W^T through
 // folded weights (ff_gemm_f32_ln).  19 -> 1 LayerNorm launches per decode step of a 6-layer decoder.
+// phase: 0 the whole pass; 1 only its HEAD -- every layer but the last, and the self-attention q|k|v projections of the last
+// layer (the launches that still have all t * Bc rows when the last layer is pruned to its newest position); 2 only the TAIL
+// -- the rest of the last layer, decoder.norm and project (Bc rows each: what a chain launch takes over on the large steps).
 int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuffers& bufs, const Scratch& buf,
                  const Chunk& ck, const unsigned char* mask, const int* kv_len, int t, bool full_rows,
-                 float* proj_all, hipStream_t st) {
+                 float* proj_all, hipStream_t st, int phase = 0) {
   const int E = m->E, FFd = m->FF, H = m->H, S = prm->L + m->num_token, F = ck.Fc, T = prm->T;
   const int Bc = ck.Bc, R = t * Bc, nd = m->num_dec_layers;
   const size_t newoff = (size_t)(t - 1) * Bc;
@@ -290,13 +295,15 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     return ff_gemm_f32_ln(&d, st);
   };
 
-  for (int l = 0; l < nd; ++l) {
+  for (int l = (phase == 2 ? nd - 1 : 0); l < nd; ++l) {
     const ff_layer_weights& w = m->dec[l];
     const bool last = prune_last && (l == nd - 1);
     const float* xin = (l == 0) ? ck.x0 : buf.x;
     const float* QKV;
     // ---- self attention: q = k = LN1(x) + qpos, v = LN1(x), no mask (transformer.py:242-246) ----
-    if (l == 0 && reuse0) {
+    if (phase == 2) {   // the head already projected q|k|v of this (last) layer
+      QKV = (l == 0 && reuse0) ? ck.qkv0 : buf.qkv;
+    } else if (l == 0 && reuse0) {
       FF_RETURN_IF(ff_layernorm(xin + newoff * E, E, w.norm1_w, w.norm1_b, m->ln_eps, buf.y, E, buf.yq, E,
                                 qpos_new, E, Bc, 1, Bc, E, st));
       FF_RETURN_IF(gemm(buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
@@ -307,6 +314,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
         // the pruned last layer attends from its newest position only: k | v for every row, q for the last Bc rows
         FF_RETURN_IF(gemm_ln(xin, E, w.ln1_w + (size_t)E * E, E, w.ln1_b + E, nullptr, 0, buf.qkv + E, 3 * E, R, 2 * E, E,
                              0, buf.lnstat, w.ln1_pos + E, 2 * E, E, nullptr));
+        ff_chain_next_is_independent();   // (chain launches: k|v and q share a phase)
         FF_RETURN_IF(gemm_ln(xin + newoff * E, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E,
                              0, buf.lnstat + newoff * nseg * 2, w.ln1_pos + (size_t)(t - 1) * 2 * E, 2 * E, E, nullptr));
       } else {
@@ -323,6 +331,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
         // pruned last layer: k (from LN(x)+qpos) | v (from LN(x)) for every row, q for the newest position only
         FF_RETURN_IF(gemm(buf.yq, E, buf.y, E, w.self_attn.in_proj_w + (size_t)E * E, E, w.self_attn.in_proj_b + E, nullptr,
                           0, buf.qkv + E, 3 * E, R, 2 * E, E, 0, st));
+        ff_chain_next_is_independent();
         FF_RETURN_IF(gemm(buf.yq + newoff * E, E, nullptr, 0, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
                           buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E, 0, st));
       } else {
@@ -331,6 +340,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       }
       QKV = buf.qkv;
     }
+    if (phase == 1 && l == nd - 1) return FF_OK;
     // rows that continue through the rest of this layer
     const size_t roff = last ? newoff : 0;
     const int Rl = last ? Bc : R;
@@ -604,6 +614,12 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     return FF_OK;
   };
 
+  // Chain launches need every workgroup of the launch resident: one stream only (two chain launches interleaving on the
+  // CUs could wait for each other for ever), and operand widths the small-M projection forms take.
+  auto chain_dim_ok = [](int k) { return k == 128 || k == 256 || k == 512 || k == 1024; };
+  const bool use_chain = (p->flags & FF_CHAIN) && ns == 1 && chain_dim_ok(E) && chain_dim_ok(m->FF) && getenv("FF_NO_CHAIN") == nullptr;
+  const long chain_rows = p->chain_max_rows > 0 ? p->chain_max_rows : 1024;
+  int chain_launches = 0;
   int enq = 0;
   // Everything that enqueues work on the side streams sits in this lambda: on ANY failure the streams are
   // drained before the error is returned (the caller frees the workspace the queued kernels use).
@@ -634,6 +650,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
 
     // ---- greedy loop -----------------------------------------------------------------------------------
     const int max_steps = T - 1;
+    if (use_chain)   // descriptor ring + sync words of this decode (zeroed behind the work queued so far)
+      FF_RETURN_IF(ff_chain_prepare((size_t)max_steps * chunks.size() * (size_t)(12 * m->num_dec_layers + 16), main_st));
     const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
     // Stop rule on the host WITHOUT draining the queue: every sync_every steps the counters of the steps enqueued so
@@ -658,14 +676,38 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       for (const Chunk& c : chunks) {
         hipStream_t st = sts[c.sid];
         const Scratch& sc = buf.scr[c.sid];
-        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
         const size_t trow = (size_t)step * ((size_t)N * F) + c.b0;  // traces: step stride N*F (caller sizes them so)
-        FF_RETURN_IF(ff_pointer_argmax(
-            sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
-            extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,
-            buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
-            trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
-            c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st));
+        auto pointer_head = [&]() -> int {
+          return ff_pointer_argmax(
+              sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
+              extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,
+              buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
+              trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
+              c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st);
+        };
+        // Chain launches (FF_CHAIN): a step with at most chain_rows active rows is ONE persistent launch; a larger step
+        // launches its head operator by operator and hands the last layer's newest-position tail + the pointer head (Bc
+        // rows each) to one chain launch.  An operator the chain forms cannot take leaves the recording unlaunched and
+        // the same operators are enqueued one by one.
+        int phase_done = 0;   // 0 nothing enqueued yet, 1 head enqueued, 2 everything enqueued
+        if (use_chain) {
+          const bool whole = (long)t * c.Bc <= chain_rows;
+          const bool tail = !whole && (p->flags & FF_LAST_LAYER_LAST_ROW) && c.Bc <= chain_rows;
+          if (whole || tail) {
+            int launched = 0;
+            if (tail) { FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, 1)); phase_done = 1; }
+            FF_RETURN_IF(ff_chain_begin());
+            int rc = decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, tail ? 2 : 0);
+            if (rc == FF_OK) rc = pointer_head();
+            if (rc != FF_OK) { ff_chain_abort(); return rc; }
+            FF_RETURN_IF(ff_chain_end(st, &launched));
+            if (launched) { phase_done = 2; ++chain_launches; }
+          }
+        }
+        if (phase_done < 2) {
+          FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, phase_done == 1 ? 2 : 0));
+          FF_RETURN_IF(pointer_head());
+        }
       }
       enq = step + 1;
       if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
@@ -740,6 +782,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
                                   sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
     FF_CHECK_HIP(hipStreamSynchronize(main_st));
     if (steps_done) *steps_done = steps;
+    if (chain_launches > 0) FF_RETURN_IF(ff_chain_check(main_st));   // a phase boundary that timed out voids the results
 
     // ---- optional: project(decoder(...)) of every prefix row at the last executed step
     //      (SurfaceFormer returns it as inputs['pointer'], reference model.py:217) --------------------

@@ -30,29 +30,11 @@
 #include <vector>
 
 #include "ff_common.h"
+#include "ff_device.h"
+#include "ff_chain.h"
 
 namespace {
 
-struct GemmArgs {
-  const float* A;
-  const float* A2;
-  const float* W;
-  const float* bias;
-  const float* res;
-  float* C;
-  int lda, ldw, ldr, ldc;
-  int M, N, K;
-  int n_split, act;
-  int tiles_m, tiles_n;
-  long long batch_stride_a, batch_stride_w, batch_stride_c;  // per-problem offsets (elements)
-  // LayerNorm fusion (persistent / stream-K / small-M kernels only; batch == 1):
-  const float* ln_in;   // MODE 1: [M][ln_nseg][2] (mean, M2 over 32 columns) segment statistics of the A rows
-  int ln_nseg;
-  float ln_eps;
-  const float* rowtab;  // MODE 1: C[m][n] += rowtab[(m / rowtab_div) * ld_rowtab + n] for n < rowtab_cols (no residual then)
-  int ld_rowtab, rowtab_div, rowtab_cols;
-  float* ln_out;        // MODE 2: [M][N/32][2] segment statistics of the stored C rows
-};
 
 // Row statistics of a LayerNorm input from the per-32-column (mean, M2) partials its producer left behind:
 // Chan's parallel update for equal-sized parts (no E[x^2] - mean^2 cancellation).  -> (mean, 1/sqrt(var + eps)).
@@ -63,7 +45,6 @@ struct GemmArgs {
 // at most 4), the partial sums meet through DPP moves inside the group of 8 lanes.  The raw loads are issued
 // when the load cursor enters a tile and consumed ~3 slices later (ff_ln_finish), so their latency never sits
 // in front of the MFMA chain.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int LN_NQ = 2;                     // segments per lane: ln_nseg <= 8 * LN_NQ, i.e. K <= 512 for the fused consumer
 struct LnRaw { f32x2 seg[LN_NQ]; };          // (mean, M2) pairs exactly as loaded: no register shuffling behind the loads
 __device__ __forceinline__ void ff_ln_issue(const float* __restrict__ st, int nseg, int c, LnRaw& r) {
@@ -72,12 +53,6 @@ __device__ __forceinline__ void ff_ln_issue(const float* __restrict__ st, int ns
     const int sidx = c + 8 * q;
     r.seg[q] = *reinterpret_cast<const f32x2*>(st + 2 * (sidx < nseg ? sidx : 0));
   }
-}
-__device__ __forceinline__ float ff_sum8(float v) {  // sum over the aligned group of 8 lanes, result on all of them
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  return v;
 }
 __device__ __forceinline__ void ff_ln_finish(const LnRaw& r, int nseg, int c, float eps, float& mean, float& rstd) {
   float sm = 0.f, m2 = 0.f;
@@ -1132,139 +1107,8 @@ int sk_acquire(hipStream_t st, StreamK* out) {
 // launch -- halves (K = 512: 64 -> 32 MFMAs, 1.7 -> 0.85 us).
 template <int KQ, int MODE, int NW>  // MODE as gemm_persist_kernel
 __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  constexpr int RPW = 16 / NW;  // accumulator registers (tile rows x 2 halves) a wave finishes
-  __shared__ __attribute__((aligned(16))) float red[NW * 16 * 64 + (MODE == 2 ? 32 * 33 : 0) + (MODE == 1 ? 64 : 0)];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
-  const int m0 = (blockIdx.x / g.tiles_n) * 32, n0 = (blockIdx.x % g.tiles_n) * 32;
-  const long long bz = blockIdx.y;
-  const float* Asrc = ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + bz * g.batch_stride_a;
-  int row = m0 + l32, col = n0 + l32;
-  row = row < g.M ? row : g.M - 1;
-  col = col < g.N ? col : g.N - 1;
-  const float* ap = Asrc + (size_t)row * g.lda + wave * KQ + half * 4;
-  const float* wp = g.W + bz * g.batch_stride_w + (size_t)col * g.ldw + wave * KQ + half * 4;
-  // Loads first: the wave's first operand groups, bias and the epilogue's residual / table values are in flight
-  // before anything is waited for; the row statistics (MODE 1) are merged ONCE per block -- wave w takes 32 / NW rows,
-  // eight lanes per row, one 16-byte load each -- and handed round through LDS (every wave loading every row's
-  // segments itself was half of the kernel's load requests).
-#ifndef FF_SMALL_V
-#define FF_SMALL_V 2
-#endif
-  constexpr int V = FF_SMALL_V;            // 1: all operand loads before the first MFMA; 2: groups of 4 k-groups, pipelined
-  constexpr int NG = KQ / 8;               // 8-wide k groups per wave
-  constexpr int GB = (V == 1) ? (NG < 16 ? NG : 16) : (NG < 4 ? NG : 4);   // groups per batch
-  f32x4 a[2][GB], b[2][GB];
-#pragma unroll
-  for (int j = 0; j < GB; ++j) {
-    a[0][j] = *reinterpret_cast<const f32x4*>(ap + j * 8);
-    b[0][j] = *reinterpret_cast<const f32x4*>(wp + j * 8);
-  }
-  float* lnrow = red + NW * 16 * 64 + (MODE == 2 ? 32 * 33 : 0);   // MODE 1: [32][2] (mean, rstd)
-  f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-  const int spart = lane & 7, srow = wave * (32 / NW) + ((lane >> 3) % (32 / NW));
-  if (MODE == 1) {
-    int r = m0 + srow;
-    r = r < g.M ? r : g.M - 1;
-    if (2 * spart < g.ln_nseg) sv = *reinterpret_cast<const f32x4*>(g.ln_in + ((size_t)r * g.ln_nseg + 2 * spart) * 2);
-  }
-  const int ocol = n0 + l32;
-  const bool colok = ocol < g.N;
-  const float bv = (g.bias && colok) ? g.bias[ocol] : 0.f;
-  const bool tab = MODE == 1 && g.rowtab != nullptr && !g.res;
-  float rv[RPW];
-  int orow[RPW], prow[RPW];
-#pragma unroll
-  for (int q = 0; q < RPW; ++q) {
-    const int e = wave * RPW + q;
-    prow[q] = (e & 3) + 8 * (e >> 2) + 4 * half;
-    orow[q] = m0 + prow[q];
-    const bool ok = colok && orow[q] < g.M;
-    rv[q] = 0.f;
-    if (g.res) { if (ok) rv[q] = g.res[bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol]; }
-    else if (tab && ok && ocol < g.rowtab_cols)
-      rv[q] = g.rowtab[(size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  float mu = 0.f, rs = 1.f;
-  if (MODE == 1) {
-    // Chan's update over the row's 32-column segments, two per lane, eight lanes per row (ln_nseg even, <= 16)
-    const bool sok = 2 * spart < g.ln_nseg;
-    const float fn = (float)g.ln_nseg;
-    const float mean = ff_sum8(sok ? sv.x + sv.z : 0.f) / fn;
-    const float m2 = ff_sum8(sok ? sv.y + sv.w : 0.f);
-    const float d0 = sv.x - mean, d1 = sv.z - mean;
-    const float dev = ff_sum8(sok ? d0 * d0 + d1 * d1 : 0.f);
-    const float var = (m2 + 32.f * dev) / (32.f * fn);
-    if (spart == 0 && lane < 8 * (32 / NW)) *reinterpret_cast<f32x2*>(lnrow + 2 * srow) = f32x2{mean, 1.0f / sqrtf(var + g.ln_eps)};
-    __syncthreads();
-    const f32x2 ms = *reinterpret_cast<const f32x2*>(lnrow + 2 * l32);
-    mu = ms.x;
-    rs = ms.y;
-  }
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-  for (int g0 = 0; g0 < NG; g0 += GB) {
-    const int cur = (g0 / GB) & 1;
-    if (g0 + GB < NG) {
-#pragma unroll
-      for (int j = 0; j < GB; ++j) {
-        a[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(ap + (g0 + GB + j) * 8);
-        b[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(wp + (g0 + GB + j) * 8);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < GB; ++j) {
-      f32x4 av = a[cur][j];
-      if (MODE == 1) av = (av - mu) * rs;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], b[cur][j][c], acc, 0, 0, 0);
-    }
-  }
-  // partial tiles -> LDS [wave][reg][lane]; wave w then finishes registers RPW*w .. RPW*w + RPW-1
-#pragma unroll
-  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
-  __syncthreads();
-  float* Cout = g.C + bz * g.batch_stride_c;
-  float v[RPW];
-#pragma unroll
-  for (int q = 0; q < RPW; ++q) {
-    const int e = wave * RPW + q;
-    v[q] = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
-           (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
-    if (NW == 8)
-      v[q] += (red[(4 * 16 + e) * 64 + lane] + red[(5 * 16 + e) * 64 + lane]) +
-              (red[(6 * 16 + e) * 64 + lane] + red[(7 * 16 + e) * 64 + lane]);
-  }
-  float* patch = red + NW * 16 * 64;
-#pragma unroll
-  for (int q = 0; q < RPW; ++q) {
-    float o = v[q] + bv + (tab ? rv[q] : 0.f);
-    if (g.act == 1) o = fmaxf(o, 0.f);
-    if (!tab) o += rv[q];
-    if (colok && orow[q] < g.M) Cout[(size_t)orow[q] * g.ldc + ocol] = o;
-    if (MODE == 2) patch[prow[q] * 33 + l32] = o;
-  }
-  if (MODE == 2) {  // row statistics of the finished 32x32 tile: 64 threads, (row, column half) each
-    __syncthreads();
-    if (tid < 64) {
-      float x[16], sm = 0.f;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) { x[c] = patch[l32 * 33 + half * 16 + c]; sm += x[c]; }
-      sm += __shfl_xor(sm, 32, FF_WAVE);
-      const float mean = sm * (1.0f / 32.0f);
-      float m2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) { const float d = x[c] - mean; m2 += d * d; }
-      m2 += __shfl_xor(m2, 32, FF_WAVE);
-      const int r = m0 + l32;
-      if (half == 0 && r < g.M) {
-        *reinterpret_cast<f32x2*>(g.ln_out + ((size_t)r * (g.N >> 5) + (n0 >> 5)) * 2) = f32x2{mean, m2};
-      }
-    }
-  }
+  __shared__ __attribute__((aligned(16))) float red[ff_gemm_small_lds_floats(MODE, NW)];
+  ff_gemm_small_tile<KQ, MODE, NW, false>(g, (int)blockIdx.x, (long long)blockIdx.y, red);
 }
 
 #ifndef FF_SMALL_WIDE_BLOCKS
@@ -1375,6 +1219,7 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
   if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
   if (tile == 5 && !split128) tile = 4;
   const int M = g.M, N = g.N, K = g.K;
+  if (ff_chain_recording()) return ff_chain_record_gemm(g, batch);   // operator of a chain launch (ff_chain.hip)
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
   ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (g.res ? 2 : 1)));
   switch (tile) {

@@ -10,19 +10,11 @@
 #include <float.h>
 
 #include "ff_common.h"
+#include "ff_device.h"
+#include "ff_chain.h"
 
 namespace {
 
-struct PointerArgs {
-  const float* p; int ldp;
-  const float* memory; int S, E;
-  const unsigned char* mask; const int* kv_len;
-  const unsigned char* extra; int ldextra;
-  int B, spg;
-  int* next_tok; float* best; float* second; float* logits; int ldlogits;
-  float* next_rows; int ldnext;
-  int* count_ge; int ge_bound; int* count_eq; int eq_value;
-};
 
 template <int NV>
 __global__ __launch_bounds__(256) void pointer_kernel(PointerArgs a) {
@@ -127,54 +119,12 @@ __global__ __launch_bounds__(256) void pointer_kernel(PointerArgs a) {
   }
 }
 
-// GEMM path, stage 2: `logits` holds the raw dot products of every (sequence, key); mask the row in
-// place and reduce (value, index) pairs -- per lane over its strided keys, then across the 64 lanes
-// with a butterfly that keeps torch's tie rule (lowest index) and the runner-up value.
+// GEMM path, stage 2 (ff_pointer_reduce_row, ff_device.h): mask the raw logit row in place and reduce it.
 __global__ __launch_bounds__(256) void pointer_reduce_kernel(PointerArgs a) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= a.B) return;
-  const int w = b / a.spg;
-  int kv = a.S;
-  if (a.kv_len) { const int k = a.kv_len[w]; kv = k < kv ? k : kv; }
-  const unsigned char* mrow = a.mask ? a.mask + (size_t)w * a.S : nullptr;
-  const unsigned char* erow = a.extra ? a.extra + (size_t)b * a.ldextra : nullptr;
-  float* lrow = a.logits + (size_t)b * a.ldlogits;
-  const float FILL = -FLT_MAX;
-  float b1 = -INFINITY, b2 = -INFINITY;
-  int i1 = 0x7fffffff;
-  for (int s = lane; s < a.S; s += 64) {
-    bool ok = s < kv;
-    if (ok && mrow) ok = mrow[s] == 0;
-    if (ok && erow) ok = erow[s] == 0;
-    const float v = ok ? lrow[s] : FILL;
-    lrow[s] = v;
-    if (v > b1) { b2 = b1; b1 = v; i1 = s; }
-    else if (v > b2) b2 = v;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ob1 = __shfl_xor(b1, off, FF_WAVE), ob2 = __shfl_xor(b2, off, FF_WAVE);
-    const int oi1 = __shfl_xor(i1, off, FF_WAVE);
-    const bool other = (ob1 > b1) || (ob1 == b1 && oi1 < i1);
-    const float nb2 = other ? fmaxf(ob2, b1) : fmaxf(b2, ob1);
-    if (other) { b1 = ob1; i1 = oi1; }
-    b2 = nb2;
-  }
-  if (i1 == 0x7fffffff) { i1 = 0; b1 = FILL; }
-  if (lane == 0) {
-    a.next_tok[b] = i1;
-    if (a.best) a.best[b] = b1;
-    if (a.second) a.second[b] = b2;
-    if (a.count_ge && i1 >= a.ge_bound) atomicAdd(a.count_ge, 1);
-    if (a.count_eq && i1 == a.eq_value) atomicAdd(a.count_eq, 1);
-  }
-  if (a.next_rows) {
-    const float* src = a.memory + ((size_t)w * a.S + i1) * a.E;
-    float* dst = a.next_rows + (size_t)b * a.ldnext;
-    for (int vi = lane; vi < (a.E >> 2); vi += 64)
-      *reinterpret_cast<f32x4*>(dst + vi * 4) = *reinterpret_cast<const f32x4*>(src + vi * 4);
-  }
+  ff_pointer_reduce_row<false>(a, b, lane);
 }
 
 }  // namespace
@@ -205,6 +155,7 @@ extern "C" int ff_pointer_argmax(const float* p, int ldp, const float* memory, i
                                      seqs_per_group, S, E, 0, 0, B / seqs_per_group,
                                      (long long)seqs_per_group * ldp, (long long)S * E,
                                      (long long)seqs_per_group * ldlogits, stream));
+    if (ff_chain_recording()) return ff_chain_record_pointer(a);
     FFProfScope prof(FF_CAT_POINTER, (double)B * S * 8.0, st);
     hipLaunchKernelGGL(pointer_reduce_kernel, grid, block, 0, st, a);
     FF_CHECK_LAUNCH();

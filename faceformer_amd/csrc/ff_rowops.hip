@@ -4,6 +4,8 @@
 #include <stdarg.h>
 
 #include "ff_common.h"
+#include "ff_device.h"
+#include "ff_chain.h"
 
 // ---- library-level helpers ---------------------------------------------------------------------
 static thread_local char g_ff_error[512] = "";
@@ -35,7 +37,7 @@ struct Profiler {
   std::vector<hipEvent_t> pool;
   size_t next = 0;
   std::vector<ProfRec> recs;
-  double bytes[FF_NUM_CAT] = {0, 0, 0, 0, 0};  // algorithmic operand + result bytes per category
+  double bytes[FF_NUM_CAT] = {0, 0, 0, 0, 0, 0};  // algorithmic operand + result bytes per category
   hipEvent_t get() {
     if (next == pool.size()) {
       hipEvent_t e;
@@ -121,57 +123,11 @@ extern "C" int ff_profile_bracket_us(int launches, double* us_per_launch, ff_str
 // NV = float4 chunks per lane (E <= 256*NV).  Two-pass statistics in registers (mean, then the
 // centred second moment) -- the same formula torch's CPU kernel evaluates, biased variance.
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(
-    const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
-    float* __restrict__ ypos, int ldypos, const float* __restrict__ pos, int ldpos, int pos_div,
-    int pos_mod, int rows, int E) {
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int nvec = E >> 2;
-  const float* xr = x + (size_t)row * ldx;
-  f32x4 v[NV];
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    int vi = lane + c * 64;
-    if (vi < nvec) {
-      v[c] = *reinterpret_cast<const f32x4*>(xr + vi * 4);
-      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-    } else {
-      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  const float inv_e = 1.0f / (float)E;
-  const float mean = ff_wave_sum(s) * inv_e;
-  float ss = 0.f;
-#pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    int vi = lane + c * 64;
-    if (vi < nvec) {
-      f32x4 d = v[c] - mean;
-      ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-    }
-  }
-  const float var = ff_wave_sum(ss) * inv_e;
-  const float rstd = 1.0f / sqrtf(var + eps);
-  const float* pr = nullptr;
-  if (ypos != nullptr) pr = pos + (size_t)((row / pos_div) % pos_mod) * ldpos;
-#pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    int vi = lane + c * 64;
-    if (vi < nvec) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + vi * 4);
-      f32x4 b = *reinterpret_cast<const f32x4*>(beta + vi * 4);
-      f32x4 o = (v[c] - mean) * rstd * g + b;
-      if (y != nullptr) *reinterpret_cast<f32x4*>(y + (size_t)row * ldy + vi * 4) = o;
-      if (ypos != nullptr) {
-        f32x4 p = *reinterpret_cast<const f32x4*>(pr + vi * 4);
-        *reinterpret_cast<f32x4*>(ypos + (size_t)row * ldypos + vi * 4) = o + p;
-      }
-    }
-  }
+  if (row >= a.rows) return;
+  ff_layernorm_row<NV, false>(a, row, lane);
 }
 
 extern "C" int ff_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
@@ -190,12 +146,12 @@ extern "C" int ff_layernorm(const float* x, int ldx, const float* gamma, const f
                  "ff_layernorm: bad pos arguments");
   }
   hipStream_t st = (hipStream_t)stream;
+  const LnArgs la{x, ldx, gamma, beta, eps, y, ldy, ypos, ldypos, pos, ldpos, pos_div, pos_mod, rows, E};
+  if (ff_chain_recording()) return ff_chain_record_layernorm(la);
   FFProfScope prof(FF_CAT_LN, (double)rows * E * 4.0 * (1 + (y != nullptr) + (ypos != nullptr)), st);
   dim3 block(256), grid(ff_cdiv(rows, 4));
   const int nv = ff_cdiv(E / 4, 64);
-#define FF_LN_LAUNCH(NV)                                                                         \
-  hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, x, ldx, gamma, beta, eps, y, ldy, \
-                     ypos, ldypos, pos, ldpos, pos_div, pos_mod, rows, E)
+#define FF_LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, st, la)
   if (nv <= 1) FF_LN_LAUNCH(1);
   else if (nv <= 2) FF_LN_LAUNCH(2);
   else if (nv <= 4) FF_LN_LAUNCH(4);

@@ -17,7 +17,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libfaceformer_hip.so")
 BUILD_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
-SOURCES = ["ff_rowops.hip", "ff_gemm.hip", "ff_gemm_x3.hip", "ff_attention.hip", "ff_pointer.hip", "ff_engine.hip"]
+SOURCES = ["ff_rowops.hip", "ff_gemm.hip", "ff_gemm_x3.hip", "ff_attention.hip", "ff_pointer.hip", "ff_chain.hip", "ff_engine.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function"]
 
@@ -41,7 +41,7 @@ def _digest(paths):
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the shared library; returns its path."""
     os.makedirs(BUILD_DIR, exist_ok=True)
-    headers = [os.path.join(INCLUDE, "faceformer_hip.h"), os.path.join(CSRC, "ff_common.h")]
+    headers = [os.path.join(INCLUDE, "faceformer_hip.h"), os.path.join(CSRC, "ff_common.h"), os.path.join(CSRC, "ff_device.h"), os.path.join(CSRC, "ff_chain.h")]
     hipcc = _hipcc()
     objs = []
     relink = force or not os.path.exists(LIB_PATH)

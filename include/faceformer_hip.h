@@ -326,6 +326,11 @@ enum ff_decode_flags {
                                 produces a LayerNorm input leaves per-row segment statistics, the GEMM that consumes
                                 it normalises its A rows while staging them (ff_gemm_f32_ln).  Needs the folded
                                 weights (ln1_w ... proj_fold_b) and E, FF multiples of 64, 128 <= E <= 512; otherwise ignored */
+  FF_CHAIN = 64,             /* chain launches (ff_chain.hip): a decode step with at most chain_max_rows active rows, and the
+                                last layer's newest-position tail + pointer head of every larger step, run as ONE persistent
+                                launch whose operators are separated by grid-wide phase boundaries instead of kernel boundaries
+                                (same device code, agent-coherent accesses).  Single-stream decodes only (num_streams <= 1);
+                                needs E, FF in {128, 256, 512, 1024}; otherwise ignored */
   FF_DEDUP_PAD_ANCHORS = 16  /* parallel variant: the F - num_input[w] padding-anchor sequences of a wireframe
                                 (start token num_token-1, reference model_para.py:204-205) are identical by
                                 construction; decode ONE of them and copy its tokens into all those rows of
@@ -353,6 +358,8 @@ typedef struct ff_decode_params {
                            (a single wireframe is never cut by it); 0: no limit */
   int ln_fuse_max_rows; /* FF_FUSE_LAYERNORM applies to decode steps with at most this many active rows
                            (t * sequences of the micro-batch); 0: the default (4096) */
+  int chain_max_rows;   /* FF_CHAIN: a step of a micro-batch with at most this many active rows is one chain launch, and the
+                           tail of a larger step when the micro-batch has at most this many sequences; 0: the default (1024) */
 } ff_decode_params;
 
 /* Greedy pointer decode (a5-a12 of SURVEY.md 8a).

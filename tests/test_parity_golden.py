@@ -44,12 +44,14 @@ def run_traced(model, case, batch):
                          x3_min_rows=model.x3_min_rows,
                          chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                          chunk_max_seqs=model.chunk_max_seqs, num_streams=model.num_streams,
-                         ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0))
+                         ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0),
+                         chain_max_rows=getattr(model, "chain_max_rows", 0))
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          extra_mask=extra, flags=model.decode_flags, return_pointer=True,
                          x3_min_rows=model.x3_min_rows,
-                         chunk_wireframes=model.chunk_wireframes)
+                         chunk_wireframes=model.chunk_wireframes,
+                         chain_max_rows=getattr(model, "chain_max_rows", 0))
     out["memory"] = memory
     return out
 
@@ -161,6 +163,27 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
     _record_margin(name, "bf16x3 from %d rows" % min_rows, stats)
 
 
+@pytest.mark.parametrize("chain_rows", [0, 64, 1 << 20])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_parity_with_chain_launches(hip_lib, name, chain_rows):
+    """FF_CHAIN: decode steps with at most `chain_rows` active rows (0 = the default 1024; 1 << 20 = every step of every
+    golden) run as ONE persistent launch whose operators -- the same device code with agent-coherent accesses -- are
+    separated by grid-wide phase boundaries; larger steps hand their last-layer tail + pointer head to a chain launch.
+    Same bars as the launch-per-operator path."""
+    from faceformer_amd.hip import lib as L
+    case, z = load_golden(name)
+    if chain_rows == (1 << 20) and case.get("slow") and case["kind"] == "parallel" and max(case["n_edges"]) > 300:
+        pytest.skip("whole-step chains of 10^4-row steps: covered by the tail form")
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    model.decode_flags = model.decode_flags | L.FF_CHAIN
+    model.chain_max_rows = chain_rows
+    out = run_traced(model, case, batch_to(batch, "cuda"))
+    stats = compare_with_golden(case, z, out)
+    print(name, chain_rows, stats)
+    _record_margin(name, "chain launches <= %d rows" % (chain_rows or 1024), stats)
+
+
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak",
                                   "par_full_n40_gain4", "seq_small_gain4", "seq_small_eos",
                                   "par_small_extramask", "par_small_ragged300"])
@@ -174,7 +197,10 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
                                                         # 32 = FF_FUSE_LAYERNORM (the default): LayerNorm folded into
                                                         # the projections; the rows above run the unfused kernels
                                                         (32, 0, 1, 0, 1), (35, 1, 0, 0, 2), (51, 0, 2, 5, 3),
-                                                        (33, 2, 1, 0, 1), (34, 0, 0, 0, 1)])
+                                                        (33, 2, 1, 0, 1), (34, 0, 0, 0, 1),
+                                                        # 64 = FF_CHAIN: chain launches (ignored with > 1 stream)
+                                                        (64 + 51, 0, 1, 0, 1), (64 + 19, 1, 0, 0, 1), (64 + 3, 0, 2, 5, 1),
+                                                        (64 + 35, 2, 1, 0, 2), (64 + 0, 0, 1, 0, 1), (64 + 32, 3, 4, 0, 1)])
 def test_engine_options_do_not_change_results(hip_lib, name, flags, chunk, sync, cseq, nstr):
     """Pruning flags, micro-batching (by wireframe or by sequence group), concurrent streams and the
     host sync period are pure scheduling choices."""

@@ -75,8 +75,9 @@ def test_module_forward_matches_reference_vectors(hip_lib, name):
     outs = out if isinstance(out, tuple) else (out,)
     for i, o in enumerate(outs):
         print(name, i, "err/bar %.3f" % _close(o, z["%s/out%d" % (name, i)], "%s out%d" % (name, i)))
-    with pytest.raises(NotImplementedError):   # training-mode forwards are out of scope and say so
-        G.call(module.train(), c, _cuda(G.make_inputs(name, c)))
+    if c["kind"] in ("decoder", "encoder", "transformer"):   # blocks with dropout: training-mode forwards are out of scope and say so
+        with pytest.raises(NotImplementedError):
+            G.call(module.train(), c, _cuda(G.make_inputs(name, c)))
 
 
 @pytest.mark.gpu
