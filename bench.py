@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 E_SIZES, E_PROBS, E_SEED = (64, 128, 256, 512, 1024), (.3, .3, .2, .1, .1), 2024
-CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops"]
+CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops", "chain_launches"]
 
 
 def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100, F=None):
@@ -196,6 +196,10 @@ def main():
     ap.add_argument("--no-x3-line", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C128 / E32 / D / A lines of the N = 1 run")
     ap.add_argument("--other-steps", type=int, default=2, help="timed passes of each `other_configs` entry")
+    ap.add_argument("--other-list", default="C128,E32,D,A", help="which `other_configs` entries to measure")
+    ap.add_argument("--chain", type=int, default=-1,
+                    help="chain launches (FF_CHAIN): 1 on, 0 off, -1 the package default")
+    ap.add_argument("--chain-max-rows", type=int, default=0, help="FF_CHAIN row limit of a whole-step chain (0: 1024)")
     ap.add_argument("--plain-multi", action="store_true",
                     help="N > 1: time the plain per-rank model(batch) + all-gather (the round-2 form) instead of decode_sharded")
     args = ap.parse_args()
@@ -251,7 +255,15 @@ def main():
             model.decode_flags = model.decode_flags & ~L.FF_DEDUP_PAD_ANCHORS
         if args.no_fuse_ln:
             model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
+        apply_chain(model)
         return model, cfg, T
+
+    def apply_chain(mod):
+        if args.chain == 1:
+            mod.decode_flags = mod.decode_flags | L.FF_CHAIN
+        elif args.chain == 0:
+            mod.decode_flags = mod.decode_flags & ~L.FF_CHAIN
+        mod.chain_max_rows = args.chain_max_rows
 
     def steps_executed(pred):   # pred [N, F, T] or [N, T]
         p = pred.reshape(-1, pred.size(-1))
@@ -411,6 +423,7 @@ def main():
     if world == 1 and not cfgE and W == 1 and not args.no_other_configs:
         other = {}
         K2 = max(1, args.other_steps)
+        want = set(args.other_list.split(","))
 
         def par_entry(name, m2, b2, n2, T2, what):
             def st():
@@ -435,21 +448,23 @@ def main():
             other[name] = ent
 
         # C128: config 3's per-GPU share on this GPU (the model of the main line, a batch of 128 wireframes)
-        bC = to_dev(make_wireframes([args.edges] * 128, L_lines, T, "parallel", seeds=list(range(128))))
-        par_entry("C128", model, bC, [args.edges] * 128, T,
-                  "BASELINE config 3's per-GPU share: 128 synthetic %d-edge wireframes in one call (configs/ours.yml, "
-                  "model.num_lines=%d), micro-batches of %d wireframes, default-xavier weights" % (args.edges, L_lines, args.chunk))
-        del bC
+        if "C128" in want:
+            bC = to_dev(make_wireframes([args.edges] * 128, L_lines, T, "parallel", seeds=list(range(128))))
+            par_entry("C128", model, bC, [args.edges] * 128, T,
+                      "BASELINE config 3's per-GPU share: 128 synthetic %d-edge wireframes in one call (configs/ours.yml, "
+                      "model.num_lines=%d), micro-batches of %d wireframes, default-xavier weights" % (args.edges, L_lines, args.chunk))
+            del bC
         # E32: config 5's per-GPU share
-        mE, cE, TE = parallel_model("ours-perspective.yml", 1024)
-        nE = config_e_edge_counts(8 * 32)[:32]
-        bE = to_dev(make_wireframes(nE, 1024, TE, "parallel", seeds=list(range(32))))
-        par_entry("E32", mE, bE, nE, TE,
-                  "BASELINE config 5's per-GPU share: 32 ragged wireframes, edge counts %s (configs/ours-perspective.yml, "
-                  "model.num_lines=1024, max_face_length %d), padding anchors de-duplicated, width-bucketed micro-batches"
-                  % ({str(k): nE.count(k) for k in E_SIZES}, TE))
-        other["E32"]["decoded_sequences"] = (getattr(mE, "last_decode_stats", None) or {}).get("decoded_seqs")
-        del mE, bE
+        if "E32" in want:
+            mE, cE, TE = parallel_model("ours-perspective.yml", 1024)
+            nE = config_e_edge_counts(8 * 32)[:32]
+            bE = to_dev(make_wireframes(nE, 1024, TE, "parallel", seeds=list(range(32))))
+            par_entry("E32", mE, bE, nE, TE,
+                      "BASELINE config 5's per-GPU share: 32 ragged wireframes, edge counts %s (configs/ours-perspective.yml, "
+                      "model.num_lines=1024, max_face_length %d), padding anchors de-duplicated, width-bucketed micro-batches"
+                      % ({str(k): nE.count(k) for k in E_SIZES}, TE))
+            other["E32"]["decoded_sequences"] = (getattr(mE, "last_decode_stats", None) or {}).get("decoded_seqs")
+            del mE, bE
 
         # D / A: the single-sequence model (SurfaceFormer), one wireframe, 258 steps with the gain-4 parity weights
         wbytes = decoder_weight_bytes()
@@ -461,12 +476,15 @@ def main():
                 ("A", "seq2seq.yml", 64, 0, 3, None,
                  "BASELINE config 1's sizes on the GPU: configs/seq2seq.yml (num_lines 110, label_seq_length 259), one 64-edge "
                  "synthetic wireframe, gain-4 synthetic weights (golden seq_full_A64_gain4)")):
+            if name not in want:
+                continue
             c1 = load_cfg(os.path.join(ROOT, "configs", cfg_file))
             L1, T1 = c1.model.num_lines, c1.model.label_seq_length
             m1 = SurfaceFormer(**c1.model)
             m1.load_state_dict(make_state_dict(state_dict_spec("seq2seq", L1, T1), "gain4", wseed))
             m1 = m1.eval().to(dev)
             m1.x3_min_rows = 0
+            apply_chain(m1)
             b1 = make_wireframes([n1], L1, T1, "seq2seq", seeds=[wfseed])
             if mask_seed is not None:
                 b1["extra_mask"] = make_extra_mask(dict(kind="seq2seq", extra_mask_seed=mask_seed), b1)

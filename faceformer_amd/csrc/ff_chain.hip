@@ -39,7 +39,9 @@ __host__ __device__ constexpr int chain_lds_floats() {
 }
 
 struct ChainSync {
-  unsigned* flags;     // [G][16] epoch of workgroup b at flags[16 b]; release word at flags[16 G + 16]; error word at [16 G + 32]
+  unsigned* flags;     // [G][16] epoch of workgroup b at flags[16 b]; release word at flags[16 G + 16]; error word at [16 G + 32];
+                       // class release words at flags[16 G + 64 + 16 c], c = 0..7
+  unsigned long long* ts;   // FF_CHAIN_TRACE: [G][64][4] wall-clock stamps (op entered, work done, boundary passed) or null
 };
 
 __device__ __forceinline__ unsigned chain_ld(const unsigned* p) {
@@ -57,12 +59,19 @@ __device__ __forceinline__ bool chain_wait_ge(const unsigned* p, unsigned target
   return false;
 }
 
-// grid-wide phase boundary (see the file header); epoch = 1, 2, 3, ... over the life of the sync words
+// grid-wide phase boundary (see the file header); epoch = 1, 2, 3, ... over the life of the sync words.
+// Release side in two levels: workgroup 0 publishes the release word, the FIRST workgroup of each XCD residue class
+// (blockIdx < 8) polls it and republishes into its class's word, which the other workgroups of the class poll.  A class =
+// blockIdx & 7 = the XCD the dispatcher puts the workgroup on (placement only matters for speed: the class word then lives in
+// that XCD's L2 and ~31 pollers are served there).  With every idle workgroup polling ONE word, 255 pollers saturate its
+// memory channel (~90 accesses/us) for the whole phase: measured 8 us per 32x32x512 tile and 36 us per attention unit next
+// to them, against 4-5 us alone.
 __device__ __forceinline__ void chain_boundary(const ChainSync& s, int G, unsigned epoch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have left the CU
   __syncthreads();
   unsigned* release = s.flags + 16 * G + 16;
   unsigned* err = s.flags + 16 * G + 32;
+  unsigned* cls = s.flags + 16 * G + 64 + 16 * (blockIdx.x & 7);
   if (threadIdx.x == 0) chain_st(s.flags + 16 * blockIdx.x, epoch);
   if (blockIdx.x == 0) {
     bool ok = true;
@@ -76,7 +85,13 @@ __device__ __forceinline__ void chain_boundary(const ChainSync& s, int G, unsign
     }
   }
   if (threadIdx.x == 0) {
-    if (!chain_wait_ge(release, epoch)) { chain_st(err, 2u); chain_st(release, CHAIN_POISON); }
+    if (blockIdx.x < 8) {
+      if (!chain_wait_ge(release, epoch)) { chain_st(err, 2u); chain_st(release, CHAIN_POISON); }
+      const unsigned r = chain_ld(release);
+      chain_st(cls, r == CHAIN_POISON ? CHAIN_POISON : epoch);
+    } else {
+      if (!chain_wait_ge(cls, epoch)) { chain_st(err, 3u); chain_st(release, CHAIN_POISON); chain_st(cls, CHAIN_POISON); }
+    }
   }
   __syncthreads();
 }
@@ -86,10 +101,32 @@ __device__ __forceinline__ void chain_boundary(const ChainSync& s, int G, unsign
 // spilled 65-96 VGPRs inside the operator bodies; as functions the only scratch traffic is the attention operator's
 // callee-saved registers, once per operator).  The dynamic LDS block is re-declared inside each one, so LDS accesses stay
 // ds_* instructions.
+// The descriptor pointer arrives in VGPRs (function-call ABI) although it is the same for every lane: readfirstlane makes
+// that provable again, so the descriptor is fetched with scalar loads and every pointer in it stays wave-uniform (SGPR base +
+// per-lane offset addressing instead of 64-bit per-lane pointers).
+__device__ __forceinline__ const FF_GLOBAL ff_chain_op* chain_uniform(const ff_chain_op* p) {
+  const ff_u64 v = (ff_u64)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const FF_GLOBAL ff_chain_op*)(((ff_u64)hi << 32) | lo);
+}
+
+// descriptor part -> registers, word by word through the global pointer (C++ has no copy constructor across address spaces)
+template <typename T>
+__device__ __forceinline__ T chain_fetch(const FF_GLOBAL void* p) {
+  static_assert(sizeof(T) % 4 == 0, "descriptor parts are whole words");
+  T out;
+  unsigned* o = reinterpret_cast<unsigned*>(&out);
+  const FF_GLOBAL unsigned* q = (const FF_GLOBAL unsigned*)p;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) o[i] = q[i];
+  return out;
+}
+
 template <int MODE>
-__device__ __attribute__((noinline)) void chain_op_gemm(const ff_chain_op* __restrict__ opp) {
+__device__ __attribute__((noinline)) void chain_op_gemm(const ff_chain_op* opp_v) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const GemmArgs g = opp->u.g;
+  const FF_GLOBAL ff_chain_op* opp = chain_uniform(opp_v);
+  const GemmArgs g = chain_fetch<GemmArgs>(&opp->u.g);
   const int units = opp->units;
   const int G = gridDim.x;
   const int per = g.tiles_m * g.tiles_n;
@@ -105,9 +142,10 @@ __device__ __attribute__((noinline)) void chain_op_gemm(const ff_chain_op* __res
   }
 }
 
-__device__ __attribute__((noinline)) void chain_op_attention(const ff_chain_op* __restrict__ opp) {
+__device__ __attribute__((noinline)) void chain_op_attention(const ff_chain_op* opp_v) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const ff_attn_desc d = opp->u.a;
+  const FF_GLOBAL ff_chain_op* opp = chain_uniform(opp_v);
+  const ff_attn_desc d = chain_fetch<ff_attn_desc>(&opp->u.a);
   const int units = opp->units, q_tiles = opp->aux0, ks = opp->aux1;
   const long total_units = opp->total_units;
   const int G = gridDim.x;
@@ -117,8 +155,9 @@ __device__ __attribute__((noinline)) void chain_op_attention(const ff_chain_op* 
   }
 }
 
-__device__ __attribute__((noinline)) void chain_op_layernorm(const ff_chain_op* __restrict__ opp) {
-  const LnArgs a = opp->u.ln;
+__device__ __attribute__((noinline)) void chain_op_layernorm(const ff_chain_op* opp_v) {
+  const FF_GLOBAL ff_chain_op* opp = chain_uniform(opp_v);
+  const LnArgs a = chain_fetch<LnArgs>(&opp->u.ln);
   const int nv = opp->aux0;
   const int G = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int row = blockIdx.x * CHAIN_WAVES + wave; row < a.rows; row += G * CHAIN_WAVES) {
@@ -129,8 +168,9 @@ __device__ __attribute__((noinline)) void chain_op_layernorm(const ff_chain_op* 
   }
 }
 
-__device__ __attribute__((noinline)) void chain_op_pointer(const ff_chain_op* __restrict__ opp) {
-  const PointerArgs a = opp->u.p;
+__device__ __attribute__((noinline)) void chain_op_pointer(const ff_chain_op* opp_v) {
+  const FF_GLOBAL ff_chain_op* opp = chain_uniform(opp_v);
+  const PointerArgs a = chain_fetch<PointerArgs>(&opp->u.p);
   const int G = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int b = blockIdx.x * CHAIN_WAVES + wave; b < a.B; b += G * CHAIN_WAVES) ff_pointer_reduce_row<true>(a, b, lane);
 }
@@ -142,6 +182,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void chain_kernel(const ff_chain_
   for (int i = 0; i < nops; ++i) {
     const ff_chain_op* op = ops + i;
     const int kind = op->kind;
+    if (sync.ts && i < 64 && threadIdx.x == 0) sync.ts[((size_t)blockIdx.x * 64 + i) * 4 + 0] = wall_clock64();
     if (kind == FF_CH_GEMM) {
       const int mode = op->u.g.ln_in ? 1 : (op->u.g.ln_out ? 2 : 0);
       if (mode == 1) chain_op_gemm<1>(op);
@@ -154,10 +195,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void chain_kernel(const ff_chain_
     } else if (kind == FF_CH_PTR) {
       chain_op_pointer(op);
     }
+    if (sync.ts && i < 64 && threadIdx.x == 0) sync.ts[((size_t)blockIdx.x * 64 + i) * 4 + 1] = wall_clock64();
     if (op->barrier && i + 1 < nops) {
       ++epoch;
       chain_boundary(sync, G, epoch);
     }
+    if (sync.ts && i < 64 && threadIdx.x == 0) sync.ts[((size_t)blockIdx.x * 64 + i) * 4 + 2] = wall_clock64();
   }
 }
 
@@ -171,6 +214,8 @@ struct ChainCtx {
   unsigned* flags = nullptr;
   unsigned epoch = 0;
   bool attr_done = false;
+  unsigned long long* ts = nullptr;   // FF_CHAIN_TRACE
+  int traced = 0;
 };
 constexpr int CHAIN_MAX_DEV = 16;
 ChainCtx g_ctx[CHAIN_MAX_DEV];
@@ -280,7 +325,7 @@ int ff_chain_prepare(size_t ops_needed, hipStream_t st) {
     FF_CHECK_HIP(hipGetDevice(&dev));
     FF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     c->G = cus < 256 ? (cus > 0 ? cus : 1) : 256;
-    FF_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c->flags), (size_t)(c->G + 4) * 64));
+    FF_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c->flags), (size_t)(c->G + 16) * 64));
     c->ready = true;
   }
   if (ops_needed > c->cap_ops) {
@@ -294,7 +339,7 @@ int ff_chain_prepare(size_t ops_needed, hipStream_t st) {
   }
   c->used_ops = 0;
   c->epoch = 0;
-  FF_CHECK_HIP(hipMemsetAsync(c->flags, 0, (size_t)(c->G + 4) * 64, st));
+  FF_CHECK_HIP(hipMemsetAsync(c->flags, 0, (size_t)(c->G + 16) * 64, st));
   return FF_OK;
 }
 
@@ -334,12 +379,41 @@ int ff_chain_end(hipStream_t st, int* launched) {
   FF_CHECK_HIP(hipMemcpyAsync(d, h, n * sizeof(ff_chain_op), hipMemcpyHostToDevice, st));
   unsigned barriers = 0;
   for (size_t i = 0; i + 1 < n; ++i) barriers += t_rec.ops[i].barrier ? 1u : 0u;
-  ChainSync s{c->flags};
+  // FF_CHAIN_TRACE=<k>: wall-clock stamps of the k-th chain launch of the process (per workgroup and operator), printed to stderr
+  static const int trace_at = getenv("FF_CHAIN_TRACE") ? atoi(getenv("FF_CHAIN_TRACE")) : -1;
+  const bool trace = trace_at >= 0 && c->traced++ == trace_at;
+  if (trace && !c->ts) FF_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c->ts), (size_t)c->G * 64 * 4 * sizeof(unsigned long long)));
+  if (trace) FF_CHECK_HIP(hipMemsetAsync(c->ts, 0, (size_t)c->G * 64 * 4 * sizeof(unsigned long long), st));
+  ChainSync s{c->flags, trace ? c->ts : nullptr};
   {
     FFProfScope prof(FF_CAT_CHAIN, t_rec.flops, st);
     hipLaunchKernelGGL(chain_kernel, dim3(c->G), dim3(CHAIN_THREADS), chain_lds_floats() * sizeof(float), st, d, (int)n, s,
                        c->epoch);
     FF_CHECK_LAUNCH();
+  }
+  if (trace) {
+    std::vector<unsigned long long> h((size_t)c->G * 64 * 4);
+    FF_CHECK_HIP(hipStreamSynchronize(st));
+    FF_CHECK_HIP(hipMemcpy(h.data(), c->ts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const unsigned long long t0 = h[0];
+    fprintf(stderr, "[chain trace] launch %d: %zu operators, G = %d (times in us since workgroup 0 entered operator 0; 100 MHz clock)\n",
+            trace_at, n, c->G);
+    for (size_t i = 0; i < n && i < 64; ++i) {
+      double work_max = 0, work_min = 1e30, enter_max = 0, leave_max = 0; int busy = 0;
+      for (int b = 0; b < c->G; ++b) {
+        const unsigned long long* r = &h[((size_t)b * 64 + i) * 4];
+        const double w = (double)(r[1] - r[0]) * 0.01;
+        work_max = w > work_max ? w : work_max; work_min = w < work_min ? w : work_min;
+        const double e = (double)(r[0] - t0) * 0.01, l = (double)(r[2] - t0) * 0.01;
+        enter_max = e > enter_max ? e : enter_max; leave_max = l > leave_max ? l : leave_max;
+      }
+      const ff_chain_op& op = t_rec.ops[i];
+      busy = op.units < c->G ? op.units : c->G;
+      const unsigned long long* r0 = &h[i * 4];
+      fprintf(stderr, "  op %2zu kind %d units %5d (%3d busy wgs) barrier %d: wg0 enter %8.2f work %6.2f boundary %6.2f | all wgs: work min %6.2f max %6.2f, "
+                      "last enter %8.2f last leave %8.2f\n", i, op.kind, op.units, busy, op.barrier, (double)(r0[0] - t0) * 0.01,
+              (double)(r0[1] - r0[0]) * 0.01, (double)(r0[2] - r0[1]) * 0.01, work_min, work_max, enter_max, leave_max);
+    }
   }
   c->epoch += barriers;
   t_rec.ops.clear();

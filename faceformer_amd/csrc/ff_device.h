@@ -12,54 +12,70 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Pointers of the chain form come out of operator descriptors in memory: the compiler cannot see that they are global
+// (it would emit flat_* accesses, which also tick the LDS counter and serialise the software pipelines), so every access
+// of the COH form goes through an explicit address_space(1) pointer.
+#define FF_GLOBAL __attribute__((address_space(1)))
+typedef unsigned long long ff_u64;
+
 template <bool COH>
 __device__ __forceinline__ f32x4 ff_ld16(const float* p) {
   if (!COH) return *reinterpret_cast<const f32x4*>(p);
   // two 8-byte agent-scope loads (the compiler tracks their vmcnt like any other load: no inline asm in pipelined code)
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const FF_GLOBAL ff_u64* q = (const FF_GLOBAL ff_u64*)p;
+  const ff_u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const ff_u64 hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const f32x2 a = __builtin_bit_cast(f32x2, lo), b = __builtin_bit_cast(f32x2, hi);
   return f32x4{a.x, a.y, b.x, b.y};
 }
 template <bool COH>
 __device__ __forceinline__ void ff_st16(float* p, f32x4 v) {
   if (!COH) { *reinterpret_cast<f32x4*>(p) = v; return; }
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-  __hip_atomic_store(q, __builtin_bit_cast(unsigned long long, f32x2{v.x, v.y}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 1, __builtin_bit_cast(unsigned long long, f32x2{v.z, v.w}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  FF_GLOBAL ff_u64* q = (FF_GLOBAL ff_u64*)p;
+  __hip_atomic_store(q, __builtin_bit_cast(ff_u64, f32x2{v.x, v.y}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, __builtin_bit_cast(ff_u64, f32x2{v.z, v.w}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool COH>
 __device__ __forceinline__ f32x2 ff_ld8(const float* p) {
   if (!COH) return *reinterpret_cast<const f32x2*>(p);
-  return __builtin_bit_cast(f32x2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT));
+  return __builtin_bit_cast(f32x2, __hip_atomic_load((const FF_GLOBAL ff_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 template <bool COH>
 __device__ __forceinline__ void ff_st8(float* p, f32x2 v) {
   if (!COH) { *reinterpret_cast<f32x2*>(p) = v; return; }
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((FF_GLOBAL ff_u64*)p, __builtin_bit_cast(ff_u64, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool COH>
 __device__ __forceinline__ float ff_ld4(const float* p) {
   if (!COH) return *p;
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load((const FF_GLOBAL float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool COH>
 __device__ __forceinline__ void ff_st4(float* p, float v) {
   if (!COH) { *p = v; return; }
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((FF_GLOBAL float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool COH>
 __device__ __forceinline__ int ff_ld4i(const int* p) {
   if (!COH) return *p;
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load((const FF_GLOBAL int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool COH>
 __device__ __forceinline__ void ff_st4i(int* p, int v) {
   if (!COH) { *p = v; return; }
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((FF_GLOBAL int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// data written BEFORE the launch (weights, biases, tables, masks, lengths, encoder memory): plain cached loads, global in
+// the chain form
+template <bool COH>
+__device__ __forceinline__ f32x4 ff_ldw16(const float* p) {
+  if (!COH) return *reinterpret_cast<const f32x4*>(p);
+  return *(const FF_GLOBAL f32x4*)p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T ff_ldw(const T* p) {
+  if (!COH) return *p;
+  return *(const FF_GLOBAL T*)p;
 }
 
 // ---- projection kernels: argument block ------------------------------------------------------------------------------
@@ -123,7 +139,7 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
 #pragma unroll
   for (int j = 0; j < GB; ++j) {
     a[0][j] = ff_ld16<COH>(ap + j * 8);
-    b[0][j] = *reinterpret_cast<const f32x4*>(wp + j * 8);
+    b[0][j] = ff_ldw16<COH>(wp + j * 8);
   }
   float* lnrow = red + NW * 16 * 64 + (MODE == 2 ? 32 * 33 : 0);   // MODE 1: [32][2] (mean, rstd)
   f32x4 sv = {0.f, 0.f, 0.f, 0.f};
@@ -135,7 +151,7 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
   }
   const int ocol = n0 + l32;
   const bool colok = ocol < g.N;
-  const float bv = (g.bias && colok) ? g.bias[ocol] : 0.f;
+  const float bv = (g.bias && colok) ? ff_ldw<COH>(g.bias + ocol) : 0.f;
   const bool tab = MODE == 1 && g.rowtab != nullptr && !g.res;
   float rv[RPW];
   int orow[RPW], prow[RPW];
@@ -148,7 +164,7 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
     rv[q] = 0.f;
     if (g.res) { if (ok) rv[q] = ff_ld4<COH>(g.res + bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol); }
     else if (tab && ok && ocol < g.rowtab_cols)
-      rv[q] = g.rowtab[(size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol];
+      rv[q] = ff_ldw<COH>(g.rowtab + (size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol);
   }
   __builtin_amdgcn_sched_barrier(0);
   float mu = 0.f, rs = 1.f;
@@ -177,7 +193,7 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
 #pragma unroll
       for (int j = 0; j < GB; ++j) {
         a[cur ^ 1][j] = ff_ld16<COH>(ap + (g0 + GB + j) * 8);
-        b[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(wp + (g0 + GB + j) * 8);
+        b[cur ^ 1][j] = ff_ldw16<COH>(wp + (g0 + GB + j) * 8);
       }
     }
 #pragma unroll
@@ -314,7 +330,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
     }
     if (mrow && lane < 32) {
       const int key = kt * 32 + lane;
-      mbyte = key < nk_s ? mrow[key] : (unsigned char)1;
+      mbyte = key < nk_s ? ff_ldw<COH>(mrow + key) : (unsigned char)1;
     }
   };
   auto load_v = [&](int kt) {   // V fragments straight to registers (each load instruction reads two full 128-byte row segments)
@@ -352,11 +368,11 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
         tq[p] = ff_ld16<COH>(d.q + xr * d.ldq + h * FF_HEAD_DIM + sc4 * 4);
       }
     }
-    if (mrow && lane < 8) tmb = (32 + lane) < nk_s ? mrow[32 + lane] : (unsigned char)1;
+    if (mrow && lane < 8) tmb = (32 + lane) < nk_s ? ff_ldw<COH>(mrow + 32 + lane) : (unsigned char)1;
   }
   int nk = nk_s;
   if (d.kv_len) {
-    const int kl = d.kv_len[g];
+    const int kl = ff_ldw<COH>(d.kv_len + g);
     nk = kl < nk ? kl : nk;
   }
   if (tails) {
@@ -669,12 +685,12 @@ __device__ __forceinline__ void ff_layernorm_row(const LnArgs& a, int row, int l
   for (int c = 0; c < NV; ++c) {
     int vi = lane + c * 64;
     if (vi < nvec) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + vi * 4);
-      f32x4 b = *reinterpret_cast<const f32x4*>(a.beta + vi * 4);
+      f32x4 g = ff_ldw16<COH>(a.gamma + vi * 4);
+      f32x4 b = ff_ldw16<COH>(a.beta + vi * 4);
       f32x4 o = (v[c] - mean) * rstd * g + b;
       if (a.y != nullptr) ff_st16<COH>(a.y + (size_t)row * a.ldy + vi * 4, o);
       if (a.ypos != nullptr) {
-        f32x4 p = *reinterpret_cast<const f32x4*>(pr + vi * 4);
+        f32x4 p = ff_ldw16<COH>(pr + vi * 4);
         ff_st16<COH>(a.ypos + (size_t)row * a.ldypos + vi * 4, o + p);
       }
     }
@@ -700,7 +716,7 @@ template <bool COH>
 __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int b, int lane) {
   const int w = b / a.spg;
   int kv = a.S;
-  if (a.kv_len) { const int k = a.kv_len[w]; kv = k < kv ? k : kv; }
+  if (a.kv_len) { const int k = ff_ldw<COH>(a.kv_len + w); kv = k < kv ? k : kv; }
   const unsigned char* mrow = a.mask ? a.mask + (size_t)w * a.S : nullptr;
   const unsigned char* erow = a.extra ? a.extra + (size_t)b * a.ldextra : nullptr;
   float* lrow = a.logits + (size_t)b * a.ldlogits;
@@ -709,8 +725,8 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
   int i1 = 0x7fffffff;
   for (int s = lane; s < a.S; s += 64) {
     bool ok = s < kv;
-    if (ok && mrow) ok = mrow[s] == 0;
-    if (ok && erow) ok = erow[s] == 0;
+    if (ok && mrow) ok = ff_ldw<COH>(mrow + s) == 0;
+    if (ok && erow) ok = ff_ldw<COH>(erow + s) == 0;
     const float v = ok ? ff_ld4<COH>(lrow + s) : FILL;
     ff_st4<COH>(lrow + s, v);
     if (v > b1) { b2 = b1; b1 = v; i1 = s; }
@@ -728,8 +744,8 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
   if (i1 == 0x7fffffff) { i1 = 0; b1 = FILL; }
   if (lane == 0) {
     ff_st4i<COH>(a.next_tok + b, i1);
-    if (a.best) a.best[b] = b1;
-    if (a.second) a.second[b] = b2;
+    if (a.best) ff_st4<COH>(a.best + b, b1);
+    if (a.second) ff_st4<COH>(a.second + b, b2);
     if (a.count_ge && i1 >= a.ge_bound) atomicAdd(a.count_ge, 1);
     if (a.count_eq && i1 == a.eq_value) atomicAdd(a.count_eq, 1);
   }
@@ -737,6 +753,6 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
     const float* src = a.memory + ((size_t)w * a.S + i1) * a.E;
     float* dst = a.next_rows + (size_t)b * a.ldnext;
     for (int vi = lane; vi < (a.E >> 2); vi += 64)
-      ff_st16<COH>(dst + vi * 4, *reinterpret_cast<const f32x4*>(src + vi * 4));
+      ff_st16<COH>(dst + vi * 4, ff_ldw16<COH>(src + vi * 4));
   }
 }

@@ -105,6 +105,39 @@ __global__ __launch_bounds__(256) void phases(Sync s, int G, int iters, float* b
   if (acc[5] == 123.456f) sink[0] = acc[5];
 }
 
+// Correctness of the exchange under address RE-USE (the chain kernel's scratch buffers are rewritten every phase): in phase i
+// every block overwrites the SAME 4 KB of its region with tag(i, block) through sc1 stores; after the boundary every block reads
+// the regions of blocks b+1, b+9, b+17 (other XCDs and its own) through sc1 loads and counts words that are not tag(i, producer).
+// A consumer L2 / L1 that served a stale line would show up here.  MODE 1: plain loads instead (expected to FAIL: shows the test bites).
+template <int VAR, int PLAIN>
+__global__ __launch_bounds__(256) void verify(Sync s, int G, int iters, float* buf, unsigned* bad) {
+  const int tid = threadIdx.x;
+  const size_t region = (size_t)256 * 4 * 16;
+  unsigned nbad = 0;
+  for (int i = 0; i < iters; ++i) {
+    const float tag = (float)(i * 1024 + (int)blockIdx.x);
+    f32x4 o = {tag, tag, tag, tag};
+    float* wp = buf + (size_t)blockIdx.x * region + tid * 4;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp), "v"(o) : "memory");
+    grid_barrier<VAR>(s, G, (unsigned)(2 * i + 1));
+    for (int k = 0; k < 3; ++k) {
+      const int src = (blockIdx.x + 1 + 8 * k) % G;
+      const float want = (float)(i * 1024 + src);
+      const float* rp = buf + (size_t)src * region + tid * 4;
+      f32x4 t;
+      if (PLAIN) {
+        t = *reinterpret_cast<const volatile f32x4*>(rp);
+      } else {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t) : "v"(rp) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)::"memory");
+      }
+      nbad += (t[0] != want) + (t[1] != want) + (t[2] != want) + (t[3] != want);
+    }
+    grid_barrier<VAR>(s, G, (unsigned)(2 * i + 2));   // nobody overwrites before everybody has read
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <typename K, typename... A>
@@ -154,6 +187,18 @@ int main() {
              run(phases<1, 4>, G, s, st, iters, buf, nm, sink) / iters, run(phases<1, 16>, G, s, st, iters, buf, nm, sink) / iters);
       printf("        flags     %.2f / %.2f / %.2f\n", run(phases<2, 1>, G, s, st, iters, buf, nm, sink) / iters,
              run(phases<2, 4>, G, s, st, iters, buf, nm, sink) / iters, run(phases<2, 16>, G, s, st, iters, buf, nm, sink) / iters);
+    }
+  }
+  {
+    unsigned* bad;
+    CK(hipMalloc(&bad, 64));
+    for (int plain = 0; plain < 2; ++plain) {
+      CK(hipMemset(bad, 0, 64));
+      const double t = plain ? run(verify<2, 1>, 256, s, st, 2000, buf, bad) : run(verify<2, 0>, 256, s, st, 2000, buf, bad);
+      unsigned nb = 0;
+      CK(hipMemcpy(&nb, bad, 4, hipMemcpyDeviceToHost));
+      printf("verify (G=256, 2000 phases, same addresses rewritten every phase, 3 producers per consumer): %s loads: %u stale words of %u  (%.2f us per phase pair)\n",
+             plain ? "PLAIN" : "sc1", nb, 2000u * 256u * 256u * 4u * 3u, t / 2000);
     }
   }
   unsigned err = 0;
