@@ -5,7 +5,8 @@
 #include "ff_common.h"
 #include "ff_device.h"
 
-enum { FF_CH_GEMM = 1, FF_CH_ATTN = 2, FF_CH_LN = 3, FF_CH_PTR = 4 };
+enum { FF_CH_GEMM = 1, FF_CH_ATTN = 2, FF_CH_LN = 3, FF_CH_PTR = 4, FF_CH_GEMM64 = 5 };
+constexpr int FF_FLOW_MAX_OPS = 4;
 
 struct ff_chain_op {
   int kind;
@@ -33,3 +34,10 @@ int ff_chain_begin();
 void ff_chain_abort();
 int ff_chain_end(hipStream_t st, int* launched);
 int ff_chain_check(hipStream_t st);
+// Flow launches (ff_gemm.hip: gemm_flow_kernel): between ff_flow_begin() and ff_flow_end() every projection is recorded as a
+// 64x64-tile operator that depends, row panel by row panel, on the projection recorded before it.
+int ff_flow_begin();
+int ff_flow_end(hipStream_t st, int* launched);
+bool ff_flow_recording();
+int ff_gemm_flow_launch(const ff_chain_op* dev_ops, int nops, unsigned* ctr, unsigned* done, unsigned* err, int panel_stride,
+                        hipStream_t st);

@@ -216,13 +216,18 @@ struct ChainCtx {
   bool attr_done = false;
   unsigned long long* ts = nullptr;   // FF_CHAIN_TRACE
   int traced = 0;
+  int flow_launches = 0;
+  unsigned* flow_ctr = nullptr;       // flow launches: [2][FF_FLOW_MAX_OPS][FLOW_PANELS] arrival / consumer counters + error word
 };
+constexpr int FLOW_PANELS = 1 << 16;   // row panels of 64 rows a flow launch can track (4 M rows)
+constexpr size_t FLOW_WORDS = (size_t)2 * FF_FLOW_MAX_OPS * FLOW_PANELS + 64;
 constexpr int CHAIN_MAX_DEV = 16;
 ChainCtx g_ctx[CHAIN_MAX_DEV];
 std::mutex g_chain_mu;
 
 struct Recorder {
   bool active = false;
+  bool flow = false;             // flow recording: only 64x64-tile projections, each depending on the one before
   bool failed = false;
   bool skip_barrier = false;     // hint: the NEXT recorded operator does not depend on the previous one
   double flops = 0;
@@ -240,7 +245,12 @@ int ctx_get(ChainCtx** out) {
 
 }  // namespace
 
+static int flow_max_ops() {   // FF_FLOW_MAX_OPS=<n>: debugging aid (operators per flow launch)
+  static const int v = getenv("FF_FLOW_MAX_OPS") ? atoi(getenv("FF_FLOW_MAX_OPS")) : FF_FLOW_MAX_OPS;
+  return v < 1 ? 1 : (v > FF_FLOW_MAX_OPS ? FF_FLOW_MAX_OPS : v);
+}
 bool ff_chain_recording() { return t_rec.active; }
+bool ff_flow_recording() { return t_rec.active && t_rec.flow; }
 void ff_chain_next_is_independent() { if (t_rec.active) t_rec.skip_barrier = true; }
 
 static void chain_push(ff_chain_op& op, double flops) {
@@ -259,6 +269,22 @@ bool ff_chain_gemm_ok(const GemmArgs& g, int batch) {
 }
 
 int ff_chain_record_gemm(const GemmArgs& g_in, int batch) {
+  if (t_rec.flow) {   // one 64x64-tile operator of a flow launch
+    const bool ok = batch == 1 && (g_in.K % 64) == 0 && g_in.K >= 128 && !g_in.A2 && !(g_in.ln_in && g_in.ln_out) &&
+                    (!g_in.ln_out || (g_in.N & 31) == 0) && (!g_in.ln_in || g_in.ln_nseg <= 16) &&
+                    (int)t_rec.ops.size() < flow_max_ops() && ff_cdiv(g_in.M, 64) <= FLOW_PANELS &&
+                    (t_rec.ops.empty() || t_rec.ops.back().u.g.M == g_in.M);
+    if (!ok) { t_rec.failed = true; return FF_OK; }
+    ff_chain_op op;
+    memset(&op, 0, sizeof(op));
+    op.kind = FF_CH_GEMM64;
+    op.u.g = g_in;
+    op.u.g.tiles_m = ff_cdiv(g_in.M, 64);
+    op.u.g.tiles_n = ff_cdiv(g_in.N, 64);
+    op.units = op.u.g.tiles_m * op.u.g.tiles_n;
+    chain_push(op, 2.0 * g_in.M * g_in.N * g_in.K);
+    return FF_OK;
+  }
   if (!ff_chain_gemm_ok(g_in, batch)) { t_rec.failed = true; return FF_OK; }
   ff_chain_op op;
   memset(&op, 0, sizeof(op));
@@ -272,6 +298,7 @@ int ff_chain_record_gemm(const GemmArgs& g_in, int batch) {
 }
 
 int ff_chain_record_attention(const ff_attn_desc& d) {
+  if (t_rec.flow) { t_rec.failed = true; return FF_OK; }
   ff_chain_op op;
   memset(&op, 0, sizeof(op));
   op.kind = FF_CH_ATTN;
@@ -294,6 +321,7 @@ int ff_chain_record_attention(const ff_attn_desc& d) {
 }
 
 int ff_chain_record_layernorm(const LnArgs& a) {
+  if (t_rec.flow) { t_rec.failed = true; return FF_OK; }
   ff_chain_op op;
   memset(&op, 0, sizeof(op));
   op.kind = FF_CH_LN;
@@ -305,6 +333,7 @@ int ff_chain_record_layernorm(const LnArgs& a) {
 }
 
 int ff_chain_record_pointer(const PointerArgs& a) {
+  if (t_rec.flow) { t_rec.failed = true; return FF_OK; }
   ff_chain_op op;
   memset(&op, 0, sizeof(op));
   op.kind = FF_CH_PTR;
@@ -326,6 +355,7 @@ int ff_chain_prepare(size_t ops_needed, hipStream_t st) {
     FF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     c->G = cus < 256 ? (cus > 0 ? cus : 1) : 256;
     FF_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c->flags), (size_t)(c->G + 16) * 64));
+    FF_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&c->flow_ctr), FLOW_WORDS * sizeof(unsigned)));
     c->ready = true;
   }
   if (ops_needed > c->cap_ops) {
@@ -340,10 +370,52 @@ int ff_chain_prepare(size_t ops_needed, hipStream_t st) {
   c->used_ops = 0;
   c->epoch = 0;
   FF_CHECK_HIP(hipMemsetAsync(c->flags, 0, (size_t)(c->G + 16) * 64, st));
+  FF_CHECK_HIP(hipMemsetAsync(c->flow_ctr, 0, FLOW_WORDS * sizeof(unsigned), st));
+  return FF_OK;
+}
+
+int ff_flow_begin() {
+  FF_RETURN_IF(ff_chain_begin());
+  t_rec.flow = true;
+  return FF_OK;
+}
+
+// Ends a flow recording and enqueues ONE gemm_flow_kernel launch (ff_gemm.hip); *launched = 0: nothing enqueued.
+int ff_flow_end(hipStream_t st, int* launched) {
+  *launched = 0;
+  t_rec.active = false;
+  t_rec.flow = false;
+  if (t_rec.failed || t_rec.ops.empty()) { t_rec.ops.clear(); return FF_OK; }
+  ChainCtx* c;
+  FF_RETURN_IF(ctx_get(&c));
+  const size_t n = t_rec.ops.size();
+  if (!c->ready || c->used_ops + n > c->cap_ops) { t_rec.ops.clear(); return FF_OK; }
+  ff_chain_op* h = c->host_ops + c->used_ops;
+  ff_chain_op* d = c->dev_ops + c->used_ops;
+  memcpy(h, t_rec.ops.data(), n * sizeof(ff_chain_op));
+  c->used_ops += n;
+  FF_CHECK_HIP(hipMemcpyAsync(d, h, n * sizeof(ff_chain_op), hipMemcpyHostToDevice, st));
+  unsigned* ctr = c->flow_ctr;
+  unsigned* done = c->flow_ctr + (size_t)FF_FLOW_MAX_OPS * FLOW_PANELS;
+  unsigned* err = c->flow_ctr + (size_t)2 * FF_FLOW_MAX_OPS * FLOW_PANELS;
+  {
+    FFProfScope prof(FF_CAT_GEMM, t_rec.flops, st);
+    double bytes = 0;
+    for (const ff_chain_op& op : t_rec.ops) {
+      const GemmArgs& g = op.u.g;
+      bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * (g.res ? 2 : 1));
+    }
+    ff_prof_add_bytes(FF_CAT_GEMM, bytes);
+    FF_RETURN_IF(ff_gemm_flow_launch(d, (int)n, ctr, done, err, FLOW_PANELS, st));
+  }
+  c->flow_launches++;
+  t_rec.ops.clear();
+  *launched = 1;
   return FF_OK;
 }
 
 int ff_chain_begin() {
+  t_rec.flow = false;
   t_rec.active = true;
   t_rec.failed = false;
   t_rec.skip_barrier = false;
@@ -354,6 +426,7 @@ int ff_chain_begin() {
 
 void ff_chain_abort() {
   t_rec.active = false;
+  t_rec.flow = false;
   t_rec.ops.clear();
 }
 
@@ -426,9 +499,15 @@ int ff_chain_check(hipStream_t st) {
   ChainCtx* c;
   FF_RETURN_IF(ctx_get(&c));
   if (!c->ready) return FF_OK;
-  unsigned err = 0;
+  unsigned err = 0, ferr = 0;
   FF_CHECK_HIP(hipMemcpyAsync(&err, c->flags + 16 * c->G + 32, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  FF_CHECK_HIP(hipMemcpyAsync(&ferr, c->flow_ctr + (size_t)2 * FF_FLOW_MAX_OPS * FLOW_PANELS, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   FF_CHECK_HIP(hipStreamSynchronize(st));
+  if (ferr != 0) {
+    ff_set_error("ff_decode: a row-panel dependency of a flow launch timed out (code %u): its workgroups were not all resident "
+                 "(another process on the device?); re-run without FF_FLOW", ferr);
+    return FF_ERR_LAUNCH;
+  }
   if (err != 0) {
     ff_set_error("ff_decode: a grid-wide phase boundary of the chain kernel timed out (code %u): the workgroups of the launch were "
                  "not all resident (another process on the device?); re-run without FF_CHAIN", err);

@@ -276,7 +276,15 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   // LayerNorm it replaces (MI355X: +7..14 % on a 9216-row projection vs +5..10 us for the LayerNorm launch), so the
   // fused form is used up to ln_fuse_max_rows active rows (default 4096) -- both forms are parity-tested.
   const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows : 4096;
-  const bool fuse = can_fuse_layernorm(m, prm) && R <= fuse_max;
+  // Flow launches (FF_FLOW): the dependent projections between two attention operators -- out-proj -> q-proj and
+  // out-proj -> linear1 -> linear2 -> the next layer's q|k|v -- run inside ONE persistent launch each, tile by tile behind
+  // row-panel dependency counters (ff_gemm.hip: gemm_flow_kernel).  They need the LayerNorm-folded forms, so a step that takes
+  // them folds at every size; steps below flow_min_rows rows keep the small-M kernels.
+  const int flow_min = prm->flow_min_rows > 0 ? prm->flow_min_rows : 1025;
+  const bool flow = (prm->flags & FF_FLOW) && can_fuse_layernorm(m, prm) && R >= flow_min && (E % 64) == 0 && (FFd % 64) == 0 &&
+                    !ff_chain_recording() && getenv("FF_NO_FLOW") == nullptr &&
+                    (getenv("FF_FLOW_MAX_ROWS") == nullptr || R <= atoi(getenv("FF_FLOW_MAX_ROWS")));   // (probe knob)
+  const bool fuse = can_fuse_layernorm(m, prm) && (R <= fuse_max || flow);
   const int nseg = E / 32;
   const float* qpos = m->qpos_table;
   const float* qpos_new = qpos + (size_t)(t - 1) * E;
@@ -295,6 +303,29 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     return ff_gemm_f32_ln(&d, st);
   };
 
+  // the LayerNorm-folded projection over all R rows that opens layer l2 > 0: q|k|v, or k|v alone when the layer is pruned to
+  // its newest position (its q then covers Bc rows only)
+  auto first_proj = [&](int l2) -> int {
+    const ff_layer_weights& w2 = m->dec[l2];
+    if (prune_last && l2 == nd - 1 && t > 1)
+      return gemm_ln(buf.x, E, w2.ln1_w + (size_t)E * E, E, w2.ln1_b + E, nullptr, 0, buf.qkv + E, 3 * E, R, 2 * E, E, 0,
+                     buf.lnstat, w2.ln1_pos + E, 2 * E, E, nullptr);
+    return gemm_ln(buf.x, E, w2.ln1_w, E, w2.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat, w2.ln1_pos, 2 * E,
+                   2 * E, nullptr);
+  };
+  // runs `ops` (a few dependent projections) as ONE flow launch when possible, operator by operator otherwise
+  auto flow_or_launch = [&](bool want_flow, auto&& ops) -> int {
+    if (want_flow) {
+      int launched = 0;
+      FF_RETURN_IF(ff_flow_begin());
+      const int rc = ops();
+      if (rc != FF_OK) { ff_chain_abort(); return rc; }
+      FF_RETURN_IF(ff_flow_end(st, &launched));
+      if (launched) return FF_OK;
+    }
+    return ops();
+  };
+  bool first_done = false;   // the previous layer's flow launch already ran this layer's first projection
   for (int l = (phase == 2 ? nd - 1 : 0); l < nd; ++l) {
     const ff_layer_weights& w = m->dec[l];
     const bool last = prune_last && (l == nd - 1);
@@ -310,16 +341,13 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
                         ck.qkv0 + newoff * 3 * E, 3 * E, Bc, 3 * E, E, 0, st));
       QKV = ck.qkv0;
     } else if (fuse && l > 0) {
+      if (!first_done) FF_RETURN_IF(first_proj(l));
+      first_done = false;
       if (last && t > 1) {
-        // the pruned last layer attends from its newest position only: k | v for every row, q for the last Bc rows
-        FF_RETURN_IF(gemm_ln(xin, E, w.ln1_w + (size_t)E * E, E, w.ln1_b + E, nullptr, 0, buf.qkv + E, 3 * E, R, 2 * E, E,
-                             0, buf.lnstat, w.ln1_pos + E, 2 * E, E, nullptr));
+        // the pruned last layer attends from its newest position only: k | v for every row (above), q for the last Bc rows
         ff_chain_next_is_independent();   // (chain launches: k|v and q share a phase)
         FF_RETURN_IF(gemm_ln(xin + newoff * E, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E,
                              0, buf.lnstat + newoff * nseg * 2, w.ln1_pos + (size_t)(t - 1) * 2 * E, 2 * E, E, nullptr));
-      } else {
-        FF_RETURN_IF(gemm_ln(xin, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat,
-                             w.ln1_pos, 2 * E, 2 * E, nullptr));
       }
       QKV = buf.qkv;
     } else {
@@ -360,12 +388,15 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       FF_RETURN_IF(ff_attention(&d, st));
     }
     float* qc = buf.qkv;  // [rows, E] view of the scratch
+    const bool flow_here = flow && Rl >= flow_min;
     if (fuse) {
-      FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
-                           buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
-      // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
-      FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
-                           w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr));
+      FF_RETURN_IF(flow_or_launch(flow_here, [&]() -> int {
+        FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
+                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
+        // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
+        return gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
+                       w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr);
+      }));
     } else {
       FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
                               w.self_attn.out_b, xin + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
@@ -397,13 +428,19 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       FF_RETURN_IF(ff_attention(&d, st));
     }
     if (fuse) {
-      FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.cross_attn.out_w, E, w.cross_attn.out_b, buf.x + roff * E, E,
-                           buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
-      // ---- feed forward (transformer.py:253-255) ----
-      FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln3_w, E, w.ln3_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl, FFd, E, 1,
-                           stat, nullptr, 0, 0, nullptr));
-      FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
-                           Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat));
+      // the flow launch also takes the next layer's first projection (same R rows) when there is one
+      const bool with_next = flow_here && !last && l + 1 < nd;
+      FF_RETURN_IF(flow_or_launch(flow_here, [&]() -> int {
+        FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.cross_attn.out_w, E, w.cross_attn.out_b, buf.x + roff * E, E,
+                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
+        // ---- feed forward (transformer.py:253-255) ----
+        FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln3_w, E, w.ln3_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl, FFd, E, 1,
+                             stat, nullptr, 0, 0, nullptr));
+        FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
+                             Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat));
+        return with_next ? first_proj(l + 1) : FF_OK;
+      }));
+      first_done = with_next;
     } else {
       FF_RETURN_IF(gemm_or_x3(prm, w.cross_out_planes, buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E,
                               w.cross_attn.out_b, buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
@@ -618,6 +655,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   // CUs could wait for each other for ever), and operand widths the small-M projection forms take.
   auto chain_dim_ok = [](int k) { return k == 128 || k == 256 || k == 512 || k == 1024; };
   const bool use_chain = (p->flags & FF_CHAIN) && ns == 1 && chain_dim_ok(E) && chain_dim_ok(m->FF) && getenv("FF_NO_CHAIN") == nullptr;
+  if (ns != 1) prm_local.flags &= ~(FF_CHAIN | FF_FLOW);   // (p points at prm_local) persistent launches: one stream only
+  const bool use_flow = (p->flags & FF_FLOW) != 0;
   const long chain_rows = p->chain_max_rows > 0 ? p->chain_max_rows : 1024;
   int chain_launches = 0;
   int enq = 0;
@@ -650,7 +689,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
 
     // ---- greedy loop -----------------------------------------------------------------------------------
     const int max_steps = T - 1;
-    if (use_chain)   // descriptor ring + sync words of this decode (zeroed behind the work queued so far)
+    if (use_chain || use_flow)   // descriptor ring + sync words of this decode (zeroed behind the work queued so far)
       FF_RETURN_IF(ff_chain_prepare((size_t)max_steps * chunks.size() * (size_t)(12 * m->num_dec_layers + 16), main_st));
     const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
@@ -782,7 +821,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
                                   sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
     FF_CHECK_HIP(hipStreamSynchronize(main_st));
     if (steps_done) *steps_done = steps;
-    if (chain_launches > 0) FF_RETURN_IF(ff_chain_check(main_st));   // a phase boundary that timed out voids the results
+    if (chain_launches > 0 || use_flow) FF_RETURN_IF(ff_chain_check(main_st));   // a boundary / dependency that timed out voids the results
 
     // ---- optional: project(decoder(...)) of every prefix row at the last executed step
     //      (SurfaceFormer returns it as inputs['pointer'], reference model.py:217) --------------------

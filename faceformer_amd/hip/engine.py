@@ -192,7 +192,7 @@ class PathEngine:
 
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
                chunk_wireframes=0, chunk_seqs=0, num_streams=1, sync_every=4, flags=DEFAULT_FLAGS,
-               tok_sos=1, tok_eos=3, x3_min_rows=0, chunk_max_seqs=0, ln_fuse_max_rows=0, chain_max_rows=0,
+               tok_sos=1, tok_eos=3, x3_min_rows=0, chunk_max_seqs=0, ln_fuse_max_rows=0, chain_max_rows=0, flow_min_rows=0,
                trace=False, return_pointer=False, no_stop=False):
         """Greedy decode. Returns dict(predict [N*F, T] int64, steps, decoded_seqs, [pointer], [trace
         tensors indexed like predict's rows])."""
@@ -207,6 +207,7 @@ class PathEngine:
         prm.chunk_max_seqs = int(chunk_max_seqs)
         prm.ln_fuse_max_rows = int(ln_fuse_max_rows)
         prm.chain_max_rows = int(chain_max_rows)
+        prm.flow_min_rows = int(flow_min_rows)
         prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0) | (_L.FF_NO_STOP if no_stop else 0)
         if return_pointer or extra_mask is not None:   # (every padding-anchor row has its own extra-mask row)
             prm.flags &= ~_L.FF_DEDUP_PAD_ANCHORS

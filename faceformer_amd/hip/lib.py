@@ -15,6 +15,7 @@ FF_PARALLEL, FF_SEQ2SEQ = 0, 1
 FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP, FF_DEDUP_PAD_ANCHORS = 1, 2, 4, 8, 16
 FF_FUSE_LAYERNORM = 32
 FF_CHAIN = 64
+FF_FLOW = 128
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -94,7 +95,7 @@ class DecodeParams(C.Structure):
         ("sync_every", C.c_int), ("flags", C.c_int),
         ("tok_sos", C.c_int), ("tok_eos", C.c_int),
         ("x3_min_rows", C.c_int), ("chunk_max_seqs", C.c_int), ("ln_fuse_max_rows", C.c_int),
-        ("chain_max_rows", C.c_int),
+        ("chain_max_rows", C.c_int), ("flow_min_rows", C.c_int),
     ]
 
 

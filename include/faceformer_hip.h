@@ -331,6 +331,11 @@ enum ff_decode_flags {
                                 launch whose operators are separated by grid-wide phase boundaries instead of kernel boundaries
                                 (same device code, agent-coherent accesses).  Single-stream decodes only (num_streams <= 1);
                                 needs E, FF in {128, 256, 512, 1024}; otherwise ignored */
+  FF_FLOW = 128,             /* flow launches (ff_gemm.hip, gemm_flow_kernel): on decode steps with at least flow_min_rows active rows
+                                the dependent projections between two attention operators (out-proj -> q-proj; out-proj -> linear1
+                                -> linear2 -> the next layer's q|k|v) run inside ONE persistent launch each, tile by tile behind
+                                row-panel dependency counters; implies the LayerNorm-folded forms at every size (needs what
+                                FF_FUSE_LAYERNORM needs) */
   FF_DEDUP_PAD_ANCHORS = 16  /* parallel variant: the F - num_input[w] padding-anchor sequences of a wireframe
                                 (start token num_token-1, reference model_para.py:204-205) are identical by
                                 construction; decode ONE of them and copy its tokens into all those rows of
@@ -360,6 +365,7 @@ typedef struct ff_decode_params {
                            (t * sequences of the micro-batch); 0: the default (4096) */
   int chain_max_rows;   /* FF_CHAIN: a step of a micro-batch with at most this many active rows is one chain launch, and the
                            tail of a larger step when the micro-batch has at most this many sequences; 0: the default (1024) */
+  int flow_min_rows;    /* FF_FLOW: steps (and layer tails) with at least this many rows take the flow launches; 0: 1025 */
 } ff_decode_params;
 
 /* Greedy pointer decode (a5-a12 of SURVEY.md 8a).

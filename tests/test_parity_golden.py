@@ -45,13 +45,13 @@ def run_traced(model, case, batch):
                          chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                          chunk_max_seqs=model.chunk_max_seqs, num_streams=model.num_streams,
                          ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0),
-                         chain_max_rows=getattr(model, "chain_max_rows", 0))
+                         chain_max_rows=getattr(model, "chain_max_rows", 0), flow_min_rows=getattr(model, "flow_min_rows", 0))
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          extra_mask=extra, flags=model.decode_flags, return_pointer=True,
                          x3_min_rows=model.x3_min_rows,
                          chunk_wireframes=model.chunk_wireframes,
-                         chain_max_rows=getattr(model, "chain_max_rows", 0))
+                         chain_max_rows=getattr(model, "chain_max_rows", 0), flow_min_rows=getattr(model, "flow_min_rows", 0))
     out["memory"] = memory
     return out
 
@@ -182,6 +182,25 @@ def test_golden_parity_with_chain_launches(hip_lib, name, chain_rows):
     stats = compare_with_golden(case, z, out)
     print(name, chain_rows, stats)
     _record_margin(name, "chain launches <= %d rows" % (chain_rows or 1024), stats)
+
+
+@pytest.mark.parametrize("flow_rows", [0, 1])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_parity_with_flow_launches(hip_lib, name, flow_rows):
+    """FF_FLOW: the dependent projections between two attention operators run inside one persistent launch each, tile by tile
+    behind row-panel dependency counters (steps with at least `flow_rows` active rows; 0 = the default 1025, 1 = every step of
+    every golden incl. the two-row ones).  Same bars as the launch-per-operator path."""
+    from faceformer_amd.hip import lib as L
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    model.decode_flags = model.decode_flags | L.FF_FLOW
+    model.flow_min_rows = flow_rows
+    model.x3_min_rows = 0
+    out = run_traced(model, case, batch_to(batch, "cuda"))
+    stats = compare_with_golden(case, z, out)
+    print(name, flow_rows, stats)
+    _record_margin(name, "flow launches >= %d rows" % (flow_rows or 1025), stats)
 
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak",
