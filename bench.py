@@ -202,7 +202,7 @@ def main():
     ap.add_argument("--chain-max-rows", type=int, default=0, help="FF_CHAIN row limit of a whole-step chain (0: 1024)")
     ap.add_argument("--flow", type=int, default=-1, help="flow launches (FF_FLOW): 1 on, 0 off, -1 the package default")
     ap.add_argument("--flow-min-rows", type=int, default=0, help="FF_FLOW: rows from which a step takes the flow launches (0: 1025)")
-    ap.add_argument("--ln-fuse-max-rows", type=int, default=0, help="LayerNorm folded into the projections up to this many rows (0: 4096)")
+    ap.add_argument("--ln-fuse-max-rows", type=int, default=0, help="LayerNorm folded into the projections up to this many rows (0: 12288)")
     ap.add_argument("--plain-multi", action="store_true",
                     help="N > 1: time the plain per-rank model(batch) + all-gather (the round-2 form) instead of decode_sharded")
     args = ap.parse_args()

@@ -271,11 +271,12 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   const size_t newoff = (size_t)(t - 1) * Bc;
   const bool reuse0 = (prm->flags & FF_REUSE_LAYER0_QKV) != 0 && ck.qkv0 != nullptr;
   const bool prune_last = (prm->flags & FF_LAST_LAYER_LAST_ROW) != 0 && !full_rows;
-  // Folding the LayerNorms into the projections removes 18 launches per step, which pays while the step is
-  // launch / latency bound; on the large steps the normalising consumer kernel costs more than the standalone
-  // LayerNorm it replaces (MI355X: +7..14 % on a 9216-row projection vs +5..10 us for the LayerNorm launch), so the
-  // fused form is used up to ln_fuse_max_rows active rows (default 4096) -- both forms are parity-tested.
-  const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows : 4096;
+  // Folding the LayerNorms into the projections removes 18 launches per step.  On MI355X the normalising consumer costs about
+  // what the standalone LayerNorm launch it replaces costs up to ~10^4 rows (round 3, once the position-table term of the
+  // epilogue became ONE load per lane: config B 62.1-62.4 ms folded at every step vs 62.6 with the round-2 limit of 4096 rows);
+  // above that the plain launches take the 128x64-tile kernel, which the fused forms do not have (config C / E micro-batches),
+  // so the fused form is used up to ln_fuse_max_rows active rows (default 12288) -- both forms are parity-tested.
+  const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows : 12288;
   // Flow launches (FF_FLOW): the dependent projections between two attention operators -- out-proj -> q-proj and
   // out-proj -> linear1 -> linear2 -> the next layer's q|k|v -- run inside ONE persistent launch each, tile by tile behind
   // row-panel dependency counters (ff_gemm.hip: gemm_flow_kernel).  They need the LayerNorm-folded forms, so a step that takes

@@ -81,11 +81,17 @@ __device__ __forceinline__ void ff_load_rowtab(const GemmArgs& g, int row0, int 
   const float* tp = g.rowtab + colc;
   if (div >= 28) {
     const int q0 = row0 / div, rem0 = row0 - q0 * div;
+    if (rem0 + 27 < div) {   // the lane's 28-row span lies inside ONE table row (always, when div is a multiple of 64): one load
+      const float v = ff_ldw<COH>(tp + (size_t)(q0 < qmax ? q0 : qmax) * g.ld_rowtab);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      int q = q0 + ((rem0 + (e & 3) + 8 * (e >> 2)) >= div ? 1 : 0);
-      q = q < qmax ? q : qmax;
-      rv[e] = ff_ldw<COH>(tp + (size_t)q * g.ld_rowtab);
+      for (int e = 0; e < 16; ++e) rv[e] = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int q = q0 + ((rem0 + (e & 3) + 8 * (e >> 2)) >= div ? 1 : 0);
+        q = q < qmax ? q : qmax;
+        rv[e] = ff_ldw<COH>(tp + (size_t)q * g.ld_rowtab);
+      }
     }
   } else {
 #pragma unroll

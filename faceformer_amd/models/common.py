@@ -50,7 +50,7 @@ class SurfaceFormerBase(nn.Module):
         self.num_streams = 1           # micro-batches are issued round-robin on this many HIP streams
         self.chunk_max_seqs = 8192     # ... and at most this many sequences per micro-batch of several wireframes
         self.sort_by_edges = True      # ragged batches: decode the wireframes sorted by edge count (tight micro-batches)
-        self.ln_fuse_max_rows = 0      # LayerNorm folded into the projections on steps with at most this many rows (0: 4096)
+        self.ln_fuse_max_rows = 0      # LayerNorm folded into the projections on steps with at most this many rows (0: 12288)
         self.flow_min_rows = 0         # FF_FLOW: steps with at least this many rows take the flow launches (0: 1025)
         self.chain_max_rows = 0        # FF_CHAIN: steps with at most this many active rows run as ONE persistent launch (0: 1024)
         self.sync_every = 4            # host evaluation period of the stop rule

@@ -133,7 +133,11 @@ def test_golden_parity_on_the_f32_matrix_cores_only(hip_lib, name):
     out = run_traced(model, case, batch_to(batch, "cuda"))
     st = compare_with_golden(case, z, out)
     print(name, "f32", st)
+    _record_margin(name, "f32 MFMA only, LN folded <= 12288", st)
+    model.ln_fuse_max_rows = 4096      # the mixed form: steps above the limit run standalone LayerNorm launches
+    st = compare_with_golden(case, z, run_traced(model, case, batch_to(batch, "cuda")))
     _record_margin(name, "f32 MFMA only, LN folded <= 4096", st)
+    model.ln_fuse_max_rows = 0
     from faceformer_amd.hip import lib as L
     model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
     out = run_traced(model, case, batch_to(batch, "cuda"))
