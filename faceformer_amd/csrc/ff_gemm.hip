@@ -1005,12 +1005,15 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   // (sc1 accesses that bypass the non-coherent cache levels), ordered by vmcnt(0) + the block barrier
   // on the writer and by the data dependence on the flag on the reader.
   auto end_segment = [&]() {
-    if (cp_kind == 1) {  // hand over the raw accumulators: slot[lb][e][tid]
-      float* wp = sk.ws + (size_t)lb * 4096 + tid;
+    if (cp_kind == 1) {  // hand over the raw accumulators: slot[lb][4 quads][256 threads] float4
+      // 16-byte write-through (sc1) stores: four fabric writes per thread instead of sixteen 4-byte ones (MI355X: a scalar
+      // sc1 store is one fabric write whatever its width; inline asm: the compiler has no vector form of an agent-scope access)
+      f32x4* wp = reinterpret_cast<f32x4*>(sk.ws + (size_t)lb * 4096) + tid;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        __hip_atomic_store(wp + e * 256, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        acc[e] = 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + q * 256), "v"(v) : "memory");
+        acc[4 * q] = 0.f; acc[4 * q + 1] = 0.f; acc[4 * q + 2] = 0.f; acc[4 * q + 3] = 0.f;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -1025,13 +1028,14 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
         while (__hip_atomic_load(sk.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
           __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        const float* rp = sk.ws + (size_t)c * 4096 + tid;
-        float t[16];
+        const f32x4* rp = reinterpret_cast<const f32x4*>(sk.ws + (size_t)c * 4096) + tid;
+        f32x4 t[4];   // the four loads in flight together: one memory round trip per contributor
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          t[e] = __hip_atomic_load(rp + e * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 4; ++q)
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[q]) : "v"(rp + q * 256) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] += t[e];
+        for (int e = 0; e < 16; ++e) acc[e] += t[e >> 2][e & 3];
       }
       __syncthreads();  // every thread is past its flag polls
       if (tid < lb - c0) __hip_atomic_store(sk.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1432,7 +1436,12 @@ int ff_gemm_flow_launch(const ff_chain_op* dev_ops, int nops, unsigned* ctr, uns
   FF_RETURN_IF(set_lds_limit(&gemm_flow_kernel, bytes, &attr_set));
   static const int nodep = getenv("FF_FLOW_NODEP") ? atoi(getenv("FF_FLOW_NODEP")) : 0;
   FlowSync sync{ctr, done, err, panel_stride, nodep};
-  hipLaunchKernelGGL(gemm_flow_kernel, dim3(512), dim3(256), bytes, st, dev_ops, nops, sync);
+  // every workgroup of the launch must be resident (dependency waits): two per CU, as many as the device has CUs for
+  int dev = 0, cus = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  FF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = cus >= 256 ? 512 : (cus > 0 ? 2 * cus : 2);
+  hipLaunchKernelGGL(gemm_flow_kernel, dim3(grid), dim3(256), bytes, st, dev_ops, nops, sync);
   FF_CHECK_LAUNCH();
   return FF_OK;
 }

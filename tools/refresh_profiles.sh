@@ -4,7 +4,7 @@
 # the seq2seq timings, the attention sweeps, the projection-kernel tables (tile variants vs the vendor library, zero-filled
 # operands, LayerNorm-fused forms), the vendor kernel names and the MFMA micro-benchmarks.  Results land in gpurun_out/profiles_<tag>/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -25,8 +25,14 @@ timeout 600 python tools/bench_gemm_ln.py > $OUT/gemm_ln_fusion.txt 2>&1
 ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && rm -rf /tmp/vn &&
   rocprofv3 --kernel-trace --stats -d /tmp/vn -o v -- python tools/vendor_names.py > /dev/null 2>&1 &&
   python tools/rocpd_stats.py /tmp/vn/v_results.db $OUT/vendor_kernels.md > /dev/null 2>&1; rm -rf /tmp/vn )
-for u in mfma_chain mfma_lds; do
-  hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o /tmp/$u 2>/dev/null && /tmp/$u > $OUT/ubench_$u.txt 2>&1
+for u in mfma_chain mfma_lds grid_phase launch_floor; do
+  hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o /tmp/$u 2>/dev/null && timeout 120 /tmp/$u > $OUT/ubench_$u.txt 2>&1
 done
+python tools/make_traffic_json.py $OUT > /dev/null 2>&1
+# round 3: the persistent-launch experiments (opt-in FF_CHAIN / FF_FLOW): per-operator trace, same-box A/Bs
+FF_CHAIN_TRACE=100 timeout 300 python tools/trace_chain.py 2> $OUT/chain_trace.txt > /dev/null
+bash tools/run_chain_ab.sh > $OUT/chain_ab.txt 2>&1
+bash tools/run_flow_probe.sh > $OUT/flow_probe.txt 2>&1
+bash tools/run_ln_probe.sh > $OUT/ln_fold_sweep.txt 2>&1
 ls -la $OUT
 tail -c 1500 $OUT/bench_${TAG}_B.json
