@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--chain", type=int, default=-1,
                     help="chain launches (FF_CHAIN): 1 on, 0 off, -1 the package default")
     ap.add_argument("--chain-max-rows", type=int, default=0, help="FF_CHAIN row limit of a whole-step chain (0: 1024)")
+    ap.add_argument("--graphs", type=int, default=-1, help="step graphs (FF_GRAPH): 1 on, 0 off, -1 the package default (off)")
     ap.add_argument("--flow", type=int, default=-1, help="flow launches (FF_FLOW): 1 on, 0 off, -1 the package default")
     ap.add_argument("--flow-min-rows", type=int, default=0, help="FF_FLOW: rows from which a step takes the flow launches (0: 1025)")
     ap.add_argument("--ln-fuse-max-rows", type=int, default=0, help="LayerNorm folded into the projections up to this many rows (0: 12288)")
@@ -272,6 +273,10 @@ def main():
         elif args.flow == 0:
             mod.decode_flags = mod.decode_flags & ~L.FF_FLOW
         mod.flow_min_rows = args.flow_min_rows
+        if args.graphs == 1:
+            mod.decode_flags = mod.decode_flags | L.FF_GRAPH
+        elif args.graphs == 0:
+            mod.decode_flags = mod.decode_flags & ~L.FF_GRAPH
         mod.ln_fuse_max_rows = args.ln_fuse_max_rows
 
     def steps_executed(pred):   # pred [N, F, T] or [N, T]

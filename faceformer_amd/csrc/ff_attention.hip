@@ -550,6 +550,7 @@ int g_attention_algo = 0;  // 0 = automatic, 1 = block-shared LDS staging, 2 = w
 extern "C" int ff_set_attention_algo(int algo) {
   const int old = g_attention_algo;
   g_attention_algo = algo;
+  ff_tuning_changed();
   return old;
 }
 

@@ -64,6 +64,11 @@ struct FFProfScope {
   }
 };
 
+// bumped by every setter that changes how an operator is launched (ff_set_gemm_tuning, ff_set_attention_algo): captured step
+// graphs (ff_engine.hip) are keyed on it
+unsigned long long ff_tuning_epoch();
+void ff_tuning_changed();
+
 // partial-tile workspace of the 3 x bf16 kernel for (current device, stream): allocate now (ff_gemm_x3.hip)
 extern "C" int ff_x3_prepare_stream(hipStream_t st);
 

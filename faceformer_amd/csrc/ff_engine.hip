@@ -13,9 +13,11 @@
 //                               the active rows of step t are the first t*Bc rows: every GEMM of
 //                               the step is one dense [t*Bc, K] x [K, N] product)
 // Sequences b of a micro-batch belong to wireframe w0 + b / F; nothing is replicated per sequence.
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "ff_common.h"
@@ -516,6 +518,51 @@ int pool_get(int n, StreamPool** out) {
   return FF_OK;
 }
 
+// ---- step graphs (FF_GRAPH) ----------------------------------------------------------------------------------------------
+// A decode step of a small micro-batch is ~50 dependent launches of a few microseconds each, and on a stream every one
+// of them pays the full dependent-dispatch cost (tools/ubench/launch_floor.hip: 4.6-5.3 us per small kernel that writes
+// memory, 1.5-2.3 us for the same kernels as nodes of a hipGraph).  The launches of step t are a pure function of the
+// call's arguments (tokens travel through device memory), so the steps of a decode whose arguments were seen before
+// are captured once -- one graph per step, so that the host's stop rule keeps working between them -- and replayed.
+struct StepGraphs {
+  std::string key;                     // every byte the launches depend on (graph_key)
+  std::vector<hipGraphExec_t> exec;    // [step]; nullptr: not captured
+  int seen;                            // decodes that presented this key
+  unsigned long long last_use;
+};
+struct GraphCache {
+  std::vector<StepGraphs> entries;
+  unsigned long long tick;
+};
+GraphCache g_graph_cache[FF_MAX_DEVICES];   // guarded by g_pool_busy[dev] (one decode per device at a time)
+std::atomic<int> g_graph_last_captured{0}, g_graph_last_replayed{0};   // steps of the calling process's latest ff_decode
+constexpr size_t FF_GRAPH_ENTRIES = 8;
+
+void graphs_release(StepGraphs& e) {
+  for (hipGraphExec_t g : e.exec) if (g) (void)hipGraphExecDestroy(g);
+  e.exec.clear();
+}
+
+template <typename T>
+void key_add(std::string& k, const T& v) { k.append(reinterpret_cast<const char*>(&v), sizeof(T)); }
+
+// The entry of `key` (created on first sight; least recently used entry evicted).  Callers hold the device's busy mutex
+// and every earlier decode has drained its streams, so no graph of an evicted entry is still running.
+StepGraphs* graphs_lookup(int dev, const std::string& key, int max_steps) {
+  GraphCache& gc = g_graph_cache[dev];
+  ++gc.tick;
+  for (StepGraphs& e : gc.entries)
+    if (e.key == key) { e.last_use = gc.tick; ++e.seen; return &e; }
+  if (gc.entries.size() >= FF_GRAPH_ENTRIES) {
+    size_t lru = 0;
+    for (size_t i = 1; i < gc.entries.size(); ++i) if (gc.entries[i].last_use < gc.entries[lru].last_use) lru = i;
+    graphs_release(gc.entries[lru]);
+    gc.entries.erase(gc.entries.begin() + lru);
+  }
+  gc.entries.push_back(StepGraphs{key, std::vector<hipGraphExec_t>((size_t)max_steps, nullptr), 1, gc.tick});
+  return &gc.entries.back();
+}
+
 std::mutex* pool_busy_mutex() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FF_MAX_DEVICES) return nullptr;
@@ -589,6 +636,11 @@ extern "C" int ff_encode(const ff_model* m, const float* input, const unsigned c
   return FF_OK;
 }
 
+extern "C" void ff_graph_stats(int* captured_steps, int* replayed_steps) {
+  if (captured_steps) *captured_steps = g_graph_last_captured.load();
+  if (replayed_steps) *replayed_steps = g_graph_last_replayed.load();
+}
+
 extern "C" size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p, const int* num_input_host) {
   if (!m || !p || p->N <= 0 || p->F <= 0 || p->T <= 0) return 0;
   int btot = 0, max_bc = 0;
@@ -635,6 +687,11 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
   }
   const int ns = ns_req < (int)chunks.size() ? ns_req : (int)chunks.size();
+  // Step graphs: single-stream decodes only (a micro-batch per stream has steps long enough not to need them), never while
+  // the per-launch event profile is on (events inside a capture would time nothing), never with the persistent launches.
+  const bool use_graph = (p->flags & FF_GRAPH) && ns == 1 && !(p->flags & (FF_CHAIN | FF_FLOW)) && !ff_prof_enabled() &&
+                         getenv("FF_NO_GRAPH") == nullptr;
+  const bool forked = ns > 1 || use_graph;   // the decode runs on the pool's streams (a capture cannot start on the legacy default stream)
   // With more than one stream ALL micro-batch work runs on the internal pool (the caller's stream is
   // often the legacy default stream, whose implicit synchronisation would serialise the others).
   hipStream_t sts[FF_MAX_STREAMS];
@@ -644,8 +701,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   std::mutex* busy = pool_busy_mutex();
   FF_CHECK_ARG(busy, "ff_decode: no current device");
   std::lock_guard<std::mutex> one_decode_per_device(*busy);
-  FF_RETURN_IF(pool_get(ns > 1 ? ns : 0, &pool));   // (also owns the pinned counter buffer / events of the stop check)
-  if (ns > 1)
+  FF_RETURN_IF(pool_get(forked ? ns : 0, &pool));   // (also owns the pinned counter buffer / events of the stop check)
+  if (forked)
     for (int s = 0; s < ns; ++s) sts[s] = pool->side[s];
   auto sync_all = [&]() -> int {
     for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamSynchronize(sts[s]));
@@ -661,6 +718,25 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   const long chain_rows = p->chain_max_rows > 0 ? p->chain_max_rows : 1024;
   int chain_launches = 0;
   int enq = 0;
+  StepGraphs* graphs = nullptr;
+  // steps per graph: the stop rule is looked at between graphs only (a graph launch costs the host ~55 us)
+  const int graph_steps = getenv("FF_GRAPH_STEPS") && atoi(getenv("FF_GRAPH_STEPS")) > 0 ? atoi(getenv("FF_GRAPH_STEPS"))
+                          : (p->sync_every > 0 && !(p->flags & FF_NO_STOP) ? p->sync_every : T);
+  if (use_graph) {
+    int dev = 0;
+    FF_CHECK_HIP(hipGetDevice(&dev));
+    std::string key;
+    key_add(key, *m); key_add(key, prm_local);
+    const void* ptrs[] = {memory, mask, kv_len, num_input, extra_mask, trace_logits, trace_best, trace_second, workspace, (const void*)sts[0]};
+    key_add(key, ptrs); key_add(key, workspace_bytes); key_add(key, ff_tuning_epoch()); key_add(key, graph_steps);
+    for (const Chunk& c : chunks) {   // (field by field: the struct has padding bytes)
+      const int ci[] = {c.w0, c.nw, c.Fc, c.f0, c.b0, c.Bc, c.sid};
+      const void* cp[] = {c.x0, c.qkv0};
+      key_add(key, ci); key_add(key, cp);
+    }
+    graphs = graphs_lookup(dev, key, T - 1);
+  }
+  int graph_replays = 0, graph_captures = 0;
   // Everything that enqueues work on the side streams sits in this lambda: on ANY failure the streams are
   // drained before the error is returned (the caller frees the workspace the queued kernels use).
   auto run = [&]() -> int {
@@ -674,7 +750,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     }
     FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * T, main_st));
     FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * T, main_st));
-    if (ns > 1) {  // fork
+    if (forked) {  // fork
       FF_CHECK_HIP(hipEventRecord(pool->fork_ev, main_st));
       for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], pool->fork_ev, 0));
     }
@@ -711,7 +787,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       }
       return false;
     };
-    for (int step = 0; step < max_steps && !stopped; ++step) {
+    auto enqueue_step = [&](int step) -> int {
       const int t = step + 1;
       for (const Chunk& c : chunks) {
         hipStream_t st = sts[c.sid];
@@ -749,8 +825,36 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
           FF_RETURN_IF(pointer_head());
         }
       }
-      enq = step + 1;
-      if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
+      return FF_OK;
+    };
+    const int gsteps = graphs ? graph_steps : 1;
+    for (int step = 0; step < max_steps && !stopped;) {
+      const int nstep = gsteps < max_steps - step ? gsteps : max_steps - step;
+      hipGraphExec_t ge = nullptr;
+      if (graphs) {
+        // second sight of these arguments: capture the steps; from then on: replay
+        hipGraphExec_t& slot = graphs->exec[(size_t)step];
+        if (!slot && graphs->seen >= 2) {
+          FF_CHECK_HIP(hipStreamBeginCapture(sts[0], hipStreamCaptureModeRelaxed));
+          int rc = FF_OK;
+          for (int i = 0; i < nstep && rc == FF_OK; ++i) rc = enqueue_step(step + i);
+          hipGraph_t g = nullptr;
+          const hipError_t e = hipStreamEndCapture(sts[0], &g);
+          if (rc != FF_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+          FF_CHECK_HIP(e);
+          const hipError_t ei = hipGraphInstantiate(&slot, g, nullptr, nullptr, 0);
+          (void)hipGraphDestroy(g);
+          if (ei != hipSuccess) slot = nullptr;
+          FF_CHECK_HIP(ei);
+          graph_captures += nstep;
+        }
+        ge = slot;
+      }
+      if (ge) { FF_CHECK_HIP(hipGraphLaunch(ge, sts[0])); graph_replays += nstep; }
+      else for (int i = 0; i < nstep; ++i) FF_RETURN_IF(enqueue_step(step + i));
+      step += nstep;
+      enq = step;
+      if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && ((enq % p->sync_every) == 0 || nstep > 1) && enq < max_steps) {
         const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
         if (lagged) {
           if (pending_enq > 0) {
@@ -759,7 +863,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
             pending_enq = 0;
           }
           if (!stopped) {
-            if (ns > 1)
+            if (forked)
               for (int s = 0; s < ns; ++s) {
                 FF_CHECK_HIP(hipEventRecord(pool->chk_ev[s], sts[s]));
                 FF_CHECK_HIP(hipStreamWaitEvent(main_st, pool->chk_ev[s], 0));
@@ -777,15 +881,17 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
         }
       }
     }
+    g_graph_last_captured = graph_captures;
+    g_graph_last_replayed = graph_replays;
     if (pending_enq > 0) FF_CHECK_HIP(hipEventSynchronize(pool->chk_done));   // hpin is reused by the next call
     if (dbg_timing) {
       const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
       FF_RETURN_IF(sync_all());
       const double tot_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-      fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks (%d of %d sequences decoded): %.2f ms; "
-                      "until GPU idle: %.2f ms\n", enq, chunks.size(), Btot, N * F, host_ms, tot_ms);
+      fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks (%d of %d sequences decoded; %d steps captured, %d replayed): "
+                      "%.2f ms; until GPU idle: %.2f ms\n", enq, chunks.size(), Btot, N * F, graph_captures, graph_replays, host_ms, tot_ms);
     }
-    if (ns > 1) {  // join
+    if (forked) {  // join
       for (int s = 0; s < ns; ++s) {
         FF_CHECK_HIP(hipEventRecord(pool->join_ev[s], sts[s]));
         FF_CHECK_HIP(hipStreamWaitEvent(main_st, pool->join_ev[s], 0));

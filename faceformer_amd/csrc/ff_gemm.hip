@@ -29,6 +29,8 @@
 #include <mutex>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "ff_common.h"
 #include "ff_device.h"
 #include "ff_chain.h"
@@ -1226,26 +1228,210 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
   ff_gemm_small_tile<KQ, MODE, NW, false>(g, (int)blockIdx.x, (long long)blockIdx.y, red);
 }
 
+// ---- panel form of the small-M kernel: ONE coalesced memory round trip per 512-wide K chunk -------------------------------
+// gemm_small_kernel's lanes load their MFMA operands straight from global memory: 16 bytes of 32 different rows per instruction,
+// i.e. 32 cache lines touched per instruction and every line touched by 4 instructions -- 4096 line requests per 32x32x512
+// tile on the CU's one texture-address unit (~1.7 us of address processing), in two dependent batches (~1.5 us each: the
+// second is requested after the first has been consumed).  A launch of at most one tile per CU is nothing but that chain.
+// Here the eight waves of a block fetch the tile's A panel [32 x KC] and W panel [32 x KC] (KC <= 512 columns) with fully
+// coalesced 16-byte loads -- every line requested once, ALL requests of the chunk in flight together -- write them to LDS
+// (rows padded by 4 floats: conflict-free ds_read_b128 of the MFMA fragments), and wave w then multiplies its eighth of
+// the chunk exactly like gemm_small_kernel does (same k order inside a wave, same partial-tile reduction: same result bits).
+// K = 1024 runs two chunks.  LDS: 2 x 32 x 516 floats = 129 KB for KC = 512 -> one block per CU: used where the small-M
+// kernel ran its eight-wave form (at most one tile per CU).
+template <int KC, int MODE>  // MODE as gemm_persist_kernel
+__global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
+  constexpr int NW = 8, LD = KC + 4, KQ = KC / NW, NG = KQ / 8;
+  constexpr int NV = KC / 64;             // float4 per thread and panel
+  constexpr int RPW = 16 / NW;            // accumulator registers a wave finishes
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const As = lds;                  // [32][LD]
+  float* const Ws = lds + 32 * LD;        // [32][LD]
+  float* const lnrow = lds + 64 * LD;     // MODE 1: [32][2] (mean, rstd)
+  float* const red = lds;                 // after the MFMA chain: [8][16][64] partial tiles (+ MODE 2 patch [32][33])
+  static_assert(64 * LD >= NW * 16 * 64 + 32 * 33, "the partial tiles reuse the panel area");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+  const int m0 = (blockIdx.x / g.tiles_n) * 32, n0 = (blockIdx.x % g.tiles_n) * 32;
+  const long long bz = blockIdx.y;
+  const float* Asrc = ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + bz * g.batch_stride_a;
+  const float* Wsrc = g.W + bz * g.batch_stride_w;
+  // staging map: float4 i of this thread is chunk column c4 = (tid + 512 i) % (KC/4) of panel row (tid + 512 i) / (KC/4):
+  // a wave's instruction covers 1 KB of consecutive addresses of one row
+  constexpr int C4 = KC / 4;
+  const float* a_ptr[NV];
+  const float* w_ptr[NV];
+  int srow[NV];
+  int soff[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + 512 * i;
+    const int r = idx / C4, c4 = idx % C4;
+    int row = m0 + r, col = n0 + r;
+    row = row < g.M ? row : g.M - 1;
+    col = col < g.N ? col : g.N - 1;
+    a_ptr[i] = Asrc + (size_t)row * g.lda + c4 * 4;
+    w_ptr[i] = Wsrc + (size_t)col * g.ldw + c4 * 4;
+    srow[i] = r;
+    soff[i] = r * LD + c4 * 4;
+  }
+  f32x4 ra[NV], rw[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i]);
+    rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i]);
+  }
+  // epilogue operands and (MODE 1) row statistics ride in the same round trip
+  f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+  const int spart = lane & 7, strow = wave * (32 / NW) + ((lane >> 3) % (32 / NW));
+  if (MODE == 1) {
+    int r = m0 + strow;
+    r = r < g.M ? r : g.M - 1;
+    if (2 * spart < g.ln_nseg) sv = *reinterpret_cast<const f32x4*>(g.ln_in + ((size_t)r * g.ln_nseg + 2 * spart) * 2);
+  }
+  const int ocol = n0 + l32;
+  const bool colok = ocol < g.N;
+  const float bv = (g.bias && colok) ? g.bias[ocol] : 0.f;
+  const bool tab = MODE == 1 && g.rowtab != nullptr && !g.res;
+  float rv[RPW];
+  int orow[RPW], prow[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int e = wave * RPW + q;
+    prow[q] = (e & 3) + 8 * (e >> 2) + 4 * half;
+    orow[q] = m0 + prow[q];
+    const bool ok = colok && orow[q] < g.M;
+    rv[q] = 0.f;
+    if (g.res) { if (ok) rv[q] = g.res[bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol]; }
+    else if (tab && ok && ocol < g.rowtab_cols)
+      rv[q] = g.rowtab[(size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol];
+  }
+  if (MODE == 1) {
+    // Chan's update over the row's 32-column segments, two per lane, eight lanes per row (ln_nseg even, <= 16)
+    const bool sok = 2 * spart < g.ln_nseg;
+    const float fn = (float)g.ln_nseg;
+    const float mean = ff_sum8(sok ? sv.x + sv.z : 0.f) / fn;
+    const float m2 = ff_sum8(sok ? sv.y + sv.w : 0.f);
+    const float d0 = sv.x - mean, d1 = sv.z - mean;
+    const float dev = ff_sum8(sok ? d0 * d0 + d1 * d1 : 0.f);
+    const float var = (m2 + 32.f * dev) / (32.f * fn);
+    if (spart == 0 && lane < 8 * (32 / NW)) *reinterpret_cast<f32x2*>(lnrow + 2 * strow) = f32x2{mean, 1.0f / sqrtf(var + g.ln_eps)};
+    __syncthreads();
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int nchunks = g.K / KC;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // ---- registers -> LDS (A normalised on the way in MODE 1) ----
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 av = ra[i];
+      if (MODE == 1) {
+        const f32x2 ms = *reinterpret_cast<const f32x2*>(lnrow + 2 * srow[i]);
+        av = (av - ms.x) * ms.y;
+      }
+      *reinterpret_cast<f32x4*>(As + soff[i]) = av;
+      *reinterpret_cast<f32x4*>(Ws + soff[i]) = rw[i];
+    }
+    if (ch + 1 < nchunks) {   // the next chunk's requests leave before this chunk is consumed
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (ch + 1) * KC);
+        rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + (ch + 1) * KC);
+      }
+    }
+    __syncthreads();
+    // ---- wave w: columns [w KQ, w KQ + KQ) of the chunk; lane half h takes k = 8j + 4h .. +3 of every 8-wide group ----
+    const float* fa = As + l32 * LD + wave * KQ + half * 4;
+    const float* fb = Ws + l32 * LD + wave * KQ + half * 4;
+    f32x4 a[NG], b[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      a[j] = *reinterpret_cast<const f32x4*>(fa + j * 8);
+      b[j] = *reinterpret_cast<const f32x4*>(fb + j * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][c], b[j][c], acc, 0, 0, 0);
+    __syncthreads();   // the panels are overwritten by the next chunk / the partial tiles
+  }
+  // partial tiles -> LDS [wave][reg][lane]; wave w then finishes registers RPW*w .. RPW*w + RPW-1
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
+  __syncthreads();
+  float* Cout = g.C + bz * g.batch_stride_c;
+  float v[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int e = wave * RPW + q;
+    v[q] = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
+           (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
+    v[q] += (red[(4 * 16 + e) * 64 + lane] + red[(5 * 16 + e) * 64 + lane]) +
+            (red[(6 * 16 + e) * 64 + lane] + red[(7 * 16 + e) * 64 + lane]);
+  }
+  float* patch = red + NW * 16 * 64;
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    float o = v[q] + bv + (tab ? rv[q] : 0.f);
+    if (g.act == 1) o = fmaxf(o, 0.f);
+    if (!tab) o += rv[q];
+    if (colok && orow[q] < g.M) Cout[(size_t)orow[q] * g.ldc + ocol] = o;
+    if (MODE == 2) patch[prow[q] * 33 + l32] = o;
+  }
+  if (MODE == 2) {  // row statistics of the finished 32x32 tile: 64 threads, (row, column half) each
+    __syncthreads();
+    if (tid < 64) {
+      float x[16], sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { x[c] = patch[l32 * 33 + half * 16 + c]; sm += x[c]; }
+      sm += __shfl_xor(sm, 32, FF_WAVE);
+      const float mean = sm * (1.0f / 32.0f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { const float d = x[c] - mean; m2 += d * d; }
+      m2 += __shfl_xor(m2, 32, FF_WAVE);
+      const int r = m0 + l32;
+      if (half == 0 && r < g.M) *reinterpret_cast<f32x2*>(g.ln_out + ((size_t)r * (g.N >> 5) + (n0 >> 5)) * 2) = f32x2{mean, m2};
+    }
+  }
+}
+
+template <int KC, int MODE>
+int launch_panel(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  static AttrFlags attr_set = {};
+  constexpr int bytes = (64 * (KC + 4) + 64) * (int)sizeof(float);
+  FF_RETURN_IF(set_lds_limit(&gemm_panel_kernel<KC, MODE>, bytes, &attr_set));
+  hipLaunchKernelGGL((gemm_panel_kernel<KC, MODE>), grid, dim3(512), bytes, st, g);
+  return FF_OK;
+}
+
 #ifndef FF_SMALL_WIDE_BLOCKS
 #define FF_SMALL_WIDE_BLOCKS 256
 #endif
 int g_small_wide_blocks = FF_SMALL_WIDE_BLOCKS;  // launches with at most this many tiles split K over eight waves instead of four
 
+const int g_small_panel = getenv("FF_NO_PANEL") ? 0 : 1;   // 1: launches of at most one tile per CU take gemm_panel_kernel (0: the eight-wave gemm_small_kernel)
+
 template <int MODE>
 int launch_small_mode(const GemmArgs& g, dim3 grid, hipStream_t st) {
   const bool wide = (long)grid.x * grid.y <= g_small_wide_blocks;
+  const bool panel = wide && g_small_panel != 0;
   switch (g.K) {
     case 512:
-      if (wide) hipLaunchKernelGGL((gemm_small_kernel<64, MODE, 8>), grid, dim3(512), 0, st, g);
+      if (panel) FF_RETURN_IF((launch_panel<512, MODE>(g, grid, st)));
+      else if (wide) hipLaunchKernelGGL((gemm_small_kernel<64, MODE, 8>), grid, dim3(512), 0, st, g);
       else hipLaunchKernelGGL((gemm_small_kernel<128, MODE, 4>), grid, dim3(256), 0, st, g);
       break;
     case 1024:
-      if (wide) hipLaunchKernelGGL((gemm_small_kernel<128, MODE, 8>), grid, dim3(512), 0, st, g);
+      if (panel) FF_RETURN_IF((launch_panel<512, MODE>(g, grid, st)));
+      else if (wide) hipLaunchKernelGGL((gemm_small_kernel<128, MODE, 8>), grid, dim3(512), 0, st, g);
       else hipLaunchKernelGGL((gemm_small_kernel<256, MODE, 4>), grid, dim3(256), 0, st, g);
       break;
     case 128: hipLaunchKernelGGL((gemm_small_kernel<32, MODE, 4>), grid, dim3(256), 0, st, g); break;
     case 256:
-      if (wide) hipLaunchKernelGGL((gemm_small_kernel<32, MODE, 8>), grid, dim3(512), 0, st, g);
+      if (panel) FF_RETURN_IF((launch_panel<256, MODE>(g, grid, st)));
+      else if (wide) hipLaunchKernelGGL((gemm_small_kernel<32, MODE, 8>), grid, dim3(512), 0, st, g);
       else hipLaunchKernelGGL((gemm_small_kernel<64, MODE, 4>), grid, dim3(256), 0, st, g);
       break;
     default: ff_set_error("ff_gemm_f32: small-M kernel supports K in {128, 256, 512, 1024}"); return FF_ERR_ARG;
@@ -1325,6 +1511,7 @@ extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_t
   g_sk_two_per_cu = two_per_cu_units;
   g_sk_fix_units = 0.1 * fix_tenths;
   g_small_max_rows = small_max_rows;
+  ff_tuning_changed();
   return FF_OK;
 }
 

@@ -3,6 +3,8 @@
 // butterfly reductions through __shfl_xor (no LDS).
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "ff_common.h"
 #include "ff_device.h"
 #include "ff_chain.h"
@@ -50,6 +52,10 @@ struct Profiler {
 }  // namespace
 
 bool ff_prof_enabled() { return g_prof.enabled; }
+
+static std::atomic<unsigned long long> g_tuning_epoch{0};
+unsigned long long ff_tuning_epoch() { return g_tuning_epoch.load(); }
+void ff_tuning_changed() { g_tuning_epoch.fetch_add(1); }
 void ff_prof_open(int cat, double work, hipStream_t st) {
   ProfRec r{cat, work, g_prof.get(), g_prof.get()};
   if (r.a) (void)hipEventRecord(r.a, st);

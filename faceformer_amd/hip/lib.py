@@ -16,6 +16,7 @@ FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP, FF_D
 FF_FUSE_LAYERNORM = 32
 FF_CHAIN = 64
 FF_FLOW = 128
+FF_GRAPH = 256
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -108,6 +109,7 @@ SIGNATURES = {
     "ff_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "ff_profile_bytes": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "ff_profile_bracket_us": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    "ff_graph_stats": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
                                fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,

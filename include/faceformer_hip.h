@@ -336,6 +336,13 @@ enum ff_decode_flags {
                                 -> linear2 -> the next layer's q|k|v) run inside ONE persistent launch each, tile by tile behind
                                 row-panel dependency counters; implies the LayerNorm-folded forms at every size (needs what
                                 FF_FUSE_LAYERNORM needs) */
+  FF_GRAPH = 256,            /* step graphs: the launches of a decode step are a pure function of ff_decode's arguments (tokens travel
+                                through device memory), so on the SECOND call with byte-identical arguments (model, parameters, every
+                                pointer, the micro-batch plan) each step is captured into a hipGraph -- one graph per step: the host's
+                                stop rule keeps working between them -- and every later call replays the steps (a small dependent
+                                launch costs 4.6-5.3 us on a stream, 1.5-2.3 us as a graph node).  Up to 8 argument sets are kept per
+                                device.  Single-stream decodes only (num_streams <= 1); the decode then runs on an internal stream
+                                forked from / joined into `stream`.  Results are those of the plain launches bit for bit */
   FF_DEDUP_PAD_ANCHORS = 16  /* parallel variant: the F - num_input[w] padding-anchor sequences of a wireframe
                                 (start token num_token-1, reference model_para.py:204-205) are identical by
                                 construction; decode ONE of them and copy its tokens into all those rows of
@@ -395,6 +402,10 @@ int ff_decode(const ff_model* m, const ff_decode_params* p,
               int64_t* predict, int* steps_done, int* step_counts, float* pointer_out,
               float* trace_logits, float* trace_best, float* trace_second, int* seq_of_row,
               void* workspace, size_t workspace_bytes, ff_stream_t stream);
+
+/* FF_GRAPH bookkeeping of this process's latest ff_decode: decode steps captured into graphs by that call, and decode steps
+ * it ran by replaying a graph (0 / 0: plain launches -- first sight of the arguments, or graphs not applicable). */
+void ff_graph_stats(int* captured_steps, int* replayed_steps);
 
 #ifdef __cplusplus
 }

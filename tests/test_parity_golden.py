@@ -188,6 +188,40 @@ def test_golden_parity_with_chain_launches(hip_lib, name, chain_rows):
     _record_margin(name, "chain launches <= %d rows" % (chain_rows or 1024), stats)
 
 
+@pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak", "par_full_n40_gain4",
+                                  "seq_small_gain4", "seq_small_eos", "par_small_extramask", "par_full_B256_default"])
+def test_golden_parity_with_step_graphs(hip_lib, name):
+    """FF_GRAPH: the first decode of an argument set launches plainly, the second captures its steps into hipGraphs (and
+    runs them), later ones replay.  Every pass must meet the golden's bars, and the three passes must agree bit for bit
+    (the same kernels with the same arguments) -- including the stop step of the early-stopping goldens, which the host
+    rule decides between graphs."""
+    from faceformer_amd.hip import lib as L
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    model.decode_flags = model.decode_flags | L.FF_GRAPH
+    b = batch_to(batch, "cuda")
+    outs = [run_traced(model, case, b) for _ in range(3)]
+    steps = int(z["steps"])
+    want = [(0, 0), None, None]
+    for i, out in enumerate(outs):
+        stats = compare_with_golden(case, z, out)
+        cap, rep = out["graph_steps"]
+        print(name, "pass", i, "captured", cap, "replayed", rep, stats)
+        if i == 0:
+            assert (cap, rep) == (0, 0)
+        elif i == 1:
+            assert cap >= steps and rep == cap
+        else:
+            assert cap == 0 and rep >= steps
+    _record_margin(name, "step graphs (replay)", stats)
+    for out in outs[1:]:
+        assert torch.equal(out["predict"], outs[0]["predict"]) and out["steps"] == outs[0]["steps"]
+        for k in ("logits", "best", "second"):
+            a, r = out[k][: steps], outs[0][k][: steps]
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(r, nan=-7.0)), k
+
+
 @pytest.mark.parametrize("flow_rows", [0, 1])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_parity_with_flow_launches(hip_lib, name, flow_rows):

@@ -23,11 +23,14 @@ for cfgfile, n in CASES:
     model = SurfaceFormer(**cfg.model)
     model.load_state_dict(make_state_dict(state_dict_spec("seq2seq", L, T), "gain4", 0))
     model = model.eval().cuda()
+    if os.environ.get("FF_TOOL_GRAPHS"):   # step graphs (FF_GRAPH, opt-in)
+        from faceformer_amd.hip import lib as _L
+        model.decode_flags |= _L.FF_GRAPH
     for nb in BATCHES:
         b = make_wireframes(n, L, T, "seq2seq", seeds=list(range(3, 3 + nb)))
         b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
         best = 1e9
-        for rep in range(3):
+        for rep in range(int(os.environ.get("FF_SEQ_REPS", "5"))):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             with torch.no_grad():

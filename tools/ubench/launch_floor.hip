@@ -4,8 +4,18 @@
 #include <stdio.h>
 #include <chrono>
 
+// write: 0 nothing, 1 plain store, 2 write-through (sc1) store, 3 plain 16-byte store, 4 write-through 16-byte store,
+// 5 non-temporal store
+typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ void k_empty(float* p, int write) {
-  if (write) p[blockIdx.x * blockDim.x + threadIdx.x] = 1.0f;
+  const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (write == 1) p[i] = 1.0f;
+  else if (write == 2) __hip_atomic_store(p + i, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (write == 3) reinterpret_cast<f4*>(p)[i] = f4{1.f, 2.f, 3.f, 4.f};
+  else if (write == 4) {
+    f4 v = {1.f, 2.f, 3.f, 4.f};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<f4*>(p) + i), "v"(v) : "memory");
+  } else if (write == 5) __builtin_nontemporal_store(1.0f, p + i);
 }
 
 static double run_stream(int grid, int write, float* d, hipStream_t st, int n) {
@@ -50,7 +60,7 @@ int main() {
   hipStream_t st;
   hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
   const int n = 1000;
-  for (int write = 0; write < 2; ++write)
+  for (int write = 0; write < 6; ++write)
     for (int grid : {1, 256, 2048}) {
       printf("grid=%5d write=%d: stream %.2f us/kernel, graph %.2f us/kernel\n", grid, write,
              run_stream(grid, write, d, st, n), run_graph(grid, write, d, st, n));
