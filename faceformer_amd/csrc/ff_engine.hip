@@ -278,7 +278,11 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   // epilogue became ONE load per lane: config B 62.1-62.4 ms folded at every step vs 62.6 with the round-2 limit of 4096 rows);
   // above that the plain launches take the 128x64-tile kernel, which the fused forms do not have (config C / E micro-batches),
   // so the fused form is used up to ln_fuse_max_rows active rows (default 12288) -- both forms are parity-tested.
-  const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows : 12288;
+  // With the 3 x bf16 projections bound, the steps that take them (x3_min_rows on) launch the LayerNorms: the split kernel
+  // has no folded form, and LayerNorm + split product beats the folded f32 forms there (config B 60.1 vs 61.9 ms).
+  const bool x3_bound = prm->x3_min_rows > 0 && nd > 0 && m->dec[0].in_proj_planes != nullptr;
+  const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows
+                       : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288);
   // Flow launches (FF_FLOW): the dependent projections between two attention operators -- out-proj -> q-proj and
   // out-proj -> linear1 -> linear2 -> the next layer's q|k|v -- run inside ONE persistent launch each, tile by tile behind
   // row-panel dependency counters (ff_gemm.hip: gemm_flow_kernel).  They need the LayerNorm-folded forms, so a step that takes

@@ -369,7 +369,8 @@ typedef struct ff_decode_params {
   int chunk_max_seqs;   /* > 0: a micro-batch of several wireframes holds at most this many sequences
                            (a single wireframe is never cut by it); 0: no limit */
   int ln_fuse_max_rows; /* FF_FUSE_LAYERNORM applies to decode steps with at most this many active rows
-                           (t * sequences of the micro-batch); 0: the default (12288) */
+                           (t * sequences of the micro-batch); 0: the default (12288; x3_min_rows - 1 when the 3 x bf16
+                           projections are in use: the steps that take them launch their LayerNorms) */
   int chain_max_rows;   /* FF_CHAIN: a step of a micro-batch with at most this many active rows is one chain launch, and the
                            tail of a larger step when the micro-batch has at most this many sequences; 0: the default (1024) */
   int flow_min_rows;    /* FF_FLOW: steps (and layer tails) with at least this many rows take the flow launches; 0: 1025 */
