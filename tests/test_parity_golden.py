@@ -439,6 +439,10 @@ FRESH_CASES = {
     # must bind (null planes for linear2, no folding) and decode on the plain f32 kernels
     "ff_not_multiple_of_16": (dict(E=128, H=2, FF=100, enc=1, dec=2, L=12, seq_len=6), "gain4", [12, 7]),
     "ff_200": (dict(E=128, H=2, FF=200, enc=1, dec=2, L=12, seq_len=6), "gain4", [9, 12]),
+    # widths between the configured ones: K = 256 (the 256-wide form of the small-M panel kernel) and K = 384 / 768
+    # (no small-M form, six heads: the general kernels and the folded forms' K tails)
+    "e256_h4": (dict(E=256, H=4, FF=512, enc=1, dec=2, L=24, seq_len=7), "gain4", [24, 9, 17]),
+    "e384_h6": (dict(E=384, H=6, FF=768, enc=1, dec=2, L=16, seq_len=6), "gain4", [16, 5]),
 }
 
 
