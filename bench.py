@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--ln-fuse-max-rows", type=int, default=0, help="LayerNorm folded into the projections up to this many rows (0: 12288)")
     ap.add_argument("--plain-multi", action="store_true",
                     help="N > 1: time the plain per-rank model(batch) + all-gather (the round-2 form) instead of decode_sharded")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path (process group, decode_sharded, collectives) even with WORLD_SIZE = 1: a "
+                         "self-check of that path on a one-GPU box, not a benchmark configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -213,12 +216,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    multi = world > 1 or args.force_dist   # the distributed code path
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the decode path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -236,7 +240,7 @@ def main():
         _ops.set_gemm_tuning(*[int(v) for v in args.gemm_tuning.split(",")])
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -294,7 +298,7 @@ def main():
     # main line
     # ================================================================================================================
     cfgE = args.config == "E"
-    sharded_c = world > 1 and not cfgE and not args.plain_multi
+    sharded_c = multi and not cfgE and not args.plain_multi
     W = args.wireframes_per_gpu or (32 if cfgE else (min(128, max(1, 1024 // world)) if sharded_c else 1))
     L_lines = 1024 if cfgE else args.edges
     model, cfg, T = parallel_model("ours-perspective.yml" if cfgE else "ours.yml", L_lines)
@@ -312,7 +316,7 @@ def main():
         with torch.no_grad():
             out = model(dict(batch))
         pred = out["predict"]
-        if world > 1:
+        if multi:
             if cfgE and pred.size(1) < max(all_n):   # ragged shards: pad the anchor dimension to the global F
                 pad = torch.zeros((pred.size(0), max(all_n) - pred.size(1), pred.size(2)), dtype=pred.dtype, device=dev)
                 pred = torch.cat([pred, pad], dim=1)
@@ -323,15 +327,15 @@ def main():
         with torch.no_grad():
             return decode_sharded(model, dict(batch), dist, local_shard=True)["predict"]
 
-    step = step_sharded if (world > 1 and not args.plain_multi) else step_plain
+    step = step_sharded if (multi and not args.plain_multi) else step_plain
     dt, pred = timed(step, fence, args.warmup, args.steps)
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # decode steps actually executed (the reference semantics run T-1 with these weights)
-    local = pred[rank * W:(rank + 1) * W] if world > 1 else pred
+    local = pred[rank * W:(rank + 1) * W] if multi else pred
     steps_done = steps_executed(local)
     # decoded edges = pointer selections of the REAL anchor sequences (n_w per wireframe); the reference
     # additionally decodes F - n_w identical padding-anchor rows per wireframe, reported separately
@@ -384,7 +388,7 @@ def main():
     falg = sum(alg_flops_per_wireframe(n, T) for n in n_local)
     result["path_roofline"] = path_roofline(falg, dt / args.steps)
 
-    if world > 1 and sharded_c:
+    if multi and sharded_c:
         # the one-wireframe-per-GPU weak line (what N = 1 measures as its headline), plain model(batch) + all-gather
         one = to_dev(make_wireframes([args.edges], L_lines, T, "parallel", seeds=[rank]))
 
@@ -400,7 +404,7 @@ def main():
             "steps": 3, "warmup": 1, "workload": "ONE %d-edge wireframe per GPU (BASELINE config 2 on every GPU), local stop rule, "
                                                  "all-gather of the predictions" % args.edges}
 
-    if world == 1 and args.x3_min_rows == 0 and not args.no_x3_line:
+    if not multi and args.x3_min_rows == 0 and not args.no_x3_line:
         # second line: the package default (large decoder projections as fp32-accurate 3 x bf16 products)
         model.x3_min_rows = 4096
         dt3, _ = timed(step, fence, max(1, args.warmup), args.steps)
@@ -434,7 +438,7 @@ def main():
     # ================================================================================================================
     # N = 1: the other BASELINE configurations in the same run (a few timed passes each)
     # ================================================================================================================
-    if world == 1 and not cfgE and W == 1 and not args.no_other_configs:
+    if not multi and not cfgE and W == 1 and not args.no_other_configs:
         other = {}
         K2 = max(1, args.other_steps)
         want = set(args.other_list.split(","))
@@ -530,7 +534,7 @@ def main():
             del m1, b1
         result["other_configs"] = other
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         # The oracle runs in a child process with a hard wall-clock cap.  Threads = the host's physical cores
         # (capped at 32: torch's CPU eager path gets SLOWER beyond that for these operator sizes -- measured on
         # the MI355X host: 256 threads 1.4 edges/s, 64 threads 133, 32 threads 165-245); `cores` reports what
@@ -642,7 +646,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -76,3 +76,26 @@ def test_sharded_decode_on_two_gpus_over_rccl(hip_lib, name):
         p.join(300)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_bench_distributed_code_path_runs_with_one_rank():
+    """`bench.py --gpus N` (N > 1) takes a code path the one-GPU boxes never see: process group over RCCL,
+    `decode_sharded(local_shard=True)`, max-over-ranks timing, the one-wireframe weak line.  `--force-dist` runs exactly
+    that path with WORLD_SIZE = 1, launched the way the driver launches it; the JSON line must carry the contract's keys."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist",
+           "--wireframes-per-gpu", "2", "--steps", "1", "--warmup", "1", "--no-roofline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "weak_one_wireframe_per_gpu", "scaling_series"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert "decode_sharded(local_shard=True)" in d["config"]["workload"] and d["config"]["wireframes_per_gpu"] == 2
