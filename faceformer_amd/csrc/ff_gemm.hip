@@ -1563,8 +1563,10 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
   if (M == 0 || N == 0 || batch == 0) return FF_OK;
   FF_CHECK_ARG(M > 0 && N > 0 && K > 0 && (K & 3) == 0, "ff_gemm_f32: bad M=%d N=%d K=%d (K %% 4)", M, N, K);
   FF_CHECK_ARG(A && W && C, "ff_gemm_f32: null operand");
+#ifndef FF_EXP_NO_LD_CHECK   // (tools/gemm_latency_probe.py aliases all rows onto one: timing experiments only)
   FF_CHECK_ARG((lda & 3) == 0 && (ldw & 3) == 0 && lda >= K && ldw >= K && ldc >= N,
                "ff_gemm_f32: bad leading dimensions lda=%d ldw=%d ldc=%d", lda, ldw, ldc);
+#endif
   FF_CHECK_ARG(ff_aligned16(A) && ff_aligned16(W) && (!A2 || ff_aligned16(A2)),
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
