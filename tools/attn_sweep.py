@@ -23,7 +23,7 @@ def run(t, S, algo, iters=30, F=F):
     d.q, d.k, d.v, d.o = q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * E, out.data_ptr()
     d.ldq, d.ldk, d.ldv, d.ldo = E, 2 * E, 2 * E, E
     d.num_groups, d.num_heads, d.nq, d.nk = 1, H, F * t, S
-    d.q_group_stride, d.q_inner, d.q_outer_stride = F, F, F
+    d.q_group_stride, d.q_inner, d.q_outer_stride = F, F, F   # (one wireframe: B = F)
     d.k_group_stride, d.k_stride = S, 1
     d.scale = 0.125
     st = torch.cuda.current_stream().cuda_stream
@@ -45,6 +45,14 @@ if "--seq" in sys.argv:   # single-sequence decode (seq2seq variant): t queries;
             k = S if S else t
             print("%4d %5d | %8.1f %8.1f %8.1f %8.1f" % (t, k, run(t, k, 1, F=1), run(t, k, 2, F=1), run(t, k, 3, F=1),
                                                        run(t, k, 0, F=1)))
+    ops.set_attention_algo(0)
+    sys.exit(0)
+if "--long" in sys.argv:   # key sets of the 512 / 1024-edge wireframes (config E): F = 512 / 1024 sequences of ONE wireframe
+    print("%4s %5s %5s | %8s %8s   TF/s of the automatic choice" % ("t", "F", "S", "lds(1)", "auto(0)"))
+    for Fw, S in ((512, 516), (1024, 1028)):
+        for t in (1, 2, 4, 8, 16, 24, 37):
+            t1, t0 = run(t, S, 1, iters=10, F=Fw), run(t, S, 0, iters=10, F=Fw)
+            print("%4d %5d %5d | %8.1f %8.1f   %.1f" % (t, Fw, S, t1, t0, 4.0 * 512 * t * Fw * S / t0 / 1e6))
     ops.set_attention_algo(0)
     sys.exit(0)
 print("%4s %5s | %8s %8s %8s" % ("t", "S", "lds(1)", "wave(2)", "resid(3)"))
