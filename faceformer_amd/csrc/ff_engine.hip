@@ -666,6 +666,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_CHECK_ARG(memory && mask && kv_len && predict && workspace, "ff_decode: null pointer");
   FF_CHECK_ARG(p->variant != FF_PARALLEL || num_input, "ff_decode: num_input required for the parallel variant");
   FF_CHECK_ARG(p->variant != FF_SEQ2SEQ || p->F == 1, "ff_decode: seq2seq decodes one sequence per wireframe");
+  FF_CHECK_ARG(!p->stop_fn || (p->flags & FF_NO_STOP) || p->sync_every > 0, "ff_decode: stop_fn needs sync_every > 0");
   const int E = m->E, S = p->L + m->num_token, T = p->T, F = p->F, N = p->N;
   FF_CHECK_ARG(S <= m->pos_len, "ff_decode: S=%d exceeds the position table (%d rows)", S, m->pos_len);
   FF_CHECK_ARG(T - 1 <= m->qpos_len, "ff_decode: T-1=%d exceeds the query position table (%d rows)", T - 1, m->qpos_len);
@@ -783,6 +784,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     int pending_enq = 0;   // > 0: a counter copy covering steps [0, pending_enq) is in flight
     const bool lagged = T <= FF_PINNED_COUNTERS;
     auto eval_counts = [&](const int* cnt, int n) {
+      if (p->stop_fn) return p->stop_fn(p->stop_user, cnt, n) != 0;   // the caller's (batch-global) rule
       if (p->variant == FF_PARALLEL) {
         for (int s = 0; s < n; ++s) if (cnt[s] == 0) return true;
       } else {
@@ -916,7 +918,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   // caller's workspace as well: same rule as above -- on any failure the streams are drained before the error goes back.
   auto finish = [&]() -> int {
     hipLaunchKernelGGL(steps_kernel, dim3(1), dim3(64), 0, main_st, buf.cnt_ge, buf.cnt_eq, p->variant, N, enq,
-                       (p->flags & FF_NO_STOP) ? 1 : 0, buf.steps_dev);
+                       ((p->flags & FF_NO_STOP) || p->stop_fn) ? 1 : 0, buf.steps_dev);
     FF_CHECK_LAUNCH();
     for (const Chunk& c : chunks) {
       const long total = (long)c.nw * F * T;

@@ -90,8 +90,46 @@ def apply_global_stop(predict, counts, num_wireframes, variant):
     return predict, stop
 
 
-def _decode_local(model, sub, variant, T, F, num_input, extra_rows):
-    """No-stop decode of the wireframes in `sub` with the batch-global F -> (predict [n, F, T], counts)."""
+def stop_step(counts, num_wireframes, variant):
+    """First step (1-based) at which the reference's loop breaks given GLOBAL per-step counters, or None."""
+    if variant == _L.FF_PARALLEL:
+        for s, c in enumerate(counts):
+            if c == 0:
+                return s + 1
+        return None
+    cum = 0
+    for s, c in enumerate(counts):
+        cum += c
+        if cum == num_wireframes:
+            return s + 1
+    return None
+
+
+_CONTROL_GROUPS = {}
+
+
+def _control_group(dist_mod, group):
+    """A process group whose collectives take HOST tensors (the periodic stop check sums a few integers per rank; it must not
+    queue behind the decode steps on the device stream the way an RCCL collective would).  The group itself when its backend
+    is gloo, otherwise a gloo twin of it, created once (collectively: every rank reaches its first sharded decode)."""
+    if dist_mod.get_backend(group) == "gloo":
+        return group
+    key = (id(dist_mod), id(group))
+    if key not in _CONTROL_GROUPS:
+        ranks = None if group is None else dist_mod.get_process_group_ranks(group)
+        _CONTROL_GROUPS[key] = dist_mod.new_group(ranks=ranks, backend="gloo")
+    return _CONTROL_GROUPS[key]
+
+
+def check_points(T, sync_every):
+    """(enqueued steps, counted steps) at which ff_decode evaluates its stop rule: every sync_every steps, one period
+    behind the steps it has enqueued (ff_engine.hip).  Ranks without wireframes replay this cadence."""
+    return [(enq, enq - sync_every) for enq in range(2 * sync_every, T - 1, sync_every)] if sync_every > 0 else []
+
+
+def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callback=None, sync_every=0):
+    """Decode of the wireframes in `sub` with the batch-global F and WITHOUT the local stop rule (the batch-global one arrives
+    through `stop_callback`, or afterwards) -> (predict [n, F, T], counts of the executed steps)."""
     parallel = variant == _L.FF_PARALLEL
     n = sub["input"].size(0)
     order = list(range(n))
@@ -104,10 +142,11 @@ def _decode_local(model, sub, variant, T, F, num_input, extra_rows):
                      num_input=[num_input[i] for i in order] if parallel else None,
                      chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                      chunk_max_seqs=getattr(model, "chunk_max_seqs", 0),
-                     num_streams=model.num_streams, sync_every=0, flags=model.decode_flags,
+                     num_streams=model.num_streams, sync_every=sync_every if stop_callback else 0, flags=model.decode_flags,
                      x3_min_rows=model.x3_min_rows, ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0), chain_max_rows=getattr(model, "chain_max_rows", 0), flow_min_rows=getattr(model, "flow_min_rows", 0), extra_mask=extra_rows,
                      tok_sos=model.token.SOS if not parallel else 1,
-                     tok_eos=model.token.EOS if not parallel else 3, no_stop=True)
+                     tok_eos=model.token.EOS if not parallel else 3, no_stop=stop_callback is None,
+                     stop_callback=stop_callback)
     pred = out["predict"].view(n, F, T)
     if order != list(range(n)):
         inv = torch.empty(n, dtype=torch.long, device=pred.device)
@@ -162,8 +201,26 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
         sizes = [len(p) for p in plan]
     per = max(max(sizes), 1)
 
+    # The reference breaks its loop at the first step at which NO sequence of the batch selects an edge (parallel) / every
+    # wireframe has produced its EOS (seq2seq).  No rank can see that alone, so every sync_every steps the ranks sum the
+    # counters they have so far (host tensors on the control group: a few integers) and stop together; a rank without
+    # wireframes takes part with zeros at the same check points.
+    sync_every = int(getattr(model, "sync_every", 0)) if getattr(model, "sharded_stop_checks", True) else 0
+    checks = sync_every > 0 and world > 1 and bool(check_points(T, sync_every))
+    ctrl = _control_group(dist_mod, group) if checks else None   # (None is also a valid handle: the default group)
+
+    def global_stop(my_counts):
+        tot = torch.zeros(max(T - 1, 1), dtype=torch.int64)
+        tot[: len(my_counts)] = torch.tensor(my_counts, dtype=torch.int64)
+        dist_mod.all_reduce(tot, group=ctrl)
+        return stop_step(tot[: len(my_counts)].tolist(), N, variant) is not None
+
     local = torch.zeros((per, F, T), dtype=torch.int64, device=dev)
     counts = torch.zeros(max(T - 1, 1), dtype=torch.int64, device=dev)
+    if not mine and checks:
+        for _enq, counted in check_points(T, sync_every):
+            if global_stop([0] * counted):
+                break
     if mine:
         if local_shard:
             sub, ni, ex = inputs, num_input, extra
@@ -175,7 +232,8 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
             if extra is not None:
                 rows = extra.view(N, F if parallel else 1, -1).index_select(0, idx.to(extra.device))
                 ex = rows.reshape(-1, extra.size(-1)).contiguous()
-        pred, c = _decode_local(model, sub, variant, T, F, ni, ex)
+        pred, c = _decode_local(model, sub, variant, T, F, ni, ex, stop_callback=global_stop if checks else None,
+                                sync_every=sync_every)
         local[: len(mine)] = pred
         counts[: len(c)] = torch.tensor(c, dtype=torch.int64, device=dev)
     dist_mod.all_reduce(counts, group=group)

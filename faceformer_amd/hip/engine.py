@@ -209,7 +209,7 @@ class PathEngine:
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
                chunk_wireframes=0, chunk_seqs=0, num_streams=1, sync_every=4, flags=DEFAULT_FLAGS,
                tok_sos=1, tok_eos=3, x3_min_rows=0, chunk_max_seqs=0, ln_fuse_max_rows=0, chain_max_rows=0, flow_min_rows=0,
-               trace=False, return_pointer=False, no_stop=False):
+               trace=False, return_pointer=False, no_stop=False, stop_callback=None):
         """Greedy decode. Returns dict(predict [N*F, T] int64, steps, decoded_seqs, [pointer], [trace
         tensors indexed like predict's rows])."""
         _dev(memory, "memory")
@@ -260,6 +260,18 @@ class PathEngine:
         rows = torch.empty(B, device=dev, dtype=torch.int32)
         nbytes = self._lib.ff_decode_workspace_bytes(C.byref(self.model), C.byref(prm), ni_host)
         ws = self._workspace(nbytes)
+        cb_error, cb = [], None
+        if stop_callback is not None and not no_stop:
+            # external stop rule (sharded decodes): `stop_callback(counts)` gets this call's per-step counters of the steps a
+            # period behind the enqueued ones and returns True to end the decode; `predict` keeps every executed step
+            def _stop(_user, cnt, n):
+                try:
+                    return 1 if stop_callback([cnt[i] for i in range(n)]) else 0
+                except BaseException as e:   # never unwind through the C frames: stop, re-raise below
+                    cb_error.append(e)
+                    return 1
+            cb = _L.STOP_FN(_stop)
+            prm.stop_fn = C.cast(cb, C.c_void_p)
         steps = C.c_int(0)
         counts = (C.c_int * max(T - 1, 1))()
         with torch.cuda.device(dev):
@@ -267,6 +279,8 @@ class PathEngine:
                 C.byref(self.model), C.byref(prm), _p(memory), _p(mask_u8), _p(kv_len), _p(ni), ni_host,
                 _p(extra_mask), _p(predict), C.byref(steps), counts, _p(pointer), _p(tl), _p(tb), _p(ts),
                 _p(rows), _p(ws), ws.numel(), _stream()), "ff_decode")
+        if cb_error:
+            raise cb_error[0]
         out = {"predict": predict, "steps": steps.value, "step_counts": list(counts)[: steps.value],
                "seq_of_row": rows}
         if graphs:

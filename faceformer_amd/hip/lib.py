@@ -97,7 +97,12 @@ class DecodeParams(C.Structure):
         ("tok_sos", C.c_int), ("tok_eos", C.c_int),
         ("x3_min_rows", C.c_int), ("chunk_max_seqs", C.c_int), ("ln_fuse_max_rows", C.c_int),
         ("chain_max_rows", C.c_int), ("flow_min_rows", C.c_int),
+        ("stop_fn", C.c_void_p), ("stop_user", C.c_void_p),
     ]
+
+
+# ff_stop_fn: int (*)(void* user, const int* step_counts, int num_steps)
+STOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int)
 
 
 # name -> (restype, argtypes); must list every symbol of include/faceformer_hip.h

@@ -349,6 +349,13 @@ enum ff_decode_flags {
                                 `predict`.  Needs num_input_host; ignored when an extra mask is given */
 };
 
+/* External stop rule (multi-GPU: SURVEY.md 8e).  Called on the HOST, from inside ff_decode, every sync_every steps with this
+ * call's per-step counters of steps [0, num_steps) -- #{tokens >= num_token} (parallel) or #{tokens == EOS} (seq2seq) over the
+ * sequences THIS call decodes; num_steps runs one period behind the steps already enqueued (the GPU never drains).  A
+ * non-zero return ends the decode after the steps enqueued so far.  A sharded caller sums the counters over its ranks in
+ * here (a small host-side all-reduce) and applies the reference's rule to the batch-global numbers. */
+typedef int (*ff_stop_fn)(void* user, const int* step_counts, int num_steps);
+
 typedef struct ff_decode_params {
   int variant;          /* ff_variant */
   int N;                /* wireframes */
@@ -374,6 +381,10 @@ typedef struct ff_decode_params {
   int chain_max_rows;   /* FF_CHAIN: a step of a micro-batch with at most this many active rows is one chain launch, and the
                            tail of a larger step when the micro-batch has at most this many sequences; 0: the default (1024) */
   int flow_min_rows;    /* FF_FLOW: steps (and layer tails) with at least this many rows take the flow launches; 0: 1025 */
+  ff_stop_fn stop_fn;   /* optional: replaces the LOCAL stop rule (needs sync_every > 0; ignored with FF_NO_STOP).
+                           `predict` then keeps every step that was executed (as with FF_NO_STOP): the caller zero-pads
+                           after the step its global rule names */
+  void* stop_user;      /* first argument of stop_fn */
 } ff_decode_params;
 
 /* Greedy pointer decode (a5-a12 of SURVEY.md 8a).

@@ -28,9 +28,12 @@ class _OracleEngine:
     def __init__(self, sd, num_head, batch):
         self.sd, self.H, self.batch = sd, num_head, batch
 
-    def decode(self, memory, mask, kv_len, variant, T, F, num_input, no_stop=False, **kw):
+    def decode(self, memory, mask, kv_len, variant, T, F, num_input, no_stop=False, stop_callback=None, sync_every=0, **kw):
+        """ff_decode's contract without the local stop rule: either every step (no_stop), or the steps enqueued when the
+        caller's rule -- asked every sync_every steps, one period behind (faceformer_amd.dist.check_points) -- says stop."""
         from oracle import refpath
-        assert no_stop
+        from faceformer_amd.dist import check_points
+        assert no_stop or stop_callback is not None
         sub_in = memory          # the stand-in's "memory" is the sub-batch handed to _encode
         n = sub_in["input"].size(0)
         sub = {"input": sub_in["input"], "input_mask": sub_in["input_mask"],
@@ -38,7 +41,15 @@ class _OracleEngine:
         trace = {}
         out = refpath.parallel_forward_eval(self.sd, sub, num_head=self.H, trace=trace, stop_rule=False,
                                             num_anchors=F)
-        return {"predict": out["predict"].reshape(-1, T), "steps": T - 1, "step_counts": trace["counts"]}
+        pred, counts, executed = out["predict"].reshape(-1, T).clone(), list(trace["counts"]), T - 1
+        if stop_callback is not None:
+            for enq, counted in check_points(T, sync_every):
+                if stop_callback(counts[:counted]):
+                    executed = enq
+                    break
+            pred[:, executed + 1:] = 0
+        self.executed = executed
+        return {"predict": pred, "steps": executed, "step_counts": counts[:executed]}
 
 
 def _worker(rank, world, port, name, ret, local=False):
@@ -58,7 +69,8 @@ def _worker(rank, world, port, name, ret, local=False):
                                    num_lines=m["L"], max_face_length=m["seq_len"], token=token_ns()).eval()
     eng = _OracleEngine(sd, m["H"], batch)
     model._encode = lambda sub: (eng, sub, None, None)   # carries the rank's sub-batch to the stand-in
-    if local:
+    model.sync_every = 1 if local != "nochecks" else 0    # (T - 1 is 7..8 here: ask the global rule at every step)
+    if local is True or local == "mismatch":
         # every rank holds ONLY its own wireframes (rank 0 the first one, rank 1 the rest): F, the counters and
         # the shard sizes are agreed by collectives; the result is the concatenation in rank order
         N = batch["input"].size(0)
@@ -82,6 +94,15 @@ def _worker(rank, world, port, name, ret, local=False):
         return
     out = ffd.decode_sharded(model, dict(batch), dist)
     ok = np.array_equal(out["predict"].numpy(), z["predict"])
+    # the periodic global check ends the decode on EVERY rank at most two periods behind the reference's stop step
+    steps = int(z["steps"])
+    T = m["seq_len"]
+    if hasattr(eng, "executed") and model.sync_every > 0:
+        ok = ok and eng.executed <= min(T - 1, max(steps + 2, 2))
+        if steps + 2 < T - 1:
+            ok = ok and eng.executed < T - 1
+    elif hasattr(eng, "executed"):
+        ok = ok and eng.executed == T - 1
     # face-loop JSON of every wireframe on every rank (parsed locally, gathered as bytes)
     import json
     from faceformer_amd import faces as FZ
@@ -108,6 +129,23 @@ def test_sharded_decode_equals_single_process_gloo(name):
         p.join(180)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("name,mode", [("par_small_break1", False), ("par_small_earlybreak", False), ("par_small_break1", "nochecks")])
+def test_sharded_decode_with_an_idle_rank_gloo(name, mode):
+    """Three ranks, two wireframes: rank 2 decodes nothing and must still meet the other ranks at every periodic stop check
+    (zeros at the same check points) -- or, with the checks off, only at the final collectives."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True, 2: True}
 
 
 @pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak"])

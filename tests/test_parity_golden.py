@@ -485,6 +485,49 @@ def test_fresh_inputs_against_oracle(hip_lib, name, x3_min_rows):
     assert (pred[:, steps + 1:] == 0).all()
 
 
+@pytest.mark.parametrize("name", ["par_small_earlybreak", "par_small_break1", "par_small_ragged", "seq_small_eos", "seq_small_gain4"])
+def test_external_stop_rule_through_the_c_callback(hip_lib, name):
+    """ff_decode_params.stop_fn: the engine hands the per-step counters to the caller's rule every sync_every steps (one period
+    behind the enqueued steps) and ends the decode when it says so; `predict` keeps every executed step.  With the reference's
+    own rule in the callback the result -- after the caller's zero-padding -- must be the golden tensor, the decode must end at
+    most two periods after the reference's stop step, and an exception raised inside the callback must surface in Python."""
+    from faceformer_amd.dist import apply_global_stop, check_points, stop_step
+    from faceformer_amd.hip import lib as L
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    b = batch_to(batch, "cuda")
+    parallel = case["kind"] == "parallel"
+    variant = L.FF_PARALLEL if parallel else L.FF_SEQ2SEQ
+    T, steps, N = case["model"]["seq_len"], int(z["steps"]), len(case["n_edges"])
+    eng, memory, mask, kv_len = model._encode(b)
+    seen = []
+
+    def rule(counts):
+        seen.append(len(counts))
+        return stop_step(counts, N, variant) is not None
+    kw = dict(T=T, extra_mask=model._extra_mask(b), flags=model.decode_flags, sync_every=1, stop_callback=rule)
+    if parallel:
+        ni = [int(n) for n in b["num_input"]]
+        out = eng.decode(memory, mask, kv_len, variant, F=max(ni), num_input=ni, **kw)
+    else:
+        out = eng.decode(memory, mask, kv_len, variant, F=1, tok_sos=model.token.SOS, tok_eos=model.token.EOS, **kw)
+    assert seen == [n for _e, n in check_points(T, 1)][: len(seen)] and len(out["step_counts"]) == out["steps"]
+    assert steps <= out["steps"] <= min(T - 1, max(steps + 2, 2))
+    pred, stop = apply_global_stop(out["predict"].clone(), out["step_counts"], N, variant)
+    assert stop == steps
+    assert np.array_equal(pred.cpu().numpy().reshape(z["predict"].shape), z["predict"])
+
+    def broken(counts):
+        raise RuntimeError("rule failed")
+    with pytest.raises(RuntimeError, match="rule failed"):
+        if parallel:
+            eng.decode(memory, mask, kv_len, variant, F=max(ni), num_input=ni, **dict(kw, stop_callback=broken))
+        else:
+            eng.decode(memory, mask, kv_len, variant, F=1, tok_sos=model.token.SOS, tok_eos=model.token.EOS,
+                       **dict(kw, stop_callback=broken))
+
+
 @pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak", "par_small_break1", "seq_small_gain4"])
 def test_sharded_equals_single(hip_lib, name):
     """decode_sharded on the real engine (world_size 1 over RCCL): no-stop decode + counters +
