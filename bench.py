@@ -186,7 +186,7 @@ def main():
                          "default (4096) is measured as well and reported under 'bf16x3_projections'")
     ap.add_argument("--no-fuse-ln", action="store_true", help="standalone LayerNorm launches (A/B of FF_FUSE_LAYERNORM)")
     ap.add_argument("--no-dedup", action="store_true", help="decode every padding-anchor row like the reference does")
-    ap.add_argument("--sync-every", type=int, default=4, help="host stop-rule check period in steps (0 = never)")
+    ap.add_argument("--sync-every", type=int, default=1, help="host stop-rule check period in steps (0 = never; package default 1)")
     ap.add_argument("--cpu-anchors", type=int, default=0,
                     help="anchor sequences in the CPU baseline (0 = all: the FULL wireframe, SURVEY 8d)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU oracle (0 = physical cores, at most 32)")

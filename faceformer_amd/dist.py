@@ -207,7 +207,7 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
     # wireframe has produced its EOS (seq2seq).  No rank can see that alone, so every sync_every steps the ranks sum the
     # counters they have so far (host tensors on the control group: a few integers) and stop together; a rank without
     # wireframes takes part with zeros at the same check points.
-    sync_every = int(getattr(model, "sync_every", 0)) if getattr(model, "sharded_stop_checks", True) else 0
+    sync_every = int(getattr(model, "sharded_sync_every", getattr(model, "sync_every", 0)))   # 0: rule applied after the decode
     checks = sync_every > 0 and world > 1 and bool(check_points(T, sync_every))
     ctrl = None   # (None is also a valid handle: the default group)
     if checks:

@@ -53,7 +53,10 @@ class SurfaceFormerBase(nn.Module):
         self.ln_fuse_max_rows = 0      # LayerNorm folded into the projections on steps with at most this many rows (0: 12288)
         self.flow_min_rows = 0         # FF_FLOW: steps with at least this many rows take the flow launches (0: 1025)
         self.chain_max_rows = 0        # FF_CHAIN: steps with at most this many active rows run as ONE persistent launch (0: 1024)
-        self.sync_every = 4            # host evaluation period of the stop rule
+        self.sync_every = 1            # the host looks at the stop rule every k steps, one period behind the enqueued steps
+                                       # (the queue never drains: free at every step, tools/run_sync_probe.sh); a decode
+                                       # that stops at step s executes s + k ... s + 2k - 1 steps
+        self.sharded_sync_every = 2    # ... period of the batch-global rule in dist.decode_sharded (a host all-reduce per check)
         # Decoder projections of launches with at least this many rows (q|k|v; linear2 from 1.5x, linear1 from 2x, the
         # E x E ones from 4x as many) run as 3 x bf16 split products on the bf16 matrix cores: fp32-accurate (error
         # vs fp64 = an fp32 dot product's, tests/test_hip_ops.py) and 1.2-1.5x the f32-MFMA kernel from ~9000 rows

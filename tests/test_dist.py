@@ -69,7 +69,7 @@ def _worker(rank, world, port, name, ret, local=False):
                                    num_lines=m["L"], max_face_length=m["seq_len"], token=token_ns()).eval()
     eng = _OracleEngine(sd, m["H"], batch)
     model._encode = lambda sub: (eng, sub, None, None)   # carries the rank's sub-batch to the stand-in
-    model.sync_every = 1 if local != "nochecks" else 0    # (T - 1 is 7..8 here: ask the global rule at every step)
+    model.sharded_sync_every = 1 if local != "nochecks" else 0    # (T - 1 is 7..8 here: ask the global rule at every step)
     if local is True or local == "mismatch":
         # every rank holds ONLY its own wireframes (rank 0 the first one, rank 1 the rest): F, the counters and
         # the shard sizes are agreed by collectives; the result is the concatenation in rank order
@@ -97,7 +97,7 @@ def _worker(rank, world, port, name, ret, local=False):
     # the periodic global check ends the decode on EVERY rank at most two periods behind the reference's stop step
     steps = int(z["steps"])
     T = m["seq_len"]
-    if hasattr(eng, "executed") and model.sync_every > 0:
+    if hasattr(eng, "executed") and model.sharded_sync_every > 0:
         ok = ok and eng.executed <= min(T - 1, max(steps + 2, 2))
         if steps + 2 < T - 1:
             ok = ok and eng.executed < T - 1
