@@ -196,7 +196,8 @@ class PathEngine:
         buf = self._pinned_bufs.pop(key, None)
         if buf is None:
             buf = torch.empty_like(t, memory_format=torch.contiguous_format)
-            for old in [k for k in self._pinned_bufs if k[0] == name][: -keep + 1 or None]:
+            mine = [k for k in self._pinned_bufs if k[0] == name]        # least recently used first
+            for old in mine[: max(0, len(mine) - (keep - 1))]:           # at most `keep` shapes per operand
                 del self._pinned_bufs[old]
         self._pinned_bufs[key] = buf   # (re-inserted: the dict is in least-recently-used order)
         buf.copy_(t)
