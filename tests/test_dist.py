@@ -233,3 +233,20 @@ def test_shard_range_and_global_stop():
     assert stop == 3 and out[:, 4:].eq(0).all()
     out, stop = ffd.apply_global_stop(pred.clone(), [1, 2, 0, 0, 0], 2, L.FF_SEQ2SEQ)
     assert stop == 5 and out.equal(pred)   # the count jumped past N: the reference never stops early
+
+
+def test_check_points_and_stop_step():
+    """The cadence every rank of a sharded decode replays (ff_engine.hip: rule looked at every k steps, one period behind the
+    enqueued steps) and the reference's loop-break rule on batch-global counters."""
+    from faceformer_amd import dist as ffd
+    from faceformer_amd.hip import lib as L
+    assert ffd.check_points(10, 1) == [(e, e - 1) for e in range(2, 9)]
+    assert ffd.check_points(37, 4) == [(8, 4), (12, 8), (16, 12), (20, 16), (24, 20), (28, 24), (32, 28)]
+    assert ffd.check_points(37, 0) == [] and ffd.check_points(3, 1) == [] and ffd.check_points(9, 4) == []
+    assert ffd.stop_step([3, 1, 0, 5], 2, L.FF_PARALLEL) == 3 and ffd.stop_step([3, 1], 2, L.FF_PARALLEL) is None
+    assert ffd.stop_step([0, 1, 0, 1], 2, L.FF_SEQ2SEQ) == 4 and ffd.stop_step([1, 2, 0], 2, L.FF_SEQ2SEQ) is None
+    assert ffd.stop_step([], 2, L.FF_PARALLEL) is None
+    # apply_global_stop and stop_step agree on where the loop breaks
+    for counts, n, v in (([3, 0, 2], 2, L.FF_PARALLEL), ([1, 0, 1, 0], 2, L.FF_SEQ2SEQ), ([2, 2, 2], 3, L.FF_PARALLEL)):
+        _, stop = ffd.apply_global_stop(torch.ones(1, len(counts) + 1, dtype=torch.int64), counts, n, v)
+        assert stop == (ffd.stop_step(counts, n, v) or len(counts))
