@@ -225,6 +225,7 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node by contract: the host-side control group of decode_sharded
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from faceformer_amd.config import load_cfg
