@@ -114,7 +114,8 @@ def _control_group(dist_mod, group):
     is gloo, otherwise a gloo twin of it, created once (collectively: every rank reaches its first sharded decode)."""
     if dist_mod.get_backend(group) == "gloo":
         return group
-    key = (dist_mod, group)   # (holds the group: an id() could be reused by a later object)
+    # keyed by the group OBJECT (the default group's when `group` is None: it changes when the process group is re-initialised)
+    key = (dist_mod, group if group is not None else getattr(getattr(dist_mod, "group", None), "WORLD", None))
     if key in _CONTROL_GROUPS and _CONTROL_GROUPS[key] is None:
         raise RuntimeError("not available (failed before)")
     if key not in _CONTROL_GROUPS:
@@ -216,7 +217,7 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
         except (RuntimeError, ValueError) as e:   # no host-side backend in this build of torch.distributed: every rank
             import warnings                        # fails the same way and decodes all T - 1 steps, as before round 3
             warnings.warn("decode_sharded: no gloo control group (%s); the global stop rule is applied after the decode" % e)
-            _CONTROL_GROUPS[(dist_mod, group)] = None
+            _CONTROL_GROUPS[(dist_mod, group if group is not None else getattr(getattr(dist_mod, "group", None), "WORLD", None))] = None
             checks = False
 
     def global_stop(my_counts):

@@ -543,6 +543,13 @@ def test_sharded_equals_single(hip_lib, name):
         created = True
     try:
         out = decode_sharded(model, batch_to(batch, "cuda"), dist)
+        # the host-side twin of an RCCL group that carries the periodic stop checks of a world > 1 decode (HOST tensors)
+        from faceformer_amd.dist import _control_group
+        ctrl = _control_group(dist, None)
+        assert dist.get_backend(ctrl) == "gloo" and _control_group(dist, None) is ctrl
+        t = torch.tensor([3, 0, 5], dtype=torch.int64)
+        dist.all_reduce(t, group=ctrl)
+        assert t.tolist() == [3, 0, 5] and t.device.type == "cpu"
     finally:
         if created:
             dist.destroy_process_group()
