@@ -67,6 +67,23 @@ __device__ __forceinline__ void ff_st4i(int* p, int v) {
 }
 // data written BEFORE the launch (weights, biases, tables, masks, lengths, encoder memory): plain cached loads, global in
 // the chain form
+// The 16 accumulator rows of a lane (row0 + (e&3) + 8*(e>>2), one column) -> C.  Whole tiles -- the wave's 32 rows inside M --
+// take 16 unguarded stores in a row; only the last row tile of a launch takes the guarded form.
+template <bool COH>
+__device__ __forceinline__ void ff_store_tile(float* cp, int ldc, int row0, int col, int M, bool colok, const float (&v)[16]) {
+  float* p = cp + (size_t)row0 * ldc + col;
+  if (row0 - (row0 & 4) + 32 <= M) {   // wave-uniform (row0 differs by 4 between the lane halves): rows row0 .. row0 + 27 exist
+    if (colok) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ff_st4<COH>(p + (size_t)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (row0 + (e & 3) + 8 * (e >> 2) < M && colok) ff_st4<COH>(p + (size_t)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
+  }
+}
+
 template <bool COH>
 __device__ __forceinline__ f32x4 ff_ldw16(const float* p) {
   if (!COH) return *reinterpret_cast<const f32x4*>(p);

@@ -35,6 +35,27 @@
 #include "ff_device.h"
 #include "ff_chain.h"
 
+// Timing experiment (tools/gemm_slice_probe.py, -DFF_EXP_STAMP): the four waves of workgroup 0 of the persistent kernel stamp
+// the shader clock in front of and behind the block barrier of their first 256 slices.
+#ifdef FF_EXP_STAMP
+__device__ unsigned long long ff_exp_stamps[4][256][2];
+#define FF_EXP_STAMP_PRE()                                                                          \
+  unsigned long long _t0 = 0;                                                                       \
+  if (blockIdx.x == 0 && _slice < 256) _t0 = __builtin_readcyclecounter();
+#define FF_EXP_STAMP_POST()                                                                         \
+  if (blockIdx.x == 0 && _slice < 256) {                                                            \
+    const unsigned long long _t1 = __builtin_readcyclecounter();                                    \
+    if (lane == 0) { ff_exp_stamps[wave][_slice][0] = _t0; ff_exp_stamps[wave][_slice][1] = _t1; }  \
+  }                                                                                                 \
+  ++_slice;
+extern "C" int ff_exp_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_exp_stamps), sizeof(ff_exp_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define FF_EXP_STAMP_PRE()
+#define FF_EXP_STAMP_POST()
+#endif
+
 namespace {
 
 
@@ -708,17 +729,20 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
   auto end_tile = [&]() {
     float* cp = g.C + e_coff;
     float fin[16];
+    // All values FIRST, then the stores back to back.  (With the store inside the loop each of its 16 guarded blocks began
+    // with `s_waitcnt vmcnt(0)` -- the compiler re-establishes "bias / residual have arrived" in every block, and on gfx9 that
+    // counter also counts the store issued by the block before: sixteen serialised write round trips, ~600 cycles each,
+    // 9.8 k cycles per tile against 2.0 k per K-slice: tools/gemm_slice_probe.py.)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = e_row0 + (e & 3) + 8 * (e >> 2);
       const bool tab = MODE == 1 && g.rowtab != nullptr;   // a position table belongs INSIDE the activation
       float v = acc[e] + bv + (tab ? rv[e] : 0.f);
       if (g.act == 1) v = fmaxf(v, 0.f);
       if (!tab) v += rv[e];
-      if (row < g.M && e_colok) ff_st4<COH>(cp + (size_t)row * g.ldc + e_col, v);
       fin[e] = v;
       acc[e] = 0.f;
     }
+    ff_store_tile<COH>(cp, g.ldc, e_row0, e_col, g.M, e_colok, fin);
     if (MODE == 2)
       ff_emit_ln_stats<COH>(fin, lds + 3 * BUF_FLOATS + wave * (32 * 33), l32, half, e_row0 - 4 * half, g.M, g.ln_out,
                        g.N >> 5, (e_col - l32) >> 5);
@@ -736,6 +760,9 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
   read_frags(fa[0], fb[0], 0);
 
   int b0 = 0, b1 = 1, b2 = 2;
+#ifdef FF_EXP_STAMP
+  int _slice = 0;
+#endif
   // Outer loop over this block's tiles, inner loop over the K-slices of one tile (two per trip: static register-set
   // indices).  The software pipeline (staging registers, LDS ring, load cursor) runs across the tile boundary; only
   // the epilogue sits between two inner loops, so the hot loop body is one straight basic block.
@@ -750,7 +777,9 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
         mfma_frags(fa[u], fb[u]);
         ff_persist_hints<MODE>();
         advance(true);
+        FF_EXP_STAMP_PRE();
         __syncthreads();
+        FF_EXP_STAMP_POST();
         { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
       }
     }
@@ -1045,16 +1074,15 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
     float* cp = g.C + e_coff;
     float fin[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = e_row0 + (e & 3) + 8 * (e >> 2);
+    for (int e = 0; e < 16; ++e) {   // all values first, then the stores back to back: see gemm_persist_body
       const bool tab = MODE == 1 && g.rowtab != nullptr;   // a position table belongs INSIDE the activation
       float v = acc[e] + bv + (tab ? rv[e] : 0.f);
       if (g.act == 1) v = fmaxf(v, 0.f);
       if (!tab) v += rv[e];
-      if (row < g.M && e_colok) cp[(size_t)row * g.ldc + e_col] = v;
       fin[e] = v;
       acc[e] = 0.f;
     }
+    ff_store_tile<false>(cp, g.ldc, e_row0, e_col, g.M, e_colok, fin);
     if (MODE == 2)
       ff_emit_ln_stats(fin, lds + 3 * BUF_FLOATS + wave * (32 * 33), l32, half, e_row0 - 4 * half, g.M, g.ln_out,
                        g.N >> 5, (e_col - l32) >> 5);

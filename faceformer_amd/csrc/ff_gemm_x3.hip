@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "ff_common.h"
+#include "ff_device.h"
 
 namespace {
 
@@ -149,8 +150,12 @@ __device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2]
       __syncthreads();  // every thread is past its flag polls
       if (tid < lb - c0) __hip_atomic_store(g.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // bias, activation, residual, store; the residual of a sub-tile is read before its stores
-    // (it may alias C)
+    // bias, activation, residual, store.  Per 32-column half of the wave tile: the residual values of both 32x32 sub-tiles
+    // are requested together, every result is finished in its accumulator register, and only then the 32 stores go out back
+    // to back.  (Stores inside the per-element loop were each preceded by `s_waitcnt vmcnt(0)` -- the compiler re-establishes
+    // "the residual has arrived" in every guarded block and on gfx9 that counter also counts the store before: 64 serialised
+    // write round trips per tile, about as long as the tile's whole K = 512 MFMA chain; see gemm_persist_body.)  A lane reads
+    // and writes the same elements, so a residual that aliases C stays correct.
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       int col = e_n0 + wn0 + ni * 32 + l32;
@@ -158,29 +163,31 @@ __device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2]
       const bool colok = col < g.N;
       const int colc = colok ? col : g.N - 1;
       const float bv = g.bias ? g.bias[colc] : 0.f;
+      int rbase[2];
+      float rl[2][16];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        int rbase = e_m0 + wm0 + mi * 32 + 4 * half;
-        asm volatile("" : "+v"(rbase));
-        float rl[16];
+        rbase[mi] = e_m0 + wm0 + mi * 32 + 4 * half;
+        asm volatile("" : "+v"(rbase[mi]));
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          int row = rbase + (e & 3) + 8 * (e >> 2);
+          int row = rbase[mi] + (e & 3) + 8 * (e >> 2);
           row = row < g.M ? row : g.M - 1;
-          rl[e] = g.res ? g.res[(size_t)row * g.ldr + colc] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = rbase + (e & 3) + 8 * (e >> 2);
-          float v = acc[mi][ni][e] + bv;
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          v += rl[e];
-          if (row < g.M && colok) {
-            g.C[(size_t)row * g.ldc + col] = v;
-          }
-          acc[mi][ni][e] = 0.f;
+          rl[mi][e] = g.res ? g.res[(size_t)row * g.ldr + colc] : 0.f;
         }
       }
+      float fin[2][16];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[mi][ni][e] + bv;
+          if (g.act == 1) v = fmaxf(v, 0.f);
+          fin[mi][e] = v + rl[mi][e];
+          acc[mi][ni][e] = 0.f;
+        }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) ff_store_tile<false>(g.C, g.ldc, rbase[mi], col, g.M, colok, fin[mi]);
     }
   }
 }
