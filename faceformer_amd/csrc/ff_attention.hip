@@ -286,6 +286,29 @@ constexpr int RK_REC = 34 * 64;                  // one partial record: O[32 reg
 constexpr int RK_LDS_FLOATS = RK_KEYS * 128 + RK_KEYS;
 static_assert(2 * RK_NW * RK_REC <= RK_KEYS * 128, "records must fit the K/V area");
 
+// V operand reads of the K/V-resident kernel, issued by hand (see the P.V loop): rows r = 2 PR, 2 PR + 1 of the accumulator layout
+// ((r & 3) + 8 (r >> 2) key rows of 64 floats past `va`), columns l32 and 32 + l32 -> dst[0..3].
+template <int PR>
+__device__ __forceinline__ void rk_read_v(float (&dst)[4], unsigned va) {
+  constexpr int R0 = 2 * PR, R1 = 2 * PR + 1;
+  constexpr int O0 = ((R0 & 3) + 8 * (R0 >> 2)) * 256, O1 = ((R1 & 3) + 8 * (R1 >> 2)) * 256;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(va), "n"(O0) : "memory");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(va), "n"(O0 + 128) : "memory");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(va), "n"(O1) : "memory");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(va), "n"(O1 + 128) : "memory");
+}
+__device__ __forceinline__ void rk_read_v_dyn(float (&dst)[4], unsigned va, int pr) {   // pr is a compile-time constant after unrolling
+  switch (pr) {
+    case 1: rk_read_v<1>(dst, va); break;
+    case 2: rk_read_v<2>(dst, va); break;
+    case 3: rk_read_v<3>(dst, va); break;
+    case 4: rk_read_v<4>(dst, va); break;
+    case 5: rk_read_v<5>(dst, va); break;
+    case 6: rk_read_v<6>(dst, va); break;
+    default: rk_read_v<7>(dst, va); break;
+  }
+}
+
 struct RkState {
   float m, l;
   f32x16 o0, o1;
@@ -405,13 +428,24 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
 #pragma unroll
           for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
         }
+        // The V values of two key rows (four reads) are in flight ahead of the four MFMAs that take them.  Left to the compiler
+        // every MFMA had its own read-and-wait in front of it (the kernel sits at the register limit, loads sink to their uses):
+        // one LDS latency per MFMA.  So the reads are issued by hand, one pair of rows ahead.
+        const unsigned va = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(Vs + (kt * 32 + 4 * half) * 64 + l32);
+        float x[2][4];
+        rk_read_v<0>(x[0], va);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int keyl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float v0 = Vs[keyl * 64 + l32];
-          const float v1 = Vs[keyl * 64 + 32 + l32];
-          st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[r], st.o0, 0, 0, 0);
-          st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[r], st.o1, 0, 0, 0);
+        for (int pr = 0; pr < 8; ++pr) {   // pair pr: accumulator rows r = 2 pr, 2 pr + 1
+          if (pr + 1 < 8) {
+            rk_read_v_dyn(x[(pr + 1) & 1], va, pr + 1);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[pr & 1][0]), "+v"(x[pr & 1][1]), "+v"(x[pr & 1][2]), "+v"(x[pr & 1][3]));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[pr & 1][0]), "+v"(x[pr & 1][1]), "+v"(x[pr & 1][2]), "+v"(x[pr & 1][3]));
+          }
+          st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][0], sacc[2 * pr], st.o0, 0, 0, 0);
+          st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][1], sacc[2 * pr], st.o1, 0, 0, 0);
+          st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][2], sacc[2 * pr + 1], st.o0, 0, 0, 0);
+          st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][3], sacc[2 * pr + 1], st.o1, 0, 0, 0);
         }
       }
       if (vtail && kt1 == ntiles) {   // wave-uniform: this range ends with the query tile's last full key tile
