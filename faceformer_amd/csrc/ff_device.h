@@ -237,14 +237,17 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
               (red[(6 * 16 + e) * 64 + lane] + red[(7 * 16 + e) * 64 + lane]);
   }
   float* patch = red + NW * 16 * 64;
+  float o[RPW];
 #pragma unroll
-  for (int q = 0; q < RPW; ++q) {
-    float o = v[q] + bv + (tab ? rv[q] : 0.f);
-    if (g.act == 1) o = fmaxf(o, 0.f);
-    if (!tab) o += rv[q];
-    if (colok && orow[q] < g.M) ff_st4<COH>(Cout + (size_t)orow[q] * g.ldc + ocol, o);
-    if (MODE == 2) patch[prow[q] * 33 + l32] = o;
+  for (int q = 0; q < RPW; ++q) {   // values first, stores behind them (a store between two uses of loaded operands serialises)
+    o[q] = v[q] + bv + (tab ? rv[q] : 0.f);
+    if (g.act == 1) o[q] = fmaxf(o[q], 0.f);
+    if (!tab) o[q] += rv[q];
+    if (MODE == 2) patch[prow[q] * 33 + l32] = o[q];
   }
+#pragma unroll
+  for (int q = 0; q < RPW; ++q)
+    if (colok && orow[q] < g.M) ff_st4<COH>(Cout + (size_t)orow[q] * g.ldc + ocol, o[q]);
   if (MODE == 2) {  // row statistics of the finished 32x32 tile: 64 threads, (row, column half) each
     __syncthreads();
     if (tid < 64) {

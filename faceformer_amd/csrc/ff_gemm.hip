@@ -56,6 +56,18 @@ extern "C" int ff_exp_read_stamps(unsigned long long* out) {
 #define FF_EXP_STAMP_POST()
 #endif
 
+// Timing experiment (tools/panel_phase_probe.py, -DFF_EXP_PANEL_STAMP): workgroup 0 of gemm_panel_kernel stamps the shader
+// clock at entry, when its panels are in LDS, when the MFMA chains are done and after the stores were issued.
+#ifdef FF_EXP_PANEL_STAMP
+__device__ unsigned long long ff_exp_panel_stamps[8];
+extern "C" int ff_exp_read_panel_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_exp_panel_stamps), sizeof(ff_exp_panel_stamps)) == hipSuccess ? 0 : -1;
+}
+#define FF_EXP_PSTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ff_exp_panel_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FF_EXP_PSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 
@@ -1278,6 +1290,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
   float* const lnrow = lds + 64 * LD;     // MODE 1: [32][2] (mean, rstd)
   float* const red = lds;                 // after the MFMA chain: [8][16][64] partial tiles (+ MODE 2 patch [32][33])
   static_assert(64 * LD >= NW * 16 * 64 + 32 * 33, "the partial tiles reuse the panel area");
+  FF_EXP_PSTAMP(0);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int m0 = (blockIdx.x / g.tiles_n) * 32, n0 = (blockIdx.x % g.tiles_n) * 32;
   const long long bz = blockIdx.y;
@@ -1369,6 +1382,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
       }
     }
     __syncthreads();
+    FF_EXP_PSTAMP(1);
     // ---- wave w: columns [w KQ, w KQ + KQ) of the chunk; lane half h takes k = 8j + 4h .. +3 of every 8-wide group ----
     const float* fa = As + l32 * LD + wave * KQ + half * 4;
     const float* fb = Ws + l32 * LD + wave * KQ + half * 4;
@@ -1383,6 +1397,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][c], b[j][c], acc, 0, 0, 0);
     __syncthreads();   // the panels are overwritten by the next chunk / the partial tiles
+    FF_EXP_PSTAMP(2);
   }
   // partial tiles -> LDS [wave][reg][lane]; wave w then finishes registers RPW*w .. RPW*w + RPW-1
 #pragma unroll
@@ -1399,14 +1414,19 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
             (red[(6 * 16 + e) * 64 + lane] + red[(7 * 16 + e) * 64 + lane]);
   }
   float* patch = red + NW * 16 * 64;
+  float o[RPW];
 #pragma unroll
-  for (int q = 0; q < RPW; ++q) {
-    float o = v[q] + bv + (tab ? rv[q] : 0.f);
-    if (g.act == 1) o = fmaxf(o, 0.f);
-    if (!tab) o += rv[q];
-    if (colok && orow[q] < g.M) Cout[(size_t)orow[q] * g.ldc + ocol] = o;
-    if (MODE == 2) patch[prow[q] * 33 + l32] = o;
+  for (int q = 0; q < RPW; ++q) {   // values first, stores behind them (see gemm_persist_body)
+    o[q] = v[q] + bv + (tab ? rv[q] : 0.f);
+    if (g.act == 1) o[q] = fmaxf(o[q], 0.f);
+    if (!tab) o[q] += rv[q];
+    if (MODE == 2) patch[prow[q] * 33 + l32] = o[q];
   }
+  FF_EXP_PSTAMP(3);
+#pragma unroll
+  for (int q = 0; q < RPW; ++q)
+    if (colok && orow[q] < g.M) Cout[(size_t)orow[q] * g.ldc + ocol] = o[q];
+  FF_EXP_PSTAMP(4);
   if (MODE == 2) {  // row statistics of the finished 32x32 tile: 64 threads, (row, column half) each
     __syncthreads();
     if (tid < 64) {
