@@ -22,6 +22,18 @@
 #include "ff_device.h"
 #include "ff_chain.h"
 
+// Timing experiment (tools/attn_phase_probe.py, -DFF_EXP_ATTN_STAMP): workgroup 0, wave 0 of the K/V-resident kernel stamps the
+// shader clock at entry, when K / V are in LDS, when its items are done, after the partial records are exchanged, at the end.
+#ifdef FF_EXP_ATTN_STAMP
+__device__ unsigned long long ff_exp_attn_stamps[8 + 16];
+extern "C" int ff_exp_read_attn_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_exp_attn_stamps), sizeof(ff_exp_attn_stamps)) == hipSuccess ? 0 : -1;
+}
+#define FF_EXP_ASTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) ff_exp_attn_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FF_EXP_ASTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
   float* const Ms = lds + RK_KEYS * 128;       // additive key bias: 0 or -inf
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const float qscale = d.scale * 1.4426950408889634f;
+  FF_EXP_ASTAMP(0);
 
   const int nblk = gridDim.x;
   const int rank = (P <= nblk) ? blockIdx.x / P : 0;           // which share of the pair's query tiles
@@ -379,6 +392,7 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
     if (ia < ib) fetch_q(rank + (ia / ntiles) * c);
     if (tid < tiles_max * 32) Ms[tid] = (tid >= nk || mbyte != 0) ? -INFINITY : 0.f;
     __syncthreads();   // (waits for the LDS-DMA: it counts in vmcnt)
+    FF_EXP_ASTAMP(1);
 
     auto process = [&](int qt, int kt0, int kt1, bool fetched, RkState& st) {
       const int qi = qt * 32 + l32;
@@ -531,7 +545,12 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
         has_last = true; last_k = k; last_kt0 = kt0;
       }
     }
+    FF_EXP_ASTAMP(2);
+#ifdef FF_EXP_ATTN_STAMP
+    if (blockIdx.x == 0 && lane == 0) { ff_exp_attn_stamps[8 + wave] = __builtin_readcyclecounter(); ff_exp_attn_stamps[16 + wave] = (unsigned long long)(ib - ia); }
+#endif
     __syncthreads();                 // every wave is done with K / V: the area now carries the partial records
+    FF_EXP_ASTAMP(3);
     auto put = [&](const RkState& st, int slot) {
       float* rec = lds + (wave * 2 + slot) * RK_REC;
 #pragma unroll
@@ -573,7 +592,9 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
       cur.m = m_star;
       store_out(rank + last_k * c, cur);
     }
+    FF_EXP_ASTAMP(4);
     __syncthreads();                 // the next pair overwrites the area
+    FF_EXP_ASTAMP(5);
   }
 }
 
