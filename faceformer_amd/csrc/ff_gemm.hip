@@ -68,6 +68,18 @@ extern "C" int ff_exp_read_panel_stamps(unsigned long long* out) {
 #define FF_EXP_PSTAMP(i) do { } while (0)
 #endif
 
+// Timing experiment (tools/streamk_probe.py, -DFF_EXP_SK_STAMP): block lb == 100 of gemm_streamk_kernel stamps the shader clock at
+// entry, around its hand-over (contributed partial tile) and around its fix-up (owned tile) and at its end.
+#ifdef FF_EXP_SK_STAMP
+__device__ unsigned long long ff_exp_sk_stamps[8];
+extern "C" int ff_exp_read_sk_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_exp_sk_stamps), sizeof(ff_exp_sk_stamps)) == hipSuccess ? 0 : -1;
+}
+#define FF_EXP_SKSTAMP(i) do { if (lb == 100 && threadIdx.x == 0) ff_exp_sk_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FF_EXP_SKSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 
@@ -906,6 +918,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   const int u0 = lb * sk.base + (lb < sk.rem ? lb : sk.rem);
   const int u1 = u0 + sk.base + (lb < sk.rem ? 1 : 0);
   if (u0 >= u1) return;
+  FF_EXP_SKSTAMP(0);
   const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
   const int ja = u0 - k0 * upt;  // first unit of tile k0 in the range
   const int jb = u1 - k1 * upt;  // one past the last unit of tile k1 in the range (1..upt)
@@ -1048,6 +1061,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   // (sc1 accesses that bypass the non-coherent cache levels), ordered by vmcnt(0) + the block barrier
   // on the writer and by the data dependence on the flag on the reader.
   auto end_segment = [&]() {
+    FF_EXP_SKSTAMP(cp_kind == 1 ? 1 : (cp_kind == 2 ? 3 : 6));
     if (cp_kind == 1) {  // hand over the raw accumulators: slot[lb][4 quads][256 threads] float4
       // 16-byte write-through (sc1) stores: four fabric writes per thread instead of sixteen 4-byte ones (MI355X: a scalar
       // sc1 store is one fabric write whatever its width; inline asm: the compiler has no vector form of an agent-scope access)
@@ -1061,6 +1075,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(sk.flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      FF_EXP_SKSTAMP(2);
       return;
     }
     if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
@@ -1082,6 +1097,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       }
       __syncthreads();  // every thread is past its flag polls
       if (tid < lb - c0) __hip_atomic_store(sk.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      FF_EXP_SKSTAMP(4);
     }
     float* cp = g.C + e_coff;
     float fin[16];
@@ -1141,6 +1157,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
     end_segment();
     if (cp_p + 1 < nseg) begin_segment(cp_p + 1);
   }
+  FF_EXP_SKSTAMP(5);
 }
 
 // hipFuncSetAttribute is per device: one flag per (kernel, device)
