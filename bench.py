@@ -163,6 +163,66 @@ def path_roofline(falg, sec_per_step):
             "frac_of_f32_mfma_peak": falg / sec_per_step / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec through torch.distributed.run with N ranks on 127.0.0.1 (the
+    command line the driver uses) and return its exit status.  Refuses -- non-zero, nothing printed on stdout -- when fewer
+    than N devices are visible: a `--gpus 8` request is never answered by a smaller run."""
+    import subprocess
+    n = args.gpus
+    if n < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    if not args.dry_spawn:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d requested but %d ROCm device(s) visible on this node; refusing to run a "
+                             "smaller configuration in its place\n" % (n, have))
+            return 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_rank(args, rank, world):
+    """--dry-spawn, one rank: the rendezvous, the process group (gloo: no device) and the metadata exchange of
+    decode_sharded(local_shard=True) -- every rank contributes (F, wireframes held, padded width) -- then rank 0 prints
+    the planned shards.  Exercises everything of an N-rank launch except the GPU work."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfgE = args.config == "E"
+    W = args.wireframes_per_gpu or (32 if cfgE else (min(128, max(1, 1024 // world)) if world > 1 else 1))
+    n_local = config_e_edge_counts(world * W)[rank * W:(rank + 1) * W] if cfgE else [args.edges] * W
+    meta = torch.tensor([max(n_local), len(n_local), 1024 if cfgE else args.edges], dtype=torch.int64)
+    allmeta = torch.empty(3 * world, dtype=torch.int64)
+    dist.all_gather_into_tensor(allmeta, meta)
+    allmeta = allmeta.view(world, 3).tolist()
+    ranks_seen = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ranks_seen)
+    if rank == 0:
+        print(json.dumps({"dry_spawn": True, "n_gpus": world, "backend": dist.get_backend(), "ranks_in_group": int(ranks_seen.item()),
+                          "shard_sizes": [int(m[1]) for m in allmeta], "global_F": max(int(m[0]) for m in allmeta),
+                          "global_batch": sum(int(m[1]) for m in allmeta), "config": args.config,
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +243,7 @@ def main():
     ap.add_argument("--x3-min-rows", type=int, default=0,
                     help="3 x bf16 projections (fp32-accurate, bf16 matrix cores) on launches with at least this many rows. "
                          "The HEADLINE is measured with 0 (every product on the f32 matrix cores, dtype f32); the package "
-                         "default (4096) is measured as well and reported under 'bf16x3_projections'")
+                         "default is measured as well and reported under 'bf16x3_projections'")
     ap.add_argument("--no-fuse-ln", action="store_true", help="standalone LayerNorm launches (A/B of FF_FUSE_LAYERNORM)")
     ap.add_argument("--no-dedup", action="store_true", help="decode every padding-anchor row like the reference does")
     ap.add_argument("--sync-every", type=int, default=1, help="host stop-rule check period in steps (0 = never; package default 1)")
@@ -209,13 +269,26 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (process group, decode_sharded, collectives) even with WORLD_SIZE = 1: a "
                          "self-check of that path on a one-GPU box, not a benchmark configuration")
+    ap.add_argument("--dry-spawn", action="store_true",
+                    help="launch plumbing only, no GPU: spawn --gpus ranks the way a real run does, build a gloo group, agree the "
+                         "shard sizes with the collectives decode_sharded(local_shard=True) uses and print them as one JSON line")
+    ap.add_argument("--no-json-gather", action="store_true", help="N > 1: skip the timed face-loop JSON gather (second figure)")
     args = ap.parse_args()
 
+    # ---- launch contract: `--gpus N` is what runs, or nothing does ---------------------------------------------------
+    # Launched by torch.distributed.run (WORLD_SIZE set): WORLD_SIZE must equal --gpus.  Launched bare with --gpus N > 1:
+    # this process spawns the N ranks itself through torch.distributed.run (after checking that N devices are visible) and
+    # exits with their status -- it never falls through to a one-GPU run that would print `n_gpus: 1` for `--gpus 8`.
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_spawn):
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or run `python bench.py "
+                         "--gpus %d` bare and let it spawn its ranks)" % (args.gpus, world, args.gpus, args.gpus))
+    if args.dry_spawn:
+        return dry_rank(args, rank, world)
     multi = world > 1 or args.force_dist   # the distributed code path
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the decode path has no CPU fallback)")
@@ -233,6 +306,7 @@ def main():
     from faceformer_amd.hip import lib as L
     from faceformer_amd.hip import ops as _ops
     from faceformer_amd.models import SurfaceFormer, SurfaceFormer_Parallel
+    from faceformer_amd.models.common import X3_MIN_ROWS_DEFAULT
     from faceformer_amd.synth import make_extra_mask, make_state_dict, make_wireframes, state_dict_spec
 
     lib = L.load()
@@ -372,6 +446,14 @@ def main():
         "wireframes_per_s": world * W * args.steps / dt,
         "ms_per_wireframe_per_gpu": 1e3 * dt / args.steps / W,
     }
+    if multi:
+        try:
+            rv = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001 - the version string is informational
+            rv = None
+        result["rccl_ranks"] = dist.get_world_size()          # what the collective library saw, not what --gpus asked for
+        result["collective_backend"] = "%s (RCCL on ROCm)" % dist.get_backend()
+        result["rccl_version"] = rv
     if sharded_c:
         result["scaling_series"] = {
             "per_gpu_workload": "%d wireframes of %d edges (config 3's per-GPU share)" % (W, args.edges),
@@ -405,18 +487,40 @@ def main():
             "steps": 3, "warmup": 1, "workload": "ONE %d-edge wireframe per GPU (BASELINE config 2 on every GPU), local stop rule, "
                                                  "all-gather of the predictions" % args.edges}
 
+    if multi and sharded_c and not args.no_json_gather:
+        # second figure of the north-star: the predicted face loops as JSON on every rank -- decode + face parsing of the
+        # rank's own wireframes (host, reference trainer.py:118-136,181-208) + the length-prefixed RCCL all-gather of the bytes
+        from faceformer_amd.dist import decode_to_face_json
+        nrec = [0, 0]
+
+        def step_json():
+            with torch.no_grad():
+                recs = decode_to_face_json(model, dict(batch), dist, local_shard=True)
+            nrec[0], nrec[1] = len(recs), sum(len(r) for r in recs)
+            return recs
+        dtj, _ = timed(step_json, fence, 1, 2)
+        tt = torch.tensor([dtj], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dtj = float(tt.item())
+        result["face_json_gather"] = {
+            "value": sel_per_step * 2 / dtj, "unit": "edges/s", "ms_per_step": 1e3 * dtj / 2, "steps": 2, "warmup": 1,
+            "records": nrec[0], "json_bytes": nrec[1],
+            "workload": "the same sharded decode, then face parsing of the rank's own wireframes on the host and the all-gather of "
+                        "the per-wireframe JSON records (u32 length prefix + utf-8, one padded uint8 all_gather_into_tensor over RCCL)"}
+
     if not multi and args.x3_min_rows == 0 and not args.no_x3_line:
         # second line: the package default (large decoder projections as fp32-accurate 3 x bf16 products)
-        model.x3_min_rows = 4096
+        model.x3_min_rows = X3_MIN_ROWS_DEFAULT
         dt3, _ = timed(step, fence, max(1, args.warmup), args.steps)
         model.x3_min_rows = 0
         step()      # (re-binds the engine without the bf16 planes for the profiling leg below)
         fence()
         result["bf16x3_projections"] = {
             "value": sel_per_step * args.steps / dt3, "unit": "edges/s", "ms_per_step": 1e3 * dt3 / args.steps,
-            "x3_min_rows": 4096,
-            "note": "package default: decoder projections of launches with >= 4096 rows (q|k|v; linear2 / linear1 / ExE from "
-                    "1.5x / 2x / 4x that) as 3 x bf16 split products on the bf16 matrix cores, fp32-accurate; NOT the headline"}
+            "x3_min_rows": X3_MIN_ROWS_DEFAULT,
+            "note": "package default: decoder projections of launches with >= %d rows (q|k|v; linear1 from 7/4 x, the 512-column "
+                    "ones from 11/4 x that) as 3 x bf16 split products on the bf16 matrix cores with the LayerNorms folded in "
+                    "(ff_gemm_x3_ln), fp32-accurate; NOT the headline" % X3_MIN_ROWS_DEFAULT}
 
     if rank == 0 and not args.no_roofline:
         def once():
@@ -459,11 +563,11 @@ def main():
                 ent["roofline"] = roof
                 ent.update(ex)
             if not args.no_x3_line:
-                m2.x3_min_rows = 4096
+                m2.x3_min_rows = X3_MIN_ROWS_DEFAULT
                 d3, _ = timed(st, fence, 1, K2)
                 m2.x3_min_rows = 0
                 ent["bf16x3_projections"] = {"value": sum(n2) * sd2 * K2 / d3, "unit": "edges/s", "ms_per_step": 1e3 * d3 / K2,
-                                             "note": "package default (x3_min_rows = 4096), fp32-accurate; not the headline form"}
+                                             "note": "package default (x3_min_rows = %d), fp32-accurate; not the headline form" % X3_MIN_ROWS_DEFAULT}
             other[name] = ent
 
         # C128: config 3's per-GPU share on this GPU (the model of the main line, a batch of 128 wireframes)

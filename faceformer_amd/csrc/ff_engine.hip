@@ -121,15 +121,22 @@ int gemm(const float* A, int lda, const float* A2, int n_split, const float* W, 
   return ff_gemm_f32(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, 0, st);
 }
 
+// Rows from which the 3 x bf16 kernel beats the f32 family, by output width (profiles/r04/gemm_x3_variants.txt, one MI355X:
+// N = 1536: 92 vs 65 TF/s at 1024 rows; N = 1024: 122 vs 94 at 2048 (69 vs 80 at 1024); the N = 512 projections, K = 512 or
+// 1024: 96 vs 72 / 119 vs 89 at 3072 (67 vs 79 / 84 vs 93 at 2048)): x3_min_rows is the threshold of the widest product, the
+// others need 7/4 and 11/4 times as many rows.
+inline bool x3_wins(const ff_decode_params* prm, int M, int N, int K) {
+  if (prm->x3_min_rows <= 0 || (K % 32) != 0 || K < 64 || (N & 3) != 0) return false;
+  const long need = (long)prm->x3_min_rows * (N >= 1536 ? 4 : (N >= 1024 ? 7 : 11)) / 4;
+  return M >= need;
+}
+
 // The same product through the 3 x bf16 kernel when the weight's planes are bound and the launch is in the
-// range where it wins (measured on MI355X: N or K >= 1024 from ~4096 rows on; tools/bench_gemm.py).
+// range where it wins.
 int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, int lda, const float* A2, int n_split,
                const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M,
                int N, int K, int act, hipStream_t st) {
-  // x3_min_rows is the threshold of the widest product (N >= 1536: 112 vs 104 TF/s at 4096 rows); the K = 1024
-  // product needs 1.5x, the N = 1024 one 2x and the N = K = 512 ones 4x as many rows before the larger tiles pay
-  const long need = (long)prm->x3_min_rows * (N >= 1536 ? 2 : (K >= 1024 ? 3 : (N >= 1024 ? 4 : 8))) / 2;
-  if (planes && prm->x3_min_rows > 0 && M >= need && (K % 32) == 0 && K >= 64 && (!A2 || (n_split % 128) == 0) &&
+  if (planes && x3_wins(prm, M, N, K) && (!A2 || (n_split % 128) == 0) &&
       !ff_chain_recording())   // (a chain launch runs every projection on the small-M f32 kernel)
     return ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
   return gemm(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, st);
@@ -280,9 +287,13 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   // so the fused form is used up to ln_fuse_max_rows active rows (default 12288) -- both forms are parity-tested.
   // With the 3 x bf16 projections bound, the steps that take them (x3_min_rows on) launch the LayerNorms: the split kernel
   // has no folded form, and LayerNorm + split product beats the folded f32 forms there (config B 60.1 vs 61.9 ms).
+  // Round 4: the 3 x bf16 kernel has the folded forms as well (ff_gemm_x3_ln).  With the planes of the folded weights bound the
+  // steps fold at EVERY size (the large launches then take the split kernel, which has no 128x64-tile problem).
   const bool x3_bound = prm->x3_min_rows > 0 && nd > 0 && m->dec[0].in_proj_planes != nullptr;
+  const bool x3_folds = x3_bound && m->dec[0].ln1_planes != nullptr && m->dec[0].ln2_planes != nullptr &&
+                        m->dec[0].ln3_planes != nullptr && E == 512;
   const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows
-                       : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288);
+                       : (x3_folds ? (1 << 30) : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288));
   // Flow launches (FF_FLOW): the dependent projections between two attention operators -- out-proj -> q-proj and
   // out-proj -> linear1 -> linear2 -> the next layer's q|k|v -- run inside ONE persistent launch each, tile by tile behind
   // row-panel dependency counters (ff_gemm.hip: gemm_flow_kernel).  They need the LayerNorm-folded forms, so a step that takes
@@ -297,9 +308,10 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   const float* qpos_new = qpos + (size_t)(t - 1) * E;
 
   // C = act(LN?(A) W^T + bias [+ table]) [+ residual], optionally leaving the row statistics of C
+  // `planes` (optional): the bf16 planes of the [plane_rows, K] weight whose rows [row0, row0 + N) are W
   auto gemm_ln = [&](const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                      float* C, int ldc, int M, int N, int K, int act, const float* st_in, const float* table, int ldt,
-                     int tcols, float* st_out) -> int {
+                     int tcols, float* st_out, const void* planes = nullptr, int plane_rows = 0, int row0 = 0) -> int {
     ff_gemm_ln_desc d;
     memset(&d, 0, sizeof(d));
     d.A = A; d.lda = lda; d.W = W; d.ldw = ldw; d.bias = bias; d.residual = res; d.ldr = ldr; d.C = C; d.ldc = ldc;
@@ -307,6 +319,9 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     d.ln_stats_in = st_in; d.ln_nseg = K / 32; d.ln_eps = m->ln_eps;
     d.row_table = table; d.ld_row_table = ldt; d.row_div = Bc; d.row_cols = tcols;
     d.ln_stats_out = st_out;
+    if (planes && x3_wins(prm, M, N, K) && (!st_in || K == 512) && (!table || (tcols & 3) == 0) && !ff_chain_recording() &&
+        !ff_flow_recording())
+      return ff_gemm_x3_ln(&d, planes, plane_rows, row0, st);
     return ff_gemm_f32_ln(&d, st);
   };
 
@@ -316,9 +331,9 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     const ff_layer_weights& w2 = m->dec[l2];
     if (prune_last && l2 == nd - 1 && t > 1)
       return gemm_ln(buf.x, E, w2.ln1_w + (size_t)E * E, E, w2.ln1_b + E, nullptr, 0, buf.qkv + E, 3 * E, R, 2 * E, E, 0,
-                     buf.lnstat, w2.ln1_pos + E, 2 * E, E, nullptr);
+                     buf.lnstat, w2.ln1_pos + E, 2 * E, E, nullptr, w2.ln1_planes, 3 * E, E);
     return gemm_ln(buf.x, E, w2.ln1_w, E, w2.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat, w2.ln1_pos, 2 * E,
-                   2 * E, nullptr);
+                   2 * E, nullptr, w2.ln1_planes, 3 * E, 0);
   };
   // runs `ops` (a few dependent projections) as ONE flow launch when possible, operator by operator otherwise
   auto flow_or_launch = [&](bool want_flow, auto&& ops) -> int {
@@ -399,10 +414,10 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     if (fuse) {
       FF_RETURN_IF(flow_or_launch(flow_here, [&]() -> int {
         FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
-                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
+                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.self_out_planes, E, 0));
         // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
         return gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
-                       w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr);
+                       w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr, w.ln2_planes, E, 0);
       }));
     } else {
       FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
@@ -439,12 +454,12 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       const bool with_next = flow_here && !last && l + 1 < nd;
       FF_RETURN_IF(flow_or_launch(flow_here, [&]() -> int {
         FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.cross_attn.out_w, E, w.cross_attn.out_b, buf.x + roff * E, E,
-                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat));
+                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.cross_out_planes, E, 0));
         // ---- feed forward (transformer.py:253-255) ----
         FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln3_w, E, w.ln3_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl, FFd, E, 1,
-                             stat, nullptr, 0, 0, nullptr));
+                             stat, nullptr, 0, 0, nullptr, w.ln3_planes, FFd, 0));
         FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
-                             Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat));
+                             Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat, w.lin2_planes, E, 0));
         return with_next ? first_proj(l + 1) : FF_OK;
       }));
       first_done = with_next;

@@ -1,34 +1,41 @@
 // fp32-accurate dense projection on the bf16 matrix cores ("3 x bf16"):
-//     C = act(Asel * W^T + bias) + residual,   A fp32 [M,K], W fp32 [N,K] given as three bf16 planes.
+//     C = act(LN?(A) * W^T + bias [+ table]) + residual,   A fp32 [M,K], W fp32 [N,K] given as three bf16 planes.
 //
 // Every fp32 value is split EXACTLY into three bf16 terms, x = x1 + x2 + x3 (round-to-nearest each
 // time, |x - x1 - x2 - x3| <= 2^-25 |x|), and a product is evaluated as the six partial products whose
 // weight is >= 2^-16:  x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1); what is dropped is <= 2^-24 |xy|,
 // the size of one fp32 rounding.  bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16
 // accumulates in fp32, so the result carries the error of an ordinary fp32 dot product (measured against
-// fp64: tools/ubench/gemm_bf16x3.hip, tests/test_hip_ops.py::test_gemm_x3_*) while the matrix pipe runs
-// at 2.5 PF/s / 6 = 417 TF/s fp32-equivalent instead of the 157 TF/s of v_mfma_f32_32x32x2_f32.
+// fp64: tests/test_hip_ops.py::test_gemm_x3_*) while the matrix pipe runs at 2.5 PF/s / 6 = 417 TF/s
+// fp32-equivalent instead of the 157 TF/s of v_mfma_f32_32x32x2_f32.
 //
-// Plane layout: [plane][k / 16][row][k % 16].  A K-slice of 16 is then 32 contiguous bytes per row AND
-// contiguous over rows: a staging instruction that covers 32 rows reads one aligned 1 KB block (eight full
-// 128-byte lines).  With row-major [row][K] planes the same instruction touched 32 lines for 32 bytes each
-// and the kernel ran at the L2 -> CU line bandwidth (4x the bytes it needed; measured 121 -> 192 TF/s
-// with the loads removed).
+// Plane layout of W: [plane][k / 16][row][k % 16]: a 16-wide K slice of 32 rows is one contiguous 1 KB block.
+// Weights are split once (ff_split_weight_bf16x3, at model bind time).
 //
-// Weights are split once (ff_split_weight_bf16x3, at model bind time); activations are split on the
-// fly while they are staged into LDS (44 VALU ops per thread and 16-wide K slice, hidden under the 24
-// MFMAs of the slice).
-//
-// Kernel: the stream-K flat (tile, slice) pipeline of ff_gemm.hip's gemm_streamk_kernel with
-//   * 128x128 block tiles, 4 waves x (64x64) = four 32x32 accumulators per wave, K slices of 16;
-//   * LDS: [3-slot ring][3 planes][256 rows][32 B], 16-byte chunk c of row r stored at c ^ ((r >> 4) & 1)
-//     (ds_read_b128 serves lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} together over 64 banks: rows 8 apart
-//     share a bank octet and must use different halves; no padding needed): 72 KB -> two blocks per CU;
-//   * per slice and wave: 12 ds_read_b128 (this slice's fragments; the co-resident block covers their
-//     latency -- a second fragment set does not fit in 256 VGPRs), 6 ds_write_b64 + 3 ds_write_b128
-//     (slice +2), 5 global loads (slice +4), 24 MFMAs, one barrier;
-//   * equal ranges of 32-wide K units per block, partial tiles (64 KB) handed over through sc1 accesses
-//     and summed by the owning block in ascending block order (deterministic).
+// Kernel (round 4; tools/ubench/x3v2.hip is the probe it grew from):
+//   * BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write, three slices in
+//     flight): the weight planes as they are, the activations as fp32 rows.  A wave reads ITS OWN 32 rows back and splits
+//     them into the three bf16 terms in registers (44 VALU per 16-wide slice, dealt out over the MFMA gaps); the two
+//     waves that share 32 rows both split them: VALU work is not what limits this loop (see below).  Bank swizzles are
+//     applied to the SOURCE address of the DMA (the LDS image of a piece is lane-linear).
+//   * Transposed accumulators: D[n][m] = W fragment x A fragment, i.e. a lane owns ONE output row and groups of four
+//     consecutive columns: the epilogue moves 16-byte pieces (16 stores per lane and 128 x 128 tile instead of 64), a
+//     row's LayerNorm statistics are two lanes apart, and the LayerNorm of the consumer is two registers per lane.
+//   * Fragments of slice s + 1 are read (one ds_read_b128 per MFMA gap) while the MFMAs of slice s issue; the second
+//     fragment set fits because nothing is staged through registers.
+//   * 64 x 128 block tiles: 2 x 2 waves of 32 x 64, 48 KB of LDS and at most 168 registers, i.e. three blocks per CU (two
+//     with the LayerNorm-consuming form), and twice the tiles of a 128 x 128 tiling for the N = 512 projections of a
+//     256-sequence decode step.  (The template also describes a 128-row tile, 4 x 1 waves of 32 x 128; it is not
+//     instantiated: see x3_launch.)
+//   * LayerNorm folding like the f32 family (ff_gemm_x3_ln): MODE 1 normalises the rows it splits ((x - mean) * rstd with
+//     the row statistics merged from the producer's segment statistics, which arrive in an LDS patch by DMA one tile
+//     ahead), MODE 2 leaves (mean, M2) per row and 32-column segment of what it stores.
+//   * Launch shapes as before: whole tiles, or equal ranges of 32-wide K units per block with the cut tiles' partial
+//     accumulators handed over through sc1 accesses and summed by the owning block in ascending block order
+//     (deterministic); chosen per problem by a cost model.
+// Measured (profiles/r04): the loop runs into the chip's POWER limit, not its issue limit -- 245-272 TF/s fp32-equivalent
+// on zero-filled operands, 170-200 on random ones (same binary); pre-split activation planes are worth 0-8 % and were
+// dropped again.
 #include <mutex>
 #include <vector>
 
@@ -38,7 +45,6 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct X3Args {
@@ -53,10 +59,18 @@ struct X3Args {
   int n_split, act;
   int tiles_m, tiles_n;
   long long plane_stride;  // elements between two planes of Wp
-  float* ws;               // [grid][64 accumulator registers][256 threads]
+  int w_rows, w_row0;      // the planes describe a [w_rows, K] weight; the product uses rows [w_row0, w_row0 + N)
+  int bal;                 // whole tiles: the blocks that get one tile more are dealt out over the XCDs and CUs
+  float* ws;               // [grid][BM * 128] partial accumulators in register order
   unsigned int* flags;     // [grid]: 1 = slot holds a partial tile
   int upt;                 // units (32 k) per tile
-  int base, rem;           // block lb owns base + (lb < rem) units
+  int base, rem, gran;     // block lb owns (base + (lb < rem)) allotments of `gran` units
+  // LayerNorm folding (MODE 1 / 2), as GemmArgs of the f32 family
+  const float* ln_in;      // MODE 1: [M][16][2] (mean, M2 over 32 columns) of the A rows (K = 512)
+  float ln_eps;
+  const float* rowtab;     // MODE 1: C[m][n] += rowtab[(m / rowtab_div) * ld_rowtab + n] for n < rowtab_cols
+  int ld_rowtab, rowtab_div, rowtab_cols;
+  float* ln_out;           // MODE 2: [M][N/32][2] segment statistics of the stored C rows
 };
 
 // x (two floats) -> packed bf16 pairs of the three terms
@@ -91,124 +105,86 @@ __global__ void split_weight_kernel(const float* __restrict__ W, int ldw, int N,
   }
 }
 
-// Measured and dropped: one block of eight waves per CU on a 128x256 tile with a four-slot ring (three
-// slices of DMA lead, 25 % fewer operand bytes per MFMA): 132 / 125 / 124 TF/s where the four-wave kernel
-// below reaches 164 / 154 / 146 -- the eight-wave barrier domain costs more than the extra lead buys.
-//
-// End of a segment of the flat (tile, slice) sequence: hand the partial tile over (kind 1), or finish the
-// tile -- after adding the partials of the lower-numbered blocks (kind 2) -- with bias / activation /
-// residual and the store.
-__device__ __forceinline__ void x3_end_segment(const X3Args& g, f32x16 (&acc)[2][2], int cp_kind, int lb, int k0,
-                                               int e_m0, int e_n0) {
-  constexpr int BM = 128, BN = 128;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int upt = g.upt;
-  {
-    if (cp_kind == 1) {  // hand over the raw accumulators: slot[lb][64][tid]
-      // slot[lb][16 quads][256 threads] float4, written / read with 16-byte sc1 accesses (inline asm: the
-      // compiler has no vector form of an agent-coherent access; the loads are fenced by the explicit wait)
-      f32x4* wp = reinterpret_cast<f32x4*>(g.ws + (size_t)lb * (BM * BN)) + tid;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + ((mi * 2 + ni) * 4 + q) * 256), "v"(v) : "memory");
-            acc[mi][ni][4 * q] = 0.f; acc[mi][ni][4 * q + 1] = 0.f; acc[mi][ni][4 * q + 2] = 0.f; acc[mi][ni][4 * q + 3] = 0.f;
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(g.flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
-      const int ub = k0 * upt;
-      const int big = g.rem * (g.base + 1);
-      const int c0 = ub < big ? ub / (g.base + 1) : g.rem + (ub - big) / g.base;
-      for (int c = c0; c < lb; ++c) {
-        while (__hip_atomic_load(g.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
-          __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        const f32x4* rp = reinterpret_cast<const f32x4*>(g.ws + (size_t)c * (BM * BN)) + tid;
-        f32x4 t[16];  // all 16 loads in flight before the first use: one memory round trip per contributor
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[q]) : "v"(rp + q * 256) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
-                       "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] += t[(mi * 2 + ni) * 4 + (e >> 2)][e & 3];
-      }
-      __syncthreads();  // every thread is past its flag polls
-      if (tid < lb - c0) __hip_atomic_store(g.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // bias, activation, residual, store.  Per 32-column half of the wave tile: the residual values of both 32x32 sub-tiles
-    // are requested together, every result is finished in its accumulator register, and only then the 32 stores go out back
-    // to back.  (Stores inside the per-element loop were each preceded by `s_waitcnt vmcnt(0)` -- the compiler re-establishes
-    // "the residual has arrived" in every guarded block and on gfx9 that counter also counts the store before: 64 serialised
-    // write round trips per tile, about as long as the tile's whole K = 512 MFMA chain; see gemm_persist_body.)  A lane reads
-    // and writes the same elements, so a residual that aliases C stays correct.
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      int col = e_n0 + wn0 + ni * 32 + l32;
-      asm volatile("" : "+v"(col));  // opaque: the address arithmetic below must not be hoisted out of the K loop
-      const bool colok = col < g.N;
-      const int colc = colok ? col : g.N - 1;
-      const float bv = g.bias ? g.bias[colc] : 0.f;
-      int rbase[2];
-      float rl[2][16];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        rbase[mi] = e_m0 + wm0 + mi * 32 + 4 * half;
-        asm volatile("" : "+v"(rbase[mi]));
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          int row = rbase[mi] + (e & 3) + 8 * (e >> 2);
-          row = row < g.M ? row : g.M - 1;
-          rl[mi][e] = g.res ? g.res[(size_t)row * g.ldr + colc] : 0.f;
-        }
-      }
-      float fin[2][16];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[mi][ni][e] + bv;
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          fin[mi][e] = v + rl[mi][e];
-          acc[mi][ni][e] = 0.f;
-        }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) ff_store_tile<false>(g.C, g.ldc, rbase[mi], col, g.M, colok, fin[mi]);
-    }
+#define X3_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// A ds_read_b128 the compiler does not see: it would put s_waitcnt vmcnt(0) in front of every LDS access that may alias
+// the destination of an LDS-DMA in flight.  Results are fenced by the explicit lgkmcnt waits of the loop.
+template <int OFF = 0>
+__device__ __forceinline__ u32x4 x3_lds_read16(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// W fragment R = plane * NI + ni of the slot whose (wave's) W fragments start at `addr`
+template <int NI, int R>
+__device__ __forceinline__ void x3_read_w(u32x4 (&wf)[3][NI], unsigned addr) {
+  wf[R / NI][R % NI] = x3_lds_read16<(R / NI) * 4096 + (R % NI) * 1024>(addr);
+}
+template <int NI>
+__device__ __forceinline__ void x3_read_w_i(u32x4 (&wf)[3][NI], unsigned addr, int r) {   // r: a constant after unrolling
+  switch (r) {
+    case 0: x3_read_w<NI, 0>(wf, addr); break; case 1: x3_read_w<NI, 1>(wf, addr); break;
+    case 2: x3_read_w<NI, 2>(wf, addr); break; case 3: x3_read_w<NI, 3>(wf, addr); break;
+    case 4: x3_read_w<NI, 4>(wf, addr); break; case 5: x3_read_w<NI, 5>(wf, addr); break;
+    case 6: if (NI == 4) x3_read_w<NI, (NI == 4 ? 6 : 0)>(wf, addr); break;
+    case 7: if (NI == 4) x3_read_w<NI, (NI == 4 ? 7 : 0)>(wf, addr); break;
+    case 8: if (NI == 4) x3_read_w<NI, (NI == 4 ? 8 : 0)>(wf, addr); break;
+    case 9: if (NI == 4) x3_read_w<NI, (NI == 4 ? 9 : 0)>(wf, addr); break;
+    case 10: if (NI == 4) x3_read_w<NI, (NI == 4 ? 10 : 0)>(wf, addr); break;
+    default: if (NI == 4) x3_read_w<NI, (NI == 4 ? 11 : 0)>(wf, addr); break;
   }
 }
+// plain (unpacked) VALU: the SLP pass would pair these into v_pk_add_f32 / v_pk_mul_f32, which issue slower beside MFMAs
+__device__ __forceinline__ float x3_fsub(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float x3_fmul(float a, float b) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
-  constexpr int BM = 128, BN = 128, BK = 16;
-  constexpr int PLANE_B = (BM + BN) * 32, BUF_B = 3 * PLANE_B;
+constexpr int X3_BN = 128, X3_BK = 16;
+constexpr int X3_STAT_BYTES = 16384;   // MODE 1: one 4 KB patch per wave (32 rows x 16 segments x (mean, M2))
+
+// BM: 128 (4 x 1 waves) or 64 (2 x 2 waves).  MODE: 0 plain, 1 LayerNorm consumer, 2 statistics producer.
+template <int BM, int MODE>
+__global__ __launch_bounds__(256, MODE == 1 ? 2 : 3) void gemm_x3_kernel(X3Args g) {
+  constexpr int BN = X3_BN, BK = X3_BK;
+  constexpr int WN = 128 / BM;              // waves along N: 1 or 2
+  constexpr int NI = BN / WN / 32;          // 32-column accumulators per wave: 4 or 2
+  constexpr int NPA = BM / 64;              // A pieces (16 rows x 64 B) per wave and slice
+  constexpr int NP = NPA + 3;               // DMA pieces per wave and slice
+  constexpr int A_REG = BM * 64, SLOT = A_REG + 3 * BN * 32;
+  constexpr int NMF = 6 * NI;               // MFMAs per wave and slice
+  constexpr int NRD = 2 + 3 * NI;           // fragment reads per wave and slice
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
   const int nsl = g.K / BK;
   const int tiles_mn = g.tiles_m * g.tiles_n;
 
-  // ---- this block's unit range and its segments (see gemm_streamk_kernel) ----
+  // ---- this block's unit range and its segments of the flat (tile, slice) sequence ----
+  // contributed beginning part of the LAST tile first (kind 1: hand the raw accumulators over), then whole tiles (kind 0),
+  // then the owned end part of the FIRST tile (kind 2: add the partials of the lower-numbered blocks, finish the tile)
   const int G = gridDim.x;
   const int lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int upt = g.upt;
-  const int u0 = lb * g.base + (lb < g.rem ? lb : g.rem);
-  const int u1 = u0 + g.base + (lb < g.rem ? 1 : 0);
+  // which blocks get one allotment more: the first `rem` logical blocks -- or (whole tiles, g.bal) the first rem / 8 blocks of
+  // EVERY XCD, which the dispatcher puts on different CUs.  (Logical blocks are XCD-contiguous: with "the first rem" two of
+  // the eight XCDs got all the extra tiles and a 1.25-round launch ran like a 2-round one.)
+  int before = lb < g.rem ? lb : g.rem, mine = lb < g.rem ? 1 : 0;
+  if (g.bal && (G & 7) == 0) {
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3, r8 = g.rem >> 3, rx = g.rem & 7;
+    const int lim = r8 + (x < rx ? 1 : 0);
+    before = x * r8 + (x < rx ? x : rx) + (i < lim ? i : lim);
+    mine = i < lim ? 1 : 0;
+  }
+  const int u0 = (lb * g.base + before) * g.gran;
+  const int u1 = u0 + (g.base + mine) * g.gran;
   if (u0 >= u1) return;
   const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
   const int ja = u0 - k0 * upt;
@@ -227,114 +203,159 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
       else { tile = k0; j0 = 2 * ja; n = nsl - j0; kind = 2; }
     }
   };
-
-  // ---- staging maps ----
-  // A (fp32): thread (ar, ac) loads 4 floats of rows ar, ar + 64; written as 3 x 8 bytes per row
-  const int ar = tid >> 2, ac = tid & 3;
-  // W (bf16 planes): thread (wr, wh) loads 8 bf16 of row wr in each of the three planes
-  const int wr = tid >> 1, wh = tid & 1;
-  const float* a_ptr[2];
-  const unsigned short* w_ptr[3];  // per plane, advanced by one K block per slice
-  const long long w_step = (long long)g.N * 16;
-  auto set_load_tile = [&](int id, int j0) {
-    const int rem2 = id % tiles_mn;
-    const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
-    const float* Asrc = (g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      int row = m0 + ar + 64 * p;
-      row = row < g.M ? row : g.M - 1;
-      a_ptr[p] = Asrc + (size_t)row * g.lda + ac * 4;
-    }
-    int n = n0 + wr;
-    n = n < g.N ? n : g.N - 1;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) w_ptr[q] = g.Wp + q * g.plane_stride + j0 * w_step + (size_t)n * 16 + wh * 8;
+  auto tile_origin = [&](int id, int& m0, int& n0) {
+    const int r = id % tiles_mn;
+    m0 = (r / g.tiles_n) * BM; n0 = (r % g.tiles_n) * BN;
   };
-  int ld_p = 0, ld_j, ld_end;
-  {
-    int tile, j0, n, kind;
-    segment(0, tile, j0, n, kind);
-    set_load_tile(tile, j0);
-    ld_j = j0; ld_end = j0 + n;
-  }
-  f32x4 sa[2][2];
-  u32x4 sw[2][3];
-  auto load_next = [&](f32x4* xa, u32x4* xw) {
-    const int kk0 = ld_j * BK;
+
+  // ---- loader: uniform base pointers (advance per slice) + per-lane BYTE offsets (change per tile) ----
+  int ld_p = 0, ld_j = 0, ld_end = 0;
+  unsigned a_off[2] = {0, 0}, w_off;   // (a fixed bound: an array of dependent size makes the DMA builtin's arguments type-dependent,
+                                       //  and the host pass then drops the whole kernel instantiation without a diagnostic)
+  const char* a_base = nullptr;
+  const char* w_base = nullptr;
+  const size_t w_step = (size_t)g.w_rows * 32, w_pl = (size_t)g.plane_stride * 2;
+  auto set_tile = [&](int id, int j0) {
+    int m0, n0;
+    tile_origin(id, m0, n0);
+    const float* Asrc = (g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A;
+    a_base = reinterpret_cast<const char*>(Asrc) + (size_t)j0 * (BK * 4);
+    w_base = reinterpret_cast<const char*>(g.Wp) + (size_t)j0 * w_step;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) xa[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + kk0);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) xw[q] = *reinterpret_cast<const u32x4*>(w_ptr[q]);
+    for (int q = 0; q < NPA; ++q) {   // piece = 16 rows x 64 B; lane: row lane / 4, 16-byte slot lane % 4 (swizzled by (row >> 2) & 3)
+      const int lr = 16 * (wave * NPA + q) + (lane >> 2);
+      int row = m0 + lr;
+      row = row < g.M ? row : g.M - 1;
+      a_off[q] = ((unsigned)row * g.lda + 4 * ((lane & 3) ^ ((lr >> 2) & 3))) * 4;
+    }
+    {                                 // piece = 32 rows x 32 B of one plane; lane: row lane / 2, slot lane % 2 (swizzled by (row >> 4) & 1)
+      const int lr = 32 * wave + (lane >> 1);
+      int row = n0 + lr;
+      row = row < g.N ? row : g.N - 1;
+      w_off = (unsigned)(g.w_row0 + row) * 32 + (((lane & 1) ^ ((lr >> 4) & 1)) * 16);
+    }
+  };
+  auto issue_piece = [&](int k, int slot) {   // piece k of the slice the loader stands on -> ring slot `slot`
+    unsigned char* base = lds + slot * SLOT;
+    if (k < NPA) {
+      __builtin_amdgcn_global_load_lds(a_base + a_off[k < NPA ? k : 0], X3_LDS_PTR(base + (wave * NPA + k) * 1024), 16, 0, 0);
+    } else {
+      const int p = k - NPA;
+      __builtin_amdgcn_global_load_lds(w_base + p * w_pl + w_off, X3_LDS_PTR(base + A_REG + p * (BN * 32) + wave * 1024), 16, 0, 0);
+    }
   };
   auto advance = [&]() {
     if (++ld_j == ld_end) {
       if (ld_p + 1 < nseg) {
         int tile, j0, n, kind;
         segment(++ld_p, tile, j0, n, kind);
-        set_load_tile(tile, j0);
+        set_tile(tile, j0);
         ld_j = j0; ld_end = j0 + n;
       } else {
-        ld_j = ld_end - 1;
+        ld_j = ld_end - 1;   // past the end: the last slice again (never read)
       }
+    } else { a_base += BK * 4; w_base += w_step; }
+  };
+  auto issue = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) issue_piece(k, slot);
+    advance();
+  };
+
+  // ---- fragment addresses (bytes inside a slot) ----
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned fw = A_REG + (wn * NI) * 1024 + l32 * 32 + ((half ^ (l32 >> 4)) * 16);        // + plane * 4096 + ni * 1024
+  const unsigned fa_r0 = (32 * wm + l32) * 64 + (((2 * half) ^ ((l32 >> 2) & 3)) * 16);         // floats k = 8 half .. + 3
+  const unsigned fa_r1 = (32 * wm + l32) * 64 + (((2 * half + 1) ^ ((l32 >> 2) & 3)) * 16);
+
+  u32x4 wf[2][3][NI];   // [set][plane][ni]
+  u32x4 af[2][3];       // [set][plane]
+  u32x4 ar[2];          // fp32 rows of the next slice (8 floats of this lane's row)
+  // Two accumulator sets: the x1 y1 products go to `acc`, the five small partial products (weight <= 2^-8) to `accs`; the sets
+  // meet once per tile.  The matrix core rounds after EVERY one of the 16 products of an instruction (measured: a K = 512
+  // chain of all six products in one accumulator is 4x as far from fp64 as the f32-MFMA kernel's, i.e. 6 x 512 roundings at
+  // the magnitude of the result against 512); this way `acc` sees exactly the f32 kernel's 512 and the roundings of `accs`
+  // are 2^-8 as large.
+  f32x16 acc[NI], accs[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[ni][e] = 0.f; accs[ni][e] = 0.f; }
+
+  // ---- MODE 1: (mean, rstd) of this lane's row for the tile being computed and the next one ----
+  float mean_c = 0.f, rstd_c = 1.f, mean_n = 0.f, rstd_n = 1.f;
+  float mean_s = 0.f, rstd_s = 1.f;   // what the split in flight uses
+  const unsigned stat_lds = lds0 + 3 * SLOT + wave * 4096;
+  auto stats_fetch = [&](int p) {     // DMA the segment statistics of segment p's rows (this wave's 32) into the wave's patch
+    if (MODE != 1 || p >= nseg) return;
+    int tile, j0, n, kind, m0, n0;
+    segment(p, tile, j0, n, kind);
+    tile_origin(tile, m0, n0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {     // piece = 8 rows x 128 B
+      int row = m0 + 32 * wm + 8 * q + (lane >> 3);
+      row = row < g.M ? row : g.M - 1;
+      __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + (lane & 7) * 4,
+                                       X3_LDS_PTR(lds + 3 * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
+    }
+  };
+  auto stats_merge = [&](float& mean, float& rstd) {   // Chan's update for 16 equal parts (as ff_ln_finish of the f32 family)
+    if (MODE != 1) return;
+    u32x4 s[8];
+    s[0] = x3_lds_read16<0>(stat_lds + l32 * 128);   s[1] = x3_lds_read16<16>(stat_lds + l32 * 128);
+    s[2] = x3_lds_read16<32>(stat_lds + l32 * 128);  s[3] = x3_lds_read16<48>(stat_lds + l32 * 128);
+    s[4] = x3_lds_read16<64>(stat_lds + l32 * 128);  s[5] = x3_lds_read16<80>(stat_lds + l32 * 128);
+    s[6] = x3_lds_read16<96>(stat_lds + l32 * 128);  s[7] = x3_lds_read16<112>(stat_lds + l32 * 128);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7])::"memory");
+    float sm = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 v = __builtin_bit_cast(f32x4, s[i]);
+      sm += v[0] + v[2]; m2 += v[1] + v[3];
+    }
+    mean = sm * (1.0f / 16.0f);
+    float dev = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 v = __builtin_bit_cast(f32x4, s[i]);
+      const float d0 = v[0] - mean, d1 = v[2] - mean;
+      dev += d0 * d0 + d1 * d1;
+    }
+    const float var = (m2 + 32.f * dev) * (1.0f / 512.0f);
+    rstd = 1.0f / sqrtf(var + g.ln_eps);
+  };
+
+  // ---- split of the 8 floats in ar[] in eight steps (pair q = step / 2, level = step % 2): dealt out over the MFMA gaps;
+  //      the results are pinned where they are computed (the optimiser would sink them to their use) ----
+  float r_[4][2];
+  unsigned p1_[4], p2_[4], p3_[4];
+  auto split_step = [&](int st) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int q = st >> 1;
+    if ((st & 1) == 0) {
+      const f32x4 v = __builtin_bit_cast(f32x4, ar[q >> 1]);
+      float x0 = v[2 * (q & 1)], x1 = v[2 * (q & 1) + 1];
+      if (MODE == 1) {   // (x - mean) * rstd, the reference's order of operations
+        x0 = x3_fmul(x3_fsub(x0, mean_s), rstd_s);
+        x1 = x3_fmul(x3_fsub(x1, mean_s), rstd_s);
+      }
+      p1_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+      r_[q][0] = x3_fsub(x0, __builtin_bit_cast(float, p1_[q] << 16));
+      r_[q][1] = x3_fsub(x1, __builtin_bit_cast(float, p1_[q] & 0xffff0000u));
+      asm volatile("" : "+v"(p1_[q]), "+v"(r_[q][0]), "+v"(r_[q][1]));
     } else {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) w_ptr[q] += w_step;
+      p2_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r_[q][0], r_[q][1]}, bf16x2));
+      const float s0 = x3_fsub(r_[q][0], __builtin_bit_cast(float, p2_[q] << 16));
+      const float s1 = x3_fsub(r_[q][1], __builtin_bit_cast(float, p2_[q] & 0xffff0000u));
+      p3_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+      asm volatile("" : "+v"(p2_[q]), "+v"(p3_[q]));
     }
   };
-  // LDS addresses (bytes inside a ring slot)
-  int sta[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int row = ar + 64 * p;
-    sta[p] = row * 32 + (((ac >> 1) ^ ((row >> 4) & 1)) * 16) + (ac & 1) * 8;
-  }
-  const int stw = (BM + wr) * 32 + ((wh ^ ((wr >> 4) & 1)) * 16);
-  auto store_from = [&](const f32x4* xa, const u32x4* xw, int buf) {
-    unsigned char* base = lds + buf * BUF_B;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      unsigned a1, a2, a3, b1, b2, b3;
-      split2(xa[p][0], xa[p][1], a1, a2, a3);
-      split2(xa[p][2], xa[p][3], b1, b2, b3);
-      *reinterpret_cast<u32x2*>(base + sta[p]) = u32x2{a1, b1};
-      *reinterpret_cast<u32x2*>(base + PLANE_B + sta[p]) = u32x2{a2, b2};
-      *reinterpret_cast<u32x2*>(base + 2 * PLANE_B + sta[p]) = u32x2{a3, b3};
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(base + q * PLANE_B + stw) = xw[q];
-  };
-  // fragment addresses: the swizzle bit of rows wm0 + mi*32 + l32 only depends on l32
-  const int fchunk = (half ^ ((l32 >> 4) & 1)) * 16;
-  const int fra = (wm0 + l32) * 32 + fchunk;
-  const int frb = (BM + wn0 + l32) * 32 + fchunk;
-  bf16x8 fa[3][2], fb[3][2];
-  auto read_frags = [&](bf16x8 (*xa)[2], bf16x8 (*xb)[2], int buf) {
-    const unsigned char* base = lds + buf * BUF_B;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        xa[p][i] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_B + fra + i * 32 * 32);
-        xb[p][i] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_B + frb + i * 32 * 32);
-      }
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-  auto mfma_frags = [&](bf16x8 (*xa)[2], bf16x8 (*xb)[2]) {
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[t]][mi], xb[PB[t]][ni], acc[mi][ni], 0, 0, 0);
+  auto split_collect = [&](u32x4 (&dst)[3]) {
+    dst[0] = u32x4{p1_[0], p1_[1], p1_[2], p1_[3]};
+    dst[1] = u32x4{p2_[0], p2_[1], p2_[2], p2_[3]};
+    dst[2] = u32x4{p3_[0], p3_[1], p3_[2], p3_[3]};
   };
 
   // ---- compute-side segment state ----
@@ -344,48 +365,264 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args g) {
     int id, j0;
     segment(p, id, j0, cp_n, cp_kind);
     cp_cnt = 0;
-    const int rem2 = id % tiles_mn;
-    e_m0 = (rem2 / g.tiles_n) * BM;
-    e_n0 = (rem2 % g.tiles_n) * BN;
+    tile_origin(id, e_m0, e_n0);
   };
-  auto end_segment = [&]() { x3_end_segment(g, acc, cp_kind, lb, k0, e_m0, e_n0); };
 
-  // ---- prologue: slices 0,1 -> LDS; slices 2,3 -> staging registers ----
-  load_next(sa[0], sw[0]); advance();
-  load_next(sa[1], sw[1]); advance();
-  store_from(sa[0], sw[0], 0);
-  store_from(sa[1], sw[1], 1);
-  load_next(sa[0], sw[0]); advance();
-  load_next(sa[1], sw[1]); advance();
+  // End of a segment: hand the partial tile over (kind 1), or finish the tile -- after adding the partials of the
+  // lower-numbered blocks (kind 2) -- with bias / activation / table / residual, the store and (MODE 2) the statistics.
+  // Every global access of this path is inline assembly with its own waits: accesses the compiler knows about leave an
+  // "unknown" wait-count state at the join with the K loop (it then opens every slice with s_waitcnt vmcnt(0)), and the
+  // stores must not be waited for at all -- they drain behind the next tile's first slices.
+  auto gload16 = [&](const float* ptr) -> f32x4 {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+  };
+  auto end_segment = [&]() {
+    constexpr int NQ = 4 * NI;   // 16-byte accumulator groups per lane
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[ni][e] += accs[ni][e]; accs[ni][e] = 0.f; }
+    if (cp_kind == 1) {
+      f32x4* wp = reinterpret_cast<f32x4*>(g.ws + (size_t)lb * (BM * BN)) + tid;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + (ni * 4 + q) * 256), "v"(v) : "memory");
+          acc[ni][4 * q] = 0.f; acc[ni][4 * q + 1] = 0.f; acc[ni][4 * q + 2] = 0.f; acc[ni][4 * q + 3] = 0.f;
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) __hip_atomic_store(g.flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
+      const int ab = (k0 * upt) / g.gran;   // allotment that starts the tile (unit ranges: gran = 1)
+      const int big = g.rem * (g.base + 1);
+      const int c0 = ab < big ? ab / (g.base + 1) : g.rem + (ab - big) / g.base;
+      for (int c = c0; c < lb; ++c) {
+        while (__hip_atomic_load(g.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const f32x4* rp = reinterpret_cast<const f32x4*>(g.ws + (size_t)c * (BM * BN)) + tid;
+        constexpr int TQ = 8;   // 8 x 16 bytes in flight per lane and round trip (all 16 of a 128-row tile would spill)
+#pragma unroll
+        for (int h = 0; h < NQ / TQ; ++h) {
+          f32x4 t[TQ];
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[j]) : "v"(rp + (h * TQ + j) * 256) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) {
+            asm volatile("" : "+v"(t[j]));
+            const int q = h * TQ + j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[q >> 2][4 * (q & 3) + i] += t[j][i];
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();  // every thread is past its flag polls
+      if (tid < lb - c0) __hip_atomic_store(g.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // This lane: row m, columns n0 + (wn * NI + ni) * 32 + 8 q + 4 half + {0..3}.  ALL epilogue operands of the tile are
+    // requested in one go (the fragments of the next slice are not live here: they are read again behind the epilogue),
+    // every result is finished in its accumulator registers, then the stores go out back to back.  A lane reads and
+    // writes the same elements, so a residual that aliases C stays correct.
+    const int m = e_m0 + 32 * wm + l32;
+    const bool rowok = m < g.M;
+    const int mc = rowok ? m : g.M - 1;
+    const int nb0 = e_n0 + wn * NI * 32 + 4 * half;
+    const bool has_tab = MODE == 1 && g.rowtab != nullptr;
+    const float* xrow = nullptr;   // residual row, or (MODE 1) the row of the position table
+    int xlim = 0;
+    if (g.res) { xrow = g.res + (size_t)mc * g.ldr; xlim = g.N; }
+    else if (has_tab) { xrow = g.rowtab + (size_t)(mc / g.rowtab_div) * g.ld_rowtab; xlim = g.rowtab_cols; }
+    // two 32-column groups at a time (8 + 8 operand registers of 16 bytes): with all of a 128-column row's operands in
+    // flight at once the register allocator spills loop-invariant addresses INTO the K loop
+    constexpr int GQ = NI == 4 ? 4 : 8;
+#pragma unroll
+    for (int h = 0; h < NQ / GQ; ++h) {
+      f32x4 xv[GQ], bv[GQ];
+#pragma unroll
+      for (int j = 0; j < GQ; ++j) {
+        const int q = h * GQ + j;
+        const int n = nb0 + (q >> 2) * 32 + (q & 3) * 8;
+        xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xrow && n + 3 < xlim) xv[j] = gload16(xrow + n);
+        if (g.bias && n + 3 < g.N) bv[j] = gload16(g.bias + n);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < GQ; ++j) asm volatile("" : "+v"(xv[j]), "+v"(bv[j]));
+#pragma unroll
+      for (int j = 0; j < GQ; ++j) {
+        const int q = h * GQ + j, ni = q >> 2, qq = q & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[ni][4 * qq + i] + bv[j][i];
+          if (MODE == 1) {           // position-table term in front of the activation, no residual
+            v += xv[j][i];
+            if (g.act == 1) v = fmaxf(v, 0.f);
+          } else {
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            v += xv[j][i];
+          }
+          acc[ni][4 * qq + i] = v;
+        }
+      }
+    }
+    if (MODE == 2) {   // (mean, M2) of this row's 32 stored values per column group: 16 here, 16 in the lane 32 away
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm += acc[ni][e];
+        sm += __shfl_xor(sm, 32, FF_WAVE);
+        const float mean = sm * (1.0f / 32.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float d = acc[ni][e] - mean; m2 += d * d; }
+        m2 += __shfl_xor(m2, 32, FF_WAVE);
+        const int seg = (e_n0 >> 5) + wn * NI + ni;
+        if (half == 0 && rowok && seg * 32 < g.N) {
+          const f32x2 st2 = f32x2{mean, m2};
+          asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g.ln_out + ((size_t)m * (g.N >> 5) + seg) * 2), "v"(st2) : "memory");
+        }
+      }
+    }
+    if (rowok) {
+      float* cp = g.C + (size_t)m * g.ldc + nb0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (nb0 + (q >> 2) * 32 + (q & 3) * 8 + 3 < g.N) {
+          const f32x4 v = {acc[q >> 2][4 * (q & 3)], acc[q >> 2][4 * (q & 3) + 1], acc[q >> 2][4 * (q & 3) + 2], acc[q >> 2][4 * (q & 3) + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(cp + (q >> 2) * 32 + (q & 3) * 8), "v"(v) : "memory");
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+  };
+
+  // ---- prologue: slices 0, 1, 2 in flight; 0 and 1 landed; fragments of slice 0 in set 0 ----
+  {
+    int tile, j0, n, kind;
+    segment(0, tile, j0, n, kind);
+    set_tile(tile, j0);
+    ld_j = j0; ld_end = j0 + n;
+  }
+  if (MODE == 1) {   // statistics of segment 0 (and 1): fetched and merged before the first split
+    stats_fetch(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    stats_merge(mean_c, rstd_c);
+    stats_fetch(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    stats_merge(mean_n, rstd_n);
+    stats_fetch(2);
+    mean_s = mean_c; rstd_s = rstd_c;
+  }
+  issue(0); issue(1); issue(2);
   begin_segment(0);
-  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0F70 | NP);   // vmcnt(NP): all but the youngest slice
+  __builtin_amdgcn_s_barrier();
+  {
+    ar[0] = x3_lds_read16(lds0 + fa_r0);
+    ar[1] = x3_lds_read16(lds0 + fa_r1);
+#pragma unroll
+    for (int r = 0; r < 3 * NI; ++r) x3_read_w_i<NI>(wf[0], lds0 + fw, r);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
+#pragma unroll
+    for (int st = 0; st < 8; ++st) split_step(st);
+    split_collect(af[0]);
+  }
+  __builtin_amdgcn_s_barrier();
 
-  int b0 = 0, b1 = 1, b2 = 2;
-  const int total_slices = 2 * (u1 - u0);
-  for (int s = 0; s < total_slices; s += 2) {
+  constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // (A plane, W plane), small terms first
+  // where the split steps and the DMA pieces go among the MFMA gaps
+  constexpr int SP0 = NI == 4 ? 5 : 3;            // first split step (the two row reads are the oldest of SP0 + 1 reads)
+  constexpr int DM0 = NI == 4 ? NRD : NMF - NP;   // first DMA piece
+  int s0 = 0, s1 = 1;   // ring slots of slice s, s + 1  (slice s + 3 goes to slot s0)
+  const int total = 2 * (u1 - u0);
+  for (int s = 0; s < total; s += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      read_frags(fa, fb, b0);
-      store_from(sa[u], sw[u], b2);
-      load_next(sa[u], sw[u]);
-      mfma_frags(fa, fb);
-      advance();
+      const unsigned nb = lds0 + s1 * SLOT;   // slot of slice s + 1
+      if (MODE == 1) {   // the rows split in this iteration belong to the next segment's tile when this is the segment's last slice
+        const bool nx = cp_cnt + 1 == cp_n;
+        mean_s = nx ? mean_n : mean_c; rstd_s = nx ? rstd_n : rstd_c;
+      }
+      // NMF MFMAs of slice s; in their gaps: the reads of slice s + 1 (one per gap), the split of its rows, the DMA of s + 3
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        const int t = i / NI, ni = i % NI;
+        if (t < 5) accs[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
+                                                                      __builtin_bit_cast(bf16x8, af[u][PA[t]]), accs[ni], 0, 0, 0);
+        else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
+                                                               __builtin_bit_cast(bf16x8, af[u][PA[t]]), acc[ni], 0, 0, 0);
+        if (i == 0) ar[0] = x3_lds_read16(nb + fa_r0);
+        else if (i == 1) ar[1] = x3_lds_read16(nb + fa_r1);
+        else if (i < NRD) x3_read_w_i<NI>(wf[u ^ 1], nb + fw, i - 2);
+        if (i == SP0) {
+          if (SP0 == 5) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
+          else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
+        }
+        if (i >= SP0 && i < SP0 + 8) split_step(i - SP0);
+        if (i == SP0 + 8) split_collect(af[u ^ 1]);
+        if (i >= DM0 && i < DM0 + NP) issue_piece(i - DM0, s0);
+        if (i == NMF - 1) advance();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (SP0 + 8 >= NMF) split_collect(af[u ^ 1]);
+      // slice s + 2 has landed (own pieces), every fragment of slice s + 1 is in registers
+      __builtin_amdgcn_s_waitcnt(0x0070 | NP);   // vmcnt(NP) lgkmcnt(0)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[u ^ 1][p][ni]));
       if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
         end_segment();
         if (++cp_p < nseg) begin_segment(cp_p);
-        // Drain the vector-memory counter on this (rare) path: otherwise the compiler's wait-count
-        // analysis merges the unknown state left by the loops above into the K loop and opens every
-        // slice with s_waitcnt vmcnt(0), i.e. exposes the full latency of the loads issued one slice ago.
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // 64-row tiles: the fragments of slice s + 1 are read AGAIN here (their slot is untouched until the barrier below),
+        // so the values read inside the loop are dead across the epilogue and its operands do not compete with them for the
+        // 168 registers of three waves per SIMD.  (128-row tiles keep them live: the second copy of the read-and-split code
+        // costs that kernel more registers than it frees.)  Either way no register that an asynchronous ds_read has not
+        // filled yet may be spilled: tools/check_x3_asm.py looks for scratch accesses inside the MFMA runs of every build.
+        if (NI == 2) {
+          ar[0] = x3_lds_read16(nb + fa_r0);
+          ar[1] = x3_lds_read16(nb + fa_r1);
+#pragma unroll
+          for (int r = 0; r < 3 * NI; ++r) x3_read_w_i<NI>(wf[u ^ 1], nb + fw, r);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[u ^ 1][p][ni]));
+          mean_s = mean_n; rstd_s = rstd_n;   // (MODE 1: these rows belong to the segment that starts now)
+#pragma unroll
+          for (int st = 0; st < 8; ++st) split_step(st);
+          split_collect(af[u ^ 1]);
+        }
+        if (MODE == 1) {       // statistics: the next segment's become current, the one after is merged from the patch
+          mean_c = mean_n; rstd_c = rstd_n;
+          stats_merge(mean_n, rstd_n);
+          stats_fetch(cp_p + 2);
+        }
       }
-      __syncthreads();
-      { const int tmp = b0; b0 = b1; b1 = b2; b2 = tmp; }
+      __builtin_amdgcn_s_barrier();
+      { const int tmp = s0; s0 = s1; s1 = 3 - s0 - tmp; }   // (s0, s1, s2) -> (s1, s2, s0)
     }
   }
 }
 
-// Partial-tile workspace: one per (device, stream), as in ff_gemm.hip (64 KB slots here).
-constexpr int X3_MAX_GRID = 512;
+// Partial-tile workspace: one per (device, stream), as in ff_gemm.hip.
+constexpr int X3_MAX_GRID = 768;
+constexpr size_t X3_WS_BYTES = (size_t)X3_MAX_GRID * 64 * 128 * sizeof(float);   // one 32 KB partial tile per block
 struct X3Workspace {
   int device;
   hipStream_t st;
@@ -405,12 +642,89 @@ int x3_acquire(hipStream_t st, X3Args* out) {
       return FF_OK;
     }
   X3Workspace w{dev, st, nullptr, nullptr};
-  FF_CHECK_HIP(hipMalloc(&w.ws, (size_t)X3_MAX_GRID * 128 * 128 * sizeof(float)));
+  FF_CHECK_HIP(hipMalloc(&w.ws, X3_WS_BYTES));
   FF_CHECK_HIP(hipMalloc(&w.flags, X3_MAX_GRID * sizeof(unsigned int)));
   FF_CHECK_HIP(hipMemset(w.flags, 0, X3_MAX_GRID * sizeof(unsigned int)));
   FF_CHECK_HIP(hipDeviceSynchronize());
   g_x3.push_back(w);
   out->ws = w.ws; out->flags = w.flags;
+  return FF_OK;
+}
+
+// tuning / tests: force the launch shape (0 auto, 1 whole tiles, 2 unit ranges)
+int g_x3_force_shape = 0;
+
+template <int BM, int MODE>
+int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
+  static bool attr_set[16] = {};   // hipFuncSetAttribute is per device
+  constexpr int bytes = 3 * (BM * 64 + 3 * X3_BN * 32) + (MODE == 1 ? X3_STAT_BYTES : 0);
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<BM, MODE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm_x3_kernel<BM, MODE>), dim3(grid), dim3(256), bytes, st, g);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+// Launch shape: WHOLE TILES, always (round 4).  Measured over the decode's shapes (profiles/r04/gemm_x3_variants.txt): once the
+// blocks that get one tile more are dealt out over the XCDs and CUs, whole tiles are as fast as or faster than equal K-unit
+// ranges everywhere but one shape (9216 x 1024 -> 512: 152 vs 163 TF/s) -- the exchange of the cut tiles (a 32 KB hand-over
+// and a fix-up round trip per block) costs what the finer balance buys -- and they need no cross-block traffic and sum every
+// output element in ONE fixed order whatever the grid.  The unit-range form stays available (ff_set_x3_tuning: tests, probes).
+// Only the 64-row tile is instantiated: the 128-row form (4 x 1 waves of 32 x 128) needs all 256 registers of a two-wave SIMD
+// and the register allocator then spills INTO the K loop (a spill of a fragment register that an asynchronous ds_read has
+// not filled yet stores garbage, and every reload costs a full vmcnt drain); where it compiled cleanly it was within +-7 %
+// of the 64-row tile.
+int x3_launch(X3Args g, int mode, hipStream_t st) {
+  const int M = g.M, N = g.N, K = g.K;
+  constexpr int BM = 64;
+  const int cus = 256;
+  const int slots = cus * (mode == 1 ? 2 : 3);
+  g.tiles_n = ff_cdiv(N, X3_BN);
+  g.tiles_m = ff_cdiv(M, BM);
+  g.upt = K / 32;
+  const long tiles = (long)g.tiles_m * g.tiles_n;
+  const long units = tiles * g.upt;
+  FF_CHECK_ARG(units < (1L << 30), "ff_gemm_x3: problem too large");
+  int shape = g_x3_force_shape ? g_x3_force_shape : 1;
+  if (units < 2) shape = 1;
+  long grid;
+  if (shape == 1) {        // whole tiles: contiguous runs of tiles per block
+    grid = tiles < slots ? tiles : slots;
+    g.gran = g.upt;
+    g.base = (int)(tiles / grid);
+    g.rem = (int)(tiles % grid);
+    g.bal = 1;
+  } else {                 // equal unit ranges over every resident block slot
+    grid = units < slots ? units : slots;
+    g.gran = 1;
+    g.base = (int)(units / grid);
+    g.rem = (int)(units % grid);
+  }
+  FF_RETURN_IF(x3_acquire(st, &g));
+  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K, st);
+  ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (g.res ? 2 : 1)));
+  if (mode == 1) return x3_launch_mode<BM, 1>(g, (int)grid, st);
+  if (mode == 2) return x3_launch_mode<BM, 2>(g, (int)grid, st);
+  return x3_launch_mode<BM, 0>(g, (int)grid, st);
+}
+
+int x3_check_common(const float* A, int lda, const void* w_planes, const float* bias, const float* residual, int ldr,
+                    float* C, int ldc, int M, int N, int K, int act, const char* who) {
+  FF_CHECK_ARG(M > 0 && N > 0 && K >= 64 && (K % 32) == 0, "%s: bad M=%d N=%d K=%d (K %% 32, K >= 64)", who, M, N, K);
+  FF_CHECK_ARG(A && w_planes && C, "%s: null operand", who);
+  FF_CHECK_ARG(ff_aligned16(w_planes), "%s: weight planes must be 16-byte aligned", who);
+  FF_CHECK_ARG((lda & 3) == 0 && lda >= K && ff_aligned16(A), "%s: A must be 16-byte aligned with lda %% 4 == 0 (lda=%d)", who, lda);
+  FF_CHECK_ARG((size_t)M * lda < ((size_t)1 << 30), "%s: A is too large for 32-bit byte offsets", who);
+  FF_CHECK_ARG((N & 3) == 0 && N >= 4 && ldc >= N && (ldc & 3) == 0 && ff_aligned16(C),
+               "%s: N %% 4, ldc %% 4 and a 16-byte aligned C are required (N=%d ldc=%d)", who, N, ldc);
+  FF_CHECK_ARG(!bias || ff_aligned16(bias), "%s: bias must be 16-byte aligned", who);
+  FF_CHECK_ARG(!residual || (ldr >= N && (ldr & 3) == 0 && ff_aligned16(residual)), "%s: bad residual (ldr %% 4, 16-byte aligned)", who);
+  FF_CHECK_ARG(act == 0 || act == 1, "%s: act must be 0 or 1", who);
   return FF_OK;
 }
 
@@ -434,58 +748,56 @@ extern "C" int ff_x3_prepare_stream(hipStream_t st) {
   return x3_acquire(st, &g);
 }
 
+extern "C" int ff_set_x3_tuning(int shape) {
+  FF_CHECK_ARG(shape >= 0 && shape <= 2, "ff_set_x3_tuning: shape in {0, 1, 2}");
+  g_x3_force_shape = shape;
+  ff_tuning_changed();
+  return FF_OK;
+}
+
 extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
                           const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
                           int K, int act, ff_stream_t stream) {
   if (M == 0 || N == 0) return FF_OK;
-  FF_CHECK_ARG(M > 0 && N > 0 && K >= 64 && (K % 32) == 0, "ff_gemm_x3: bad M=%d N=%d K=%d (K %% 32, K >= 64)", M, N, K);
-  FF_CHECK_ARG(A && w_planes && C, "ff_gemm_x3: null operand");
-  FF_CHECK_ARG(ff_aligned16(w_planes) && ((size_t)N * K % 8) == 0, "ff_gemm_x3: weight planes must be 16-byte aligned");
-  FF_CHECK_ARG((lda & 3) == 0 && lda >= K && ff_aligned16(A) && (!A2 || ff_aligned16(A2)),
-               "ff_gemm_x3: A/A2 must be 16-byte aligned with lda %% 4 == 0 (lda=%d)", lda);
-  FF_CHECK_ARG(ldc >= N, "ff_gemm_x3: bad ldc");
-  FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_x3: bad ldr");
-  FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_x3: act must be 0 or 1");
+  FF_RETURN_IF(x3_check_common(A, lda, w_planes, bias, residual, ldr, C, ldc, M, N, K, act, "ff_gemm_x3"));
+  FF_CHECK_ARG(!A2 || ff_aligned16(A2), "ff_gemm_x3: A2 must be 16-byte aligned");
   if (A2) FF_CHECK_ARG(n_split > 0 && n_split < N && (n_split % 128) == 0, "ff_gemm_x3: n_split must be a multiple of 128 inside (0,N)");
-  hipStream_t st = (hipStream_t)stream;
   X3Args g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.A2 = A2; g.lda = lda;
   g.Wp = static_cast<const unsigned short*>(w_planes); g.bias = bias; g.res = residual; g.ldr = ldr;
   g.C = C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.n_split = A2 ? n_split : N; g.act = act;
-  g.tiles_m = ff_cdiv(M, 128); g.tiles_n = ff_cdiv(N, 128);
   g.plane_stride = (long long)N * K;
-  g.upt = K / 32;
-  const long units = (long)g.tiles_m * g.tiles_n * g.upt;
-  FF_CHECK_ARG(units < (1L << 30), "ff_gemm_x3: problem too large");
-  // Launch shape.  A cut tile costs its owner one memory round trip per contributing block (64 KB each),
-  // so small launches cut every tile in two (four below 32 tiles) rather than into many pieces; from 256
-  // tiles on, 512 blocks get equal unit ranges (a tile then spans at most three blocks).
-  const long tiles = (long)g.tiles_m * g.tiles_n;
-  long grid;
-  if (tiles > X3_MAX_GRID / 2) grid = X3_MAX_GRID;
-  else {
-    long sf = tiles <= 32 ? 4 : 2;
-    if (sf > g.upt) sf = g.upt;
-    grid = tiles * sf;
-    if (grid > X3_MAX_GRID) grid = X3_MAX_GRID;
-  }
-  if (grid > units) grid = units;
-  g.base = (int)(units / grid);
-  g.rem = (int)(units % grid);
-  FF_RETURN_IF(x3_acquire(st, &g));
-  static bool attr_set[16] = {};   // hipFuncSetAttribute is per device
-  constexpr int bytes = 3 * 3 * 256 * 32;
-  int dev = 0;
-  FF_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    if (dev >= 0 && dev < 16) attr_set[dev] = true;
-  }
-  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K, st);
-  hipLaunchKernelGGL(gemm_x3_kernel, dim3((int)grid), dim3(256), bytes, st, g);
-  FF_CHECK_LAUNCH();
-  return FF_OK;
+  g.w_rows = N; g.w_row0 = 0;
+  return x3_launch(g, 0, (hipStream_t)stream);
+}
+
+extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int plane_rows, int row0, ff_stream_t stream) {
+  FF_CHECK_ARG(d != nullptr, "ff_gemm_x3_ln: null descriptor");
+  const int M = d->M, N = d->N, K = d->K;
+  if (M == 0 || N == 0) return FF_OK;
+  if (plane_rows <= 0) plane_rows = N;
+  FF_CHECK_ARG(row0 >= 0 && row0 + N <= plane_rows, "ff_gemm_x3_ln: rows [%d, %d) outside the %d rows of the planes", row0, row0 + N, plane_rows);
+  FF_RETURN_IF(x3_check_common(d->A, d->lda, w_planes, d->bias, d->residual, d->ldr, d->C, d->ldc, M, N, K, d->act, "ff_gemm_x3_ln"));
+  FF_CHECK_ARG(!(d->ln_stats_in && d->ln_stats_out), "ff_gemm_x3_ln: statistics in AND out in one launch are not supported");
+  FF_CHECK_ARG(!d->ln_stats_in || (K == 512 && d->ln_nseg == 16 && d->ln_eps >= 0.f && ff_aligned16(d->ln_stats_in)),
+               "ff_gemm_x3_ln: ln_stats_in needs K = 512 (16 segments of 32 columns), 16-byte aligned statistics");
+  FF_CHECK_ARG(!d->row_table || (d->ln_stats_in && !d->residual && d->row_div > 0 && d->row_cols > 0 && d->row_cols <= N &&
+                                 (d->row_cols & 3) == 0 && d->ld_row_table >= d->row_cols && (d->ld_row_table & 3) == 0 &&
+                                 ff_aligned16(d->row_table)),
+               "ff_gemm_x3_ln: row_table needs ln_stats_in, no residual, row_div > 0, 0 < row_cols <= N, row_cols / ld %% 4");
+  FF_CHECK_ARG(!d->ln_stats_out || (N & 31) == 0, "ff_gemm_x3_ln: ln_stats_out needs N %% 32 == 0");
+  X3Args g;
+  memset(&g, 0, sizeof(g));
+  g.A = d->A; g.lda = d->lda;
+  g.Wp = static_cast<const unsigned short*>(w_planes); g.bias = d->bias; g.res = d->residual; g.ldr = d->ldr;
+  g.C = d->C; g.ldc = d->ldc;
+  g.M = M; g.N = N; g.K = K; g.n_split = N; g.act = d->act;
+  g.plane_stride = (long long)plane_rows * K;
+  g.w_rows = plane_rows; g.w_row0 = row0;
+  g.ln_in = d->ln_stats_in; g.ln_eps = d->ln_eps;
+  g.rowtab = d->row_table; g.ld_rowtab = d->ld_row_table; g.rowtab_div = d->row_div > 0 ? d->row_div : 1; g.rowtab_cols = d->row_cols;
+  g.ln_out = d->ln_stats_out;
+  return x3_launch(g, d->ln_stats_in ? 1 : (d->ln_stats_out ? 2 : 0), (hipStream_t)stream);
 }

@@ -297,25 +297,36 @@ def gather_json_records(records, dist_mod, group=None, device=None):
 
 
 def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominant_directions=None,
-                        pairings=None, is_coedge=False, tol=2e-4):
+                        pairings=None, is_coedge=False, tol=2e-4, local_shard=False):
     """decode_sharded + face parsing of the rank's own wireframes + JSON all-gather: every rank returns
     the list of N per-wireframe JSON records in batch order (`edges`, `dominant_directions`, `pred_faces`,
     `label_faces`; reference trainer.py:118-136).  `edges[i]` / `dominant_directions[i]` / `pairings[i]`
-    are the raw-data entries of wireframe i when available (else the record carries empty lists)."""
+    are the raw-data entries of wireframe i when available (else the record carries empty lists).
+    local_shard=True: `inputs` (and edges / dominant_directions / pairings) hold only this rank's wireframes; the records
+    come back for the whole batch = the shards in rank order."""
     from . import faces as FZ
     from .models import SurfaceFormer_Parallel
-    out = decode_sharded(model, inputs, dist_mod, group)
+    n_here = inputs["input"].size(0)
+    out = decode_sharded(model, inputs, dist_mod, group, local_shard=local_shard)
     rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
-    N = inputs["input"].size(0)
     parallel = isinstance(model, SurfaceFormer_Parallel)
-    if parallel:
-        ni = [int(n) for n in inputs["num_input"]]
-        plan = shard_plan(ni, world, max(ni))
+    if local_shard:
+        sizes = out["shard_sizes"]
+        N, base = sum(sizes), sum(sizes[:rank])
+        plan = [list(range(sum(sizes[:r]), sum(sizes[:r + 1]))) for r in range(world)]
+        mine = list(range(n_here))                     # indices into the rank's own inputs
+        rows = [base + k for k in mine]                # ... and into the gathered predict
     else:
-        plan = [list(range(*shard_range(N, r, world)[:2])) for r in range(world)]
-    mine = plan[rank]
+        N = n_here
+        if parallel:
+            ni = [int(n) for n in inputs["num_input"]]
+            plan = shard_plan(ni, world, max(ni))
+        else:
+            plan = [list(range(*shard_range(N, r, world)[:2])) for r in range(world)]
+        mine = plan[rank]
+        rows = mine
     sel = torch.tensor(mine, dtype=torch.long)
-    pred = out["predict"].cpu()[sel].numpy() if mine else []
+    pred = out["predict"].cpu()[torch.tensor(rows, dtype=torch.long)].numpy() if mine else []
     labels = inputs["label"].cpu()[sel].numpy() if mine else []
     recs = []
     for k, i in enumerate(mine):

@@ -112,6 +112,13 @@ class PathEngine:
                     lw.ln3_w, lw.ln3_b, _ = self._fold(
                         (i, 3), tensors[p + "linear1.weight"], tensors[p + "linear1.bias"],
                         tensors[p + "norm3.weight"], tensors[p + "norm3.bias"], None, 0)
+                    if bf16_split_planes and E % 32 == 0:
+                        # planes of the FOLDED weights: the steps that take the 3 x bf16 projections keep the LayerNorm
+                        # folding (ff_gemm_x3_ln) instead of launching their LayerNorms
+                        for field, key in (("ln1_planes", (i, 1)), ("ln2_planes", (i, 2)), ("ln3_planes", (i, 3))):
+                            pl = split_weight(self._folded[key][0])
+                            self._planes[(i, field)] = pl
+                            setattr(lw, field, pl.data_ptr())
                 m.proj_fold_w, m.proj_fold_b, _ = self._fold(
                     ("proj",), tensors["project.weight"], tensors["project.bias"],
                     tensors["decoder.norm.weight"], tensors["decoder.norm.bias"], None, 0)

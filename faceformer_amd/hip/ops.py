@@ -149,6 +149,47 @@ def linear_ln(x, weight, bias=None, act=0, residual=None, stats_in=None, eps=1e-
 
 
 @_on_tensor_device
+def linear_x3_ln(x, planes, bias=None, act=0, residual=None, stats_in=None, eps=1e-5, row_table=None, row_div=1,
+                 row_cols=0, want_stats=False, out=None, row0=0, rows=0):
+    """ff_gemm_x3_ln: linear_ln() on the bf16 matrix cores with fp32 accuracy; `planes` = split_weight(folded weight).
+    row0 / rows: use only weight rows [row0, row0 + rows) of the planes (bias, table and output then have `rows` columns)."""
+    _check_planes(planes, "planes")
+    plane_rows, K = planes.size(2), planes.size(1) * 16
+    N = rows or plane_rows
+    x, lda = _rows(x, "x")
+    M = x.size(0)
+    if x.size(1) != K:
+        raise ValueError("linear_x3_ln: x is [%d,%d] but the weight is [%d,%d]" % (M, x.size(1), N, K))
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    out, ldc = _rows(out, "out")
+    d = _L.GemmLnDesc()
+    d.A, d.lda, d.bias = _p(x), lda, _p(bias)
+    if residual is not None:
+        residual, ldr = _rows(residual, "residual")
+        d.residual, d.ldr = _p(residual), ldr
+    d.C, d.ldc, d.M, d.N, d.K, d.act = _p(out), ldc, M, N, K, act
+    if stats_in is not None:
+        _dev(stats_in, "stats_in")
+        stats_in = stats_in.contiguous()
+        d.ln_stats_in, d.ln_nseg, d.ln_eps = _p(stats_in), stats_in.size(1), eps
+    if row_table is not None:
+        row_table, ldt = _rows(row_table, "row_table")
+        d.row_table, d.ld_row_table, d.row_div, d.row_cols = _p(row_table), ldt, row_div, row_cols or row_table.size(1)
+    stats = None
+    if want_stats:
+        stats = torch.full((M, N // 32, 2), float("nan"), device=x.device, dtype=torch.float32)
+        d.ln_stats_out = _p(stats)
+    _L.check(_L.load().ff_gemm_x3_ln(C.byref(d), planes.data_ptr(), plane_rows, row0, _stream()), "ff_gemm_x3_ln")
+    return (out, stats) if want_stats else out
+
+
+def set_x3_tuning(shape=0):
+    """Launch shape of the 3 x bf16 kernel: 0 the default (whole tiles), 1 whole tiles, 2 equal K-unit ranges."""
+    _L.check(_L.load().ff_set_x3_tuning(int(shape)), "ff_set_x3_tuning")
+
+
+@_on_tensor_device
 def fold_layernorm_linear(weight, bias, gamma, beta, pos=None, pos_cols=0):
     """(Wf, bf, P) of ff_fold_layernorm_linear: LN(x) @ weight.T + bias == z @ Wf.T + bf with z the normalised x;
     P = pos @ weight[:pos_cols].T."""

@@ -12,6 +12,9 @@ from ..transformer import (HipLinear, TransformerDecoder, TransformerDecoderLaye
 from ..utils import min_value_of_dtype
 
 
+X3_MIN_ROWS_DEFAULT = 1024   # package default of SurfaceFormerBase.x3_min_rows (bench.py reports this form beside the f32 headline)
+
+
 class SurfaceFormerBase(nn.Module):
     """Everything SurfaceFormer and SurfaceFormer_Parallel have in common (reference
     models/model.py:14-69 and models/model_para.py:14-70 build identical sub-modules)."""
@@ -57,11 +60,11 @@ class SurfaceFormerBase(nn.Module):
                                        # (the queue never drains: free at every step, tools/run_sync_probe.sh); a decode
                                        # that stops at step s executes s + k ... s + 2k - 1 steps
         self.sharded_sync_every = 2    # ... period of the batch-global rule in dist.decode_sharded (a host all-reduce per check)
-        # Decoder projections of launches with at least this many rows (q|k|v; linear2 from 1.5x, linear1 from 2x, the
-        # E x E ones from 4x as many) run as 3 x bf16 split products on the bf16 matrix cores: fp32-accurate (error
-        # vs fp64 = an fp32 dot product's, tests/test_hip_ops.py) and 1.2-1.5x the f32-MFMA kernel from ~9000 rows
-        # on (config C / E micro-batches; a single 256-edge wireframe reaches that only in its last steps).  0 = off.
-        self.x3_min_rows = 4096
+        # Decoder projections of launches with at least this many rows (q|k|v; linear1 from 7/4 x, the 512-column ones from
+        # 11/4 x as many) run as 3 x bf16 split products on the bf16 matrix cores: fp32-accurate (error vs fp64 = an fp32 dot
+        # product's, tests/test_hip_ops.py), LayerNorm folding included (ff_gemm_x3_ln), and 1.3-1.6x the f32-MFMA kernel
+        # from ~3000 rows on (profiles/r04/gemm_x3_variants.txt).  0 = off.
+        self.x3_min_rows = X3_MIN_ROWS_DEFAULT
         self._engine_obj = None
 
     def _reset_parameters(self):

@@ -154,7 +154,8 @@ int ff_fold_layernorm_linear(const float* W, int ldw, int N, int K, const float*
  * product, so the error is that of an ordinary fp32 dot product (tests compare both with fp64).
  * W is given pre-split: ff_split_weight_bf16x3 writes its three planes once per weight tensor
  * (ff_split_weight_bytes(N, K) bytes; layout [3][K/16][N][16] bf16, i.e. a 16-wide K slice of 32 rows is
- * one contiguous 1 KB block); activations are split inside the kernel.  K % 32 == 0, K >= 64; n_split % 128 == 0.  Keeps an internal 32 MB partial-tile workspace per
+ * one contiguous 1 KB block); activations are split inside the kernel.  K % 32 == 0, K >= 64; n_split % 128 == 0;
+ * N % 4 == 0, ldc / ldr % 4 == 0 and 16-byte aligned A / bias / residual / C.  Keeps an internal 24 MB partial-tile workspace per
  * (device, stream) (ff_gemm_prepare_stream allocates it ahead of time).  Same replaced call sites as ff_gemm_f32;
  * ff_decode uses it for the decoder projections of launches with at least ff_decode_params.x3_min_rows rows. */
 size_t ff_split_weight_bytes(int N, int K);
@@ -162,6 +163,19 @@ int ff_split_weight_bf16x3(const float* W, int ldw, int N, int K, void* planes, 
 int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
                const float* bias, const float* residual, int ldr, float* C, int ldc,
                int M, int N, int K, int act, ff_stream_t stream);
+
+/* The 3 x bf16 product with the neighbouring LayerNorm folded in: the descriptor of ff_gemm_f32_ln (same meaning of
+ * ln_stats_in / row_table / ln_stats_out; reference transformer.py:242-253), the weight given as the planes of the
+ * FOLDED weight (ff_fold_layernorm_linear, then ff_split_weight_bf16x3); desc->W / ldw / tile are ignored.  The planes
+ * describe a [plane_rows, K] weight of which the product uses rows [row0, row0 + N) (plane_rows = 0: exactly N rows).
+ * ln_stats_in needs K = 512 (ln_nseg = 16).  N % 4 == 0, ldc / ldr / ld_row_table % 4 == 0, row_cols % 4 == 0,
+ * 16-byte aligned operands (the kernel moves 16-byte pieces).  ff_decode uses it on the steps that take the 3 x bf16
+ * projections, so that those steps launch no stand-alone LayerNorm either. */
+int ff_gemm_x3_ln(const ff_gemm_ln_desc* desc, const void* w_planes, int plane_rows, int row0, ff_stream_t stream);
+
+/* Launch shape of the 3 x bf16 kernel (process-wide; tests and tools/): 0 = the default (whole tiles), 1 = whole tiles,
+ * 2 = equal K-unit ranges per block (cut tiles exchanged between blocks and summed in block order). */
+int ff_set_x3_tuning(int shape);
 
 /* Launch-shape tuning of the stream-K kernel (process-wide; tests and tools/): a block is never handed
  * fewer than `min_units` K units (of 64); launches with at least `two_per_cu_units` units use 512
@@ -283,6 +297,10 @@ typedef struct ff_layer_weights {
   const float *ln1_w, *ln1_b, *ln1_pos;
   const float *ln2_w, *ln2_b, *ln2_pos;
   const float *ln3_w, *ln3_b;
+  /* optional: ff_split_weight_bf16x3 planes of the FOLDED weights ln1_w [3E,E], ln2_w [E,E], ln3_w [FF,E]: with them (and the
+     planes of the out-proj / linear2 weights above) the steps that take the 3 x bf16 projections keep the LayerNorm folding
+     (ff_gemm_x3_ln) at every size */
+  const void *ln1_planes, *ln2_planes, *ln3_planes;
 } ff_layer_weights;
 
 typedef struct ff_model {

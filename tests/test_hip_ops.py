@@ -201,6 +201,96 @@ def test_gemm_x3_matches_fp64_like_fp32(ops, M, N, K):
     assert torch.equal(x, y)  # deterministic
 
 
+@pytest.fixture(params=[0, 1, 2], ids=lambda p: "shape%d" % p)
+def x3_tuning(request, ops):
+    """Every launch shape of the 3 x bf16 kernel (0 = the cost model's choice, 1 whole tiles, 2 equal K-unit ranges)."""
+    ops.set_x3_tuning(request.param)
+    yield request.param
+    ops.set_x3_tuning(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 512, 512), (77, 1536, 512), (333, 512, 1024), (64, 260, 512), (130, 96, 64),
+                                   (2304, 512, 512), (5000, 1024, 512), (9216, 1536, 512), (4608, 512, 1024)])
+def test_gemm_x3_every_tile_and_launch_shape(ops, x3_tuning, M, N, K):
+    """Whole tiles and equal K-unit ranges (cut tiles exchanged between blocks): same result up to the summation order,
+    deterministic, ragged edges in M and N."""
+    a, w, bias, res = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.1), rnd(N, seed=13), rnd(M, N, seed=14)
+    planes = ops.split_weight(w.cuda())
+    ref = torch.relu(a.double() @ w.double().t() + bias.double()) + res.double()
+    x = res.cuda()
+    ops.linear_x3(a.cuda(), planes, bias.cuda(), act=1, residual=x, out=x)
+    assert rel_err(x, ref) < 3e-6
+    y = res.cuda()
+    ops.linear_x3(a.cuda(), planes, bias.cuda(), act=1, residual=y, out=y)
+    assert torch.equal(x, y)
+    # a padded output (ldc > N) keeps the columns behind N untouched
+    wide = torch.full((M, N + 8), 7.0, device="cuda")
+    ops.linear_x3(a.cuda(), planes, bias.cuda(), out=wide[:, :N])
+    assert torch.equal(wide[:, N:], torch.full((M, 8), 7.0, device="cuda"))
+    assert rel_err(wide[:, :N], a.double() @ w.double().t() + bias.double()) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(37, 512, 512), (300, 512, 1024), (1300, 512, 512), (5000, 512, 512), (640, 128, 256),
+                                   (9216, 512, 1024)])
+def test_gemm_x3_emits_layernorm_segment_statistics(hip_lib, ops, x3_tuning, M, N, K):
+    """ff_gemm_x3_ln, producer side: C = A W^T + b + residual plus (mean, M2) per row and 32-column segment of the stored C."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = (3.0 + 2.0 * torch.randn(M, N, generator=g)).cuda()          # non-zero mean: the cancellation trap
+    out, stats = ops.linear_x3_ln(A, ops.split_weight(W), b, residual=res, want_stats=True)
+    ref = A.double() @ W.double().t() + b.double() + res.double()
+    assert (out.double() - ref).abs().max() < 2e-5 * ref.abs().max()
+    want = _seg_stats(out.double())                                    # statistics of what was actually stored
+    assert not torch.isnan(stats).any()
+    assert (stats[..., 0].double() - want[..., 0]).abs().max() < 1e-5
+    assert ((stats[..., 1].double() - want[..., 1]).abs() / want[..., 1].clamp_min(1e-6)).max() < 1e-5
+
+
+@pytest.mark.parametrize("M,N,div", [(37, 1536, 5), (300, 512, 7), (1300, 1536, 64), (5000, 1024, 256), (9216, 1536, 256),
+                                     (4352, 512, 256)])
+def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, x3_tuning, M, N, div):
+    """ff_gemm_x3_ln, consumer side: act((LN(x) + pos[row // div]) W^T + b) from raw x, its segment statistics, the planes of
+    the folded weight, the folded bias and the pos W^T table -- against the unfused arithmetic in float64."""
+    K = 512
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = (1.5 + 2.0 * torch.randn(M, K, generator=g)) * (1.0 + torch.rand(M, 1, generator=g))   # row-dependent scale / mean
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    npos = (M + div - 1) // div
+    pos = torch.randn(npos, K, generator=g)
+    pos_cols = 1024 if N >= 1536 else (N // 2 if N >= 1024 else N)
+    xd, Wd = x.cuda(), W.cuda()
+    Wf, bf, P = ops.fold_layernorm_linear(Wd, b.cuda(), gamma.cuda(), beta.cuda(), pos.cuda(), pos_cols)
+    stats = _seg_stats(xd.double()).float().contiguous()
+    out = ops.linear_x3_ln(xd, ops.split_weight(Wf), bf, act=1, stats_in=stats, row_table=P, row_div=div, row_cols=pos_cols)
+    x64 = x.double()
+    ln = torch.nn.functional.layer_norm(x64, (K,), gamma.double(), beta.double(), 1e-5)
+    rows = torch.arange(M) // div
+    addp = torch.zeros(M, N, dtype=torch.float64)
+    addp[:, :pos_cols] = pos.double()[rows] @ W.double()[:pos_cols].t()
+    ref = torch.relu(ln @ W.double().t() + b.double() + addp)
+    err = (out.cpu().double() - ref).abs().max()
+    assert err < 3e-5 * max(1.0, ref.abs().max()), err
+    # the f32 family's folded form on the same operands: the two must agree like two fp32 evaluations
+    out32 = ops.linear_ln(xd, Wf, bf, act=1, stats_in=stats, row_table=P, row_div=div, row_cols=pos_cols)
+    assert (out - out32).abs().max() < 3e-5 * max(1.0, ref.abs().max())
+
+
+def test_gemm_x3_ln_argument_validation(hip_lib, ops):
+    from faceformer_amd.hip import lib as L
+    x = torch.randn(64, 256).cuda()
+    planes = ops.split_weight(torch.randn(512, 256).cuda())
+    with pytest.raises(L.HipExtensionError):       # the normalising form is built for K = 512
+        ops.linear_x3_ln(x, planes, stats_in=torch.zeros(64, 8, 2).cuda())
+    with pytest.raises(L.HipExtensionError):       # a row table needs statistics
+        ops.linear_x3_ln(x, planes, row_table=torch.zeros(4, 512).cuda(), row_div=16, row_cols=512)
+    with pytest.raises(L.HipExtensionError):
+        ops.set_x3_tuning(3)
+
+
 def test_gemm_x3_split_a(ops):
     M, E = 300, 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)

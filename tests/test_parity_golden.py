@@ -155,8 +155,9 @@ def test_golden_parity_on_the_f32_matrix_cores_only(hip_lib, name):
 @pytest.mark.parametrize("min_rows", [1, 300])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
-    """The same bars with q|k|v, linear1 and linear2 of the decoder evaluated as 3 x bf16 split products on
-    the bf16 matrix cores (every step: min_rows=1; only the longer prefixes: 300)."""
+    """The same bars with the decoder projections evaluated as 3 x bf16 split products on the bf16 matrix cores (every step:
+    min_rows=1; only the longer prefixes: 300) -- with the LayerNorms folded into them (ff_gemm_x3_ln: the E = 512 goldens)
+    and, second pass, with standalone LayerNorm launches in front of the plain split products."""
     case, z = load_golden(name)
     sd, batch = case_weights_and_batch(case)
     model = build_model(case, sd, "cuda")
@@ -165,6 +166,10 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
     stats = compare_with_golden(case, z, out)
     print(name, min_rows, stats)
     _record_margin(name, "bf16x3 from %d rows" % min_rows, stats)
+    from faceformer_amd.hip import lib as L
+    model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
+    stats = compare_with_golden(case, z, run_traced(model, case, batch_to(batch, "cuda")))
+    _record_margin(name, "bf16x3 from %d rows, standalone LN" % min_rows, stats)
 
 
 @pytest.mark.parametrize("chain_rows", [0, 64, 1 << 20])

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--ts", default="1,2,4,8,12,16,24,36")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--tiles", default="3,7,8")
+    ap.add_argument("--x3-variants", action="store_true",
+                    help="time both launch shapes of the 3 x bf16 kernel next to the cost model's choice")
     ap.add_argument("--data", default="randn", choices=["randn", "zeros", "ones"],
                     help="operand values (the chip clocks to its power budget: zeros show the issue-bound rate)")
     args = ap.parse_args()
@@ -60,9 +62,18 @@ def main():
             planes = ops.split_weight(w)
             dt3 = timeit(lambda: ops.linear_x3(a, planes, b, act=act, residual=resid, out=out), iters)
             out.normal_()
+            var = ""
+            if args.x3_variants:
+                vs = []
+                for shp in (1, 2):
+                    ops.set_x3_tuning(shp)
+                    vs.append(flops / timeit(lambda: ops.linear_x3(a, planes, b, act=act, residual=resid, out=out), iters) / 1e12)
+                    out.normal_()
+                ops.set_x3_tuning(0)
+                var = " [whole %5.1f ranges %5.1f]" % tuple(vs)
             dt = timeit(lambda: torch.addmm(b, a, w.t(), out=out), iters)
-            print("%8d %5d %5d | %s | x3 %6.1f | %8.1f" % (M, K, N, " ".join("%10.1f" % r for r in res),
-                                                         flops / dt3 / 1e12, flops / dt / 1e12))
+            print("%8d %5d %5d | %s | x3 %6.1f%s | %8.1f" % (M, K, N, " ".join("%10.1f" % r for r in res),
+                                                           flops / dt3 / 1e12, var, flops / dt / 1e12))
 
 
 if __name__ == "__main__":
