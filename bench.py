@@ -49,7 +49,9 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 E_SIZES, E_PROBS, E_SEED = (64, 128, 256, 512, 1024), (.3, .3, .2, .1, .1), 2024
-CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops", "chain_launches"]
+CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops", "chain_launches",
+             "gemm_bf16x3_kernel"]
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense; the split product spends 6 of them per fp32 product
 
 
 def alg_flops_per_wireframe(n, T, E=512, FF=1024, layers=6, in_dim=100, F=None):
@@ -156,6 +158,31 @@ def gemm_roofline(prof, wall_ms, empty_us, traffic=None, traffic_src=None):
     if net[1] > 0:
         extra["attention_tflops"] = work[1] / (net[1] * 1e-3) / 1e12
     return roof, extra
+
+
+def x3_roofline(prof, wall_ms):
+    """`roofline` of the 3 x bf16 split projection kernel (the package default's dominant kernel) from one profiled pass:
+    algorithmic fp32 flops (2MNK) of its launches / their summed duration net of the event bracket, against the bf16 matrix
+    peak divided by the six bf16 products an fp32 product costs."""
+    ms, work, cnt, alg_bytes = prof
+    nl = max(1, sum(cnt))
+    bracket_us = max(0.0, (sum(ms) - wall_ms) / nl * 1e3)
+    net = [max(0.0, ms[i] - cnt[i] * bracket_us * 1e-3) for i in range(len(ms))]
+    i3 = CAT_NAMES.index("gemm_bf16x3_kernel")
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    ach = work[i3] / (net[i3] * 1e-3) / 1e12 if net[i3] > 0 else 0.0
+    return {
+        "kernel": "gemm_x3_kernel (ff_gemm_x3.hip): fp32-accurate product as six bf16 MFMA partial products per K slice",
+        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
+        "traffic": None, "alg_bytes_per_launch": alg_bytes[i3] / max(1, cnt[i3]), "launches_per_step": cnt[i3],
+        "avg_launch_us": 1e3 * net[i3] / max(1, cnt[i3]), "alg_flop_per_launch": work[i3] / max(1, cnt[i3]),
+        "share_of_kernel_time": net[i3] / sum(net) if sum(net) > 0 else None,
+        "event_bracket_us_per_launch": bracket_us,
+        "kernel_time_ms_per_step": {CAT_NAMES[i]: net[i] for i in range(len(ms))},
+        "kernel_launches_per_step": {CAT_NAMES[i]: cnt[i] for i in range(len(ms))},
+        "note": "peak = 2500 TF/s dense bf16 / 6 partial products; the loop is POWER-limited on this chip: the same binary reaches "
+                "245-272 TF/s-equivalent on zero-filled operands and 170-200 on random ones (profiles/r04/x3v2_*.txt)",
+    }
 
 
 def path_roofline(falg, sec_per_step):
@@ -512,6 +539,12 @@ def main():
         # second line: the package default (large decoder projections as fp32-accurate 3 x bf16 products)
         model.x3_min_rows = X3_MIN_ROWS_DEFAULT
         dt3, _ = timed(step, fence, max(1, args.warmup), args.steps)
+        roof3 = None
+        if rank == 0 and not args.no_roofline:
+            def once3():
+                with torch.no_grad():
+                    model(dict(batch))
+            roof3 = x3_roofline(profile_once(lib, L, once3), 1e3 * dt3 / args.steps)
         model.x3_min_rows = 0
         step()      # (re-binds the engine without the bf16 planes for the profiling leg below)
         fence()
@@ -520,7 +553,10 @@ def main():
             "x3_min_rows": X3_MIN_ROWS_DEFAULT,
             "note": "package default: decoder projections of launches with >= %d rows (q|k|v; linear1 from 7/4 x, the 512-column "
                     "ones from 11/4 x that) as 3 x bf16 split products on the bf16 matrix cores with the LayerNorms folded in "
-                    "(ff_gemm_x3_ln), fp32-accurate; NOT the headline" % X3_MIN_ROWS_DEFAULT}
+                    "(ff_gemm_x3_ln), fp32-accurate; NOT the headline" % X3_MIN_ROWS_DEFAULT,
+            "path_roofline": path_roofline(falg, dt3 / args.steps)}
+        if roof3 is not None:
+            result["bf16x3_projections"]["roofline"] = roof3
 
     if rank == 0 and not args.no_roofline:
         def once():
@@ -565,8 +601,11 @@ def main():
             if not args.no_x3_line:
                 m2.x3_min_rows = X3_MIN_ROWS_DEFAULT
                 d3, _ = timed(st, fence, 1, K2)
+                r3 = x3_roofline(profile_once(lib, L, st), 1e3 * d3 / K2) if not args.no_roofline else None
                 m2.x3_min_rows = 0
                 ent["bf16x3_projections"] = {"value": sum(n2) * sd2 * K2 / d3, "unit": "edges/s", "ms_per_step": 1e3 * d3 / K2,
+                                             "ms_per_wireframe": 1e3 * d3 / K2 / len(n2), "roofline": r3,
+                                             "path_roofline": path_roofline(sum(alg_flops_per_wireframe(n, T2) for n in n2), d3 / K2),
                                              "note": "package default (x3_min_rows = %d), fp32-accurate; not the headline form" % X3_MIN_ROWS_DEFAULT}
             other[name] = ent
 

@@ -326,7 +326,7 @@ struct RkState {
   f32x16 o0, o1;
 };
 
-__global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles) {
+__global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles, int w_old, int w_young) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Ks = lds;                       // [key][64], 16-byte chunks XOR-swizzled with (key & 15)
   float* const Vs = lds + RK_KEYS * 64;        // [key][64]
@@ -373,8 +373,19 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
     const int ntiles = vtail ? ntiles_all - 1 : ntiles_all;   // MFMA key tiles = work items per query tile
     const int nq_blk = rank < q_tiles ? (q_tiles - rank + c - 1) / c : 0;
     // ---- this wave's item range ----
+    // Uneven shares: a SIMD issues its older wave (0..3) first, the younger one (4..7) fills the gaps and then runs its last
+    // items alone (phase probe, profiles/r03/attn_phase_probe.txt: 76 k vs 101-107 k cycles with equal shares), so the older
+    // waves take w_old parts and the younger ones w_young parts of every SIMD's items.
     const int I = nq_blk * ntiles;
-    const int ia = (wave * I) / RK_NW, ib = ((wave + 1) * I) / RK_NW;
+    const int wsum = 4 * (w_old + w_young);
+    // range_of(w): first and one-past-last item of wave w (ascending with the wave index: the merge below relies on it)
+    auto range_of = [&](int w, int& a, int& b) {
+      const int pre0 = w < 4 ? w * w_old : 4 * w_old + (w - 4) * w_young;
+      const int pre1 = pre0 + (w < 4 ? w_old : w_young);
+      a = (int)(((long)pre0 * I) / wsum); b = (int)(((long)pre1 * I) / wsum);
+    };
+    int ia, ib;
+    range_of(wave, ia, ib);
     auto query_row = [&](int qt, bool& valid) -> size_t {
       const int qi = qt * 32 + l32;
       valid = qi < d.nq;
@@ -565,7 +576,8 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
       const int kend = (last_k + 1) * ntiles;
       float m_star = cur.m;
       for (int w2 = wave + 1; w2 < RK_NW; ++w2) {
-        const int a2 = (w2 * I) / RK_NW, b2 = ((w2 + 1) * I) / RK_NW;
+        int a2, b2;
+        range_of(w2, a2, b2);
         if (a2 >= kend) break;
         if (b2 == a2) continue;
         const float* rec = lds + (w2 * 2 + (b2 > kend ? 0 : 1)) * RK_REC;
@@ -577,7 +589,8 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
 #pragma unroll
       for (int e = 0; e < 16; ++e) { cur.o0[e] *= sc0; cur.o1[e] *= sc0; }
       for (int w2 = wave + 1; w2 < RK_NW; ++w2) {
-        const int a2 = (w2 * I) / RK_NW, b2 = ((w2 + 1) * I) / RK_NW;
+        int a2, b2;
+        range_of(w2, a2, b2);
         if (a2 >= kend) break;
         if (b2 == a2) continue;
         const float* rec = lds + (w2 * 2 + (b2 > kend ? 0 : 1)) * RK_REC;
@@ -656,7 +669,10 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     if (c > qt32) c = qt32;
     if (c < 1) c = 1;
     const int nblocks = P <= 256 ? P * c : 256;
-    hipLaunchKernelGGL(attention_resident_kernel, dim3(nblocks), dim3(64 * RK_NW), lds_bytes, st, d, P, c, qt32);
+    static const int w_old = getenv("FF_RK_SPLIT_OLD") ? atoi(getenv("FF_RK_SPLIT_OLD")) : 1;      // (probe knobs: tools/run_r04_attn.sh)
+    static const int w_young = getenv("FF_RK_SPLIT_YOUNG") ? atoi(getenv("FF_RK_SPLIT_YOUNG")) : 1;
+    hipLaunchKernelGGL(attention_resident_kernel, dim3(nblocks), dim3(64 * RK_NW), lds_bytes, st, d, P, c, qt32,
+                       w_old > 0 ? w_old : 1, w_young > 0 ? w_young : 1);
     FF_CHECK_LAUNCH();
     return FF_OK;
   }

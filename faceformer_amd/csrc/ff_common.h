@@ -48,7 +48,7 @@ static inline size_t ff_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 // ---- optional per-category event profiling (bench.py's roofline leg) ---------------------------
 // When enabled via ff_profile_begin(), every op launch is bracketed by a hipEvent pair on its own
 // stream; ff_profile_end() synchronises and sums elapsed time / algorithmic work per category.
-enum ff_prof_cat { FF_CAT_GEMM = 0, FF_CAT_ATTN = 1, FF_CAT_LN = 2, FF_CAT_POINTER = 3, FF_CAT_ROWOP = 4, FF_CAT_CHAIN = 5, FF_NUM_CAT = 6 };
+enum ff_prof_cat { FF_CAT_GEMM = 0, FF_CAT_ATTN = 1, FF_CAT_LN = 2, FF_CAT_POINTER = 3, FF_CAT_ROWOP = 4, FF_CAT_CHAIN = 5, FF_CAT_GEMM_X3 = 6, FF_NUM_CAT = 7 };
 bool ff_prof_enabled();
 void ff_prof_open(int cat, double work, hipStream_t st);
 void ff_prof_close(hipStream_t st);

@@ -682,6 +682,11 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_CHECK_ARG(p->variant != FF_PARALLEL || num_input, "ff_decode: num_input required for the parallel variant");
   FF_CHECK_ARG(p->variant != FF_SEQ2SEQ || p->F == 1, "ff_decode: seq2seq decodes one sequence per wireframe");
   FF_CHECK_ARG(!p->stop_fn || (p->flags & FF_NO_STOP) || p->sync_every > 0, "ff_decode: stop_fn needs sync_every > 0");
+  // The callback's cadence is a CONTRACT with callers that replay it elsewhere (an idle rank of a sharded decode joins the
+  // same host collectives: faceformer_amd/dist.py check_points): the counters of the first n = enq - sync_every steps when
+  // enq = 2 sync_every, 3 sync_every, ... steps are enqueued.  Only the lag-free path below has that cadence.
+  FF_CHECK_ARG(!p->stop_fn || (p->flags & FF_NO_STOP) || p->T <= 8192,
+               "ff_decode: stop_fn needs T <= 8192 (the lag-free counter copies; longer decodes check without a lag)");
   const int E = m->E, S = p->L + m->num_token, T = p->T, F = p->F, N = p->N;
   FF_CHECK_ARG(S <= m->pos_len, "ff_decode: S=%d exceeds the position table (%d rows)", S, m->pos_len);
   FF_CHECK_ARG(T - 1 <= m->qpos_len, "ff_decode: T-1=%d exceeds the query position table (%d rows)", T - 1, m->qpos_len);
@@ -740,13 +745,18 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   int enq = 0;
   StepGraphs* graphs = nullptr;
   // steps per graph: the stop rule is looked at between graphs only (a graph launch costs the host ~55 us)
-  const int graph_steps = getenv("FF_GRAPH_STEPS") && atoi(getenv("FF_GRAPH_STEPS")) > 0 ? atoi(getenv("FF_GRAPH_STEPS"))
-                          : (p->sync_every > 0 && !(p->flags & FF_NO_STOP) ? p->sync_every : T);
+  const int graph_steps = getenv("FF_GRAPH_STEPS") && atoi(getenv("FF_GRAPH_STEPS")) > 0 && !p->stop_fn   // (stop_fn: its cadence)
+                              ? atoi(getenv("FF_GRAPH_STEPS"))
+                              : (p->sync_every > 0 && !(p->flags & FF_NO_STOP) ? p->sync_every : T);
   if (use_graph) {
     int dev = 0;
     FF_CHECK_HIP(hipGetDevice(&dev));
     std::string key;
-    key_add(key, *m); key_add(key, prm_local);
+    {   // the host callback is not part of what a captured step does: a caller that passes a fresh thunk per call must still hit
+      ff_decode_params kp = prm_local;
+      kp.stop_fn = nullptr; kp.stop_user = nullptr;
+      key_add(key, *m); key_add(key, kp);
+    }
     const void* ptrs[] = {memory, mask, kv_len, num_input, extra_mask, trace_logits, trace_best, trace_second, workspace, (const void*)sts[0]};
     key_add(key, ptrs); key_add(key, workspace_bytes); key_add(key, ff_tuning_epoch()); key_add(key, graph_steps);
     for (const Chunk& c : chunks) {   // (field by field: the struct has padding bytes)

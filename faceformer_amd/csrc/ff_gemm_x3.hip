@@ -706,8 +706,8 @@ int x3_launch(X3Args g, int mode, hipStream_t st) {
     g.rem = (int)(units % grid);
   }
   FF_RETURN_IF(x3_acquire(st, &g));
-  FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K, st);
-  ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (g.res ? 2 : 1)));
+  FFProfScope prof(FF_CAT_GEMM_X3, 2.0 * M * N * K, st);
+  ff_prof_add_bytes(FF_CAT_GEMM_X3, 4.0 * (double)M * K + 6.0 * (double)N * K + 4.0 * (double)M * N * (g.res ? 2 : 1));
   if (mode == 1) return x3_launch_mode<BM, 1>(g, (int)grid, st);
   if (mode == 2) return x3_launch_mode<BM, 2>(g, (int)grid, st);
   return x3_launch_mode<BM, 0>(g, (int)grid, st);

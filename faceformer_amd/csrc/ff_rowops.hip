@@ -39,7 +39,7 @@ struct Profiler {
   std::vector<hipEvent_t> pool;
   size_t next = 0;
   std::vector<ProfRec> recs;
-  double bytes[FF_NUM_CAT] = {0, 0, 0, 0, 0, 0};  // algorithmic operand + result bytes per category
+  double bytes[FF_NUM_CAT] = {};  // algorithmic operand + result bytes per category
   hipEvent_t get() {
     if (next == pool.size()) {
       hipEvent_t e;

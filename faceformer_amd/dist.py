@@ -111,7 +111,13 @@ _CONTROL_GROUPS = {}
 def _control_group(dist_mod, group):
     """A process group whose collectives take HOST tensors (the periodic stop check sums a few integers per rank; it must not
     queue behind the decode steps on the device stream the way an RCCL collective would).  The group itself when its backend
-    is gloo, otherwise a gloo twin of it, created once (collectively: every rank reaches its first sharded decode)."""
+    is gloo, otherwise a gloo twin of it, created once.
+
+    Who has to call: `new_group` over the DEFAULT group is collective over every process, which holds whenever decode_sharded
+    runs on the default group (every rank decodes).  For a strict SUB-group only its members reach this point, so the twin is
+    made with `use_local_synchronization=True` (members only; torch >= 2.1) -- where that is not available the caller gets a
+    RuntimeError here and decode_sharded falls back to applying the stop rule after the decode.  A caller may also hand its
+    own host-side group to decode_sharded(control_group=...)."""
     if dist_mod.get_backend(group) == "gloo":
         return group
     # keyed by the group OBJECT (the default group's when `group` is None: it changes when the process group is re-initialised)
@@ -119,9 +125,24 @@ def _control_group(dist_mod, group):
     if key in _CONTROL_GROUPS and _CONTROL_GROUPS[key] is None:
         raise RuntimeError("not available (failed before)")
     if key not in _CONTROL_GROUPS:
-        ranks = None if group is None else dist_mod.get_process_group_ranks(group)
-        _CONTROL_GROUPS[key] = dist_mod.new_group(ranks=ranks, backend="gloo")
+        import datetime
+        world_group = getattr(getattr(dist_mod, "group", None), "WORLD", None)
+        whole_world = group is None or group is world_group or \
+            dist_mod.get_world_size(group) == dist_mod.get_world_size()
+        kw = {"backend": "gloo", "timeout": datetime.timedelta(seconds=CONTROL_TIMEOUT_S)}
+        if whole_world:
+            _CONTROL_GROUPS[key] = dist_mod.new_group(ranks=None, **kw)
+        else:
+            ranks = dist_mod.get_process_group_ranks(group)
+            try:
+                _CONTROL_GROUPS[key] = dist_mod.new_group(ranks=ranks, use_local_synchronization=True, **kw)
+            except TypeError as e:    # a torch without member-only group creation: do not risk a hang in new_group
+                raise RuntimeError("sub-group control twin needs torch.distributed.new_group(use_local_synchronization=True): %s" % e)
     return _CONTROL_GROUPS[key]
+
+
+# a rank that fails inside a stop check must not leave its peers blocked for torch's default 30 minutes
+CONTROL_TIMEOUT_S = 120
 
 
 def check_points(T, sync_every):
@@ -158,7 +179,7 @@ def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callbac
     return pred, out["step_counts"]
 
 
-def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
+def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False, control_group=None):
     """Decode a batch across the ranks of `group`; returns `inputs` with 'predict' [N, F, T] (parallel) /
     [N, T] (seq2seq) for the WHOLE batch on every rank, identical to a single-process
     `model(inputs)['predict']` of that batch.
@@ -166,7 +187,9 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
     local_shard=False: `inputs` is the full batch (same dict on every rank); every rank decodes the
         wireframes `shard_plan` gives it and only those slices are touched on the device.
     local_shard=True : `inputs` holds only this rank's wireframes (any number, also zero rows); the batch is
-        their concatenation in rank order.  Also returns inputs['shard_sizes'] (wireframes per rank)."""
+        their concatenation in rank order.  Also returns inputs['shard_sizes'] (wireframes per rank).
+    control_group: a host-side (gloo) process group over the same ranks for the in-decode stop checks; None = the twin that
+        `_control_group` makes (collective over the ranks of `group`: EVERY rank of `group` must call decode_sharded)."""
     from .models import SurfaceFormer_Parallel
     rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
     parallel = isinstance(model, SurfaceFormer_Parallel)
@@ -211,7 +234,9 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
     sync_every = int(getattr(model, "sharded_sync_every", getattr(model, "sync_every", 0)))   # 0: rule applied after the decode
     checks = sync_every > 0 and world > 1 and bool(check_points(T, sync_every))
     ctrl = None   # (None is also a valid handle: the default group)
-    if checks:
+    if checks and control_group is not None:
+        ctrl = control_group
+    elif checks:
         try:
             ctrl = _control_group(dist_mod, group)
         except (RuntimeError, ValueError) as e:   # no host-side backend in this build of torch.distributed: every rank
@@ -221,8 +246,9 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False):
             checks = False
 
     def global_stop(my_counts):
-        tot = torch.zeros(max(T - 1, 1), dtype=torch.int64)
-        tot[: len(my_counts)] = torch.tensor(my_counts, dtype=torch.int64)
+        # the counted prefix only: every rank is at the same check point, so the lengths agree.  (A rank that fails here
+        # leaves the decode; its peers' all-reduce then ends with the control group's timeout, CONTROL_TIMEOUT_S.)
+        tot = torch.tensor(list(my_counts) or [0], dtype=torch.int64)
         dist_mod.all_reduce(tot, group=ctrl)
         return stop_step(tot[: len(my_counts)].tolist(), N, variant) is not None
 

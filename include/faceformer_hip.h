@@ -47,12 +47,12 @@ int ff_device_count(void);
 
 /* Measurement hooks (bench.py roofline leg; not on the product path).  Between begin and end every
  * op launch of this library is bracketed by a hipEvent pair on its stream; end() synchronises the
- * device and returns, per category (0 gemm, 1 attention, 2 layernorm, 3 pointer, 4 other row ops),
- * the summed kernel time [ms], algorithmic work (flops for 0/1/3, bytes for 2/4) and launches. */
+ * device and returns, per category (0 f32 gemm, 1 attention, 2 layernorm, 3 pointer, 4 other row ops, 5 chain launches,
+ * 6 the 3 x bf16 split gemm), the summed kernel time [ms], algorithmic work (flops for 0/1/3/6, bytes for 2/4) and launches. */
 int ff_profile_begin(void);
 int ff_profile_end(double* ms_by_cat, double* work_by_cat, long long* launches_by_cat, int ncat);
 /* Algorithmic bytes (operands read once + results written once) summed per category since the last
- * ff_profile_begin (only the GEMM category is filled in). */
+ * ff_profile_begin (only the two GEMM categories are filled in). */
 int ff_profile_bytes(double* bytes_by_cat, int ncat);
 /* Mean event-pair interval [us] around an EMPTY kernel, `launches` of them queued back to back on `stream`: what the
  * event bracket adds per launch to the category times of ff_profile_end (bench.py reports times net of it). */

@@ -1,0 +1,46 @@
+"""CPU: bench.py's launch contract -- `--gpus N` is what runs, or nothing does (missing #1)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_dry_spawn_builds_a_two_rank_group_and_plans_the_shards():
+    """`bench.py --gpus 2 --dry-spawn` re-executes itself through torch.distributed.run with two ranks on 127.0.0.1, builds a gloo
+    group and agrees the shard sizes with the collectives of decode_sharded(local_shard=True): config 3's 128 wireframes per rank."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-spawn"], cwd=ROOT, env=_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dry_spawn"] is True and d["n_gpus"] == 2 and d["ranks_in_group"] == 2 and d["backend"] == "gloo"
+    assert d["shard_sizes"] == [128, 128] and d["global_batch"] == 256 and d["global_F"] == 256
+
+
+def test_gpus_n_without_n_devices_fails_loudly_instead_of_running_one_gpu():
+    """No launcher, `--gpus 2`, fewer than two devices visible (this container has none; the one-GPU box has one): non-zero exit
+    and NO JSON line -- never `n_gpus: 1` for a `--gpus 2` request."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two devices are visible here: the request would be honoured")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus 2" in p.stderr
+
+
+def test_world_size_that_disagrees_with_gpus_is_refused():
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-spawn"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)

@@ -490,8 +490,9 @@ def test_fresh_inputs_against_oracle(hip_lib, name, x3_min_rows):
     assert (pred[:, steps + 1:] == 0).all()
 
 
+@pytest.mark.parametrize("period", [1, 2, 4])
 @pytest.mark.parametrize("name", ["par_small_earlybreak", "par_small_break1", "par_small_ragged", "seq_small_eos", "seq_small_gain4"])
-def test_external_stop_rule_through_the_c_callback(hip_lib, name):
+def test_external_stop_rule_through_the_c_callback(hip_lib, name, period):
     """ff_decode_params.stop_fn: the engine hands the per-step counters to the caller's rule every sync_every steps (one period
     behind the enqueued steps) and ends the decode when it says so; `predict` keeps every executed step.  With the reference's
     own rule in the callback the result -- after the caller's zero-padding -- must be the golden tensor, the decode must end at
@@ -511,14 +512,20 @@ def test_external_stop_rule_through_the_c_callback(hip_lib, name):
     def rule(counts):
         seen.append(len(counts))
         return stop_step(counts, N, variant) is not None
-    kw = dict(T=T, extra_mask=model._extra_mask(b), flags=model.decode_flags, sync_every=1, stop_callback=rule)
+    kw = dict(T=T, extra_mask=model._extra_mask(b), flags=model.decode_flags, sync_every=period, stop_callback=rule)
     if parallel:
         ni = [int(n) for n in b["num_input"]]
         out = eng.decode(memory, mask, kv_len, variant, F=max(ni), num_input=ni, **kw)
     else:
         out = eng.decode(memory, mask, kv_len, variant, F=1, tok_sos=model.token.SOS, tok_eos=model.token.EOS, **kw)
-    assert seen == [n for _e, n in check_points(T, 1)][: len(seen)] and len(out["step_counts"]) == out["steps"]
-    assert steps <= out["steps"] <= min(T - 1, max(steps + 2, 2))
+    # the engine's check points ARE dist.check_points (idle ranks of a sharded decode replay them: one host collective each);
+    # the decode ends with the check that saw the reference's stop step, i.e. at most two periods later -- also for periods
+    # that do not divide T - 1 and for the sharded default, 2
+    cps = check_points(T, period)
+    assert seen == [n for _e, n in cps][: len(seen)] and len(out["step_counts"]) == out["steps"]
+    if len(seen) < len(cps) or (seen and stop_step(out["step_counts"][: seen[-1]], N, variant) is not None):
+        assert out["steps"] == cps[len(seen) - 1][0]       # stopped by the last check: executed = enqueued at that check
+    assert steps <= out["steps"] <= min(T - 1, max(steps + 2 * period, 2 * period))
     pred, stop = apply_global_stop(out["predict"].clone(), out["step_counts"], N, variant)
     assert stop == steps
     assert np.array_equal(pred.cpu().numpy().reshape(z["predict"].shape), z["predict"])
@@ -594,6 +601,10 @@ def test_cli_decode_writes_reference_json(hip_lib, tmp_path):
     ckpt = tmp_path / "last.ckpt"
     torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "hyper_parameters": dict(cfg)}, ckpt)
     out_dir = cli.run_test(cfg, str(ckpt), out_dir=str(tmp_path / "out"))
+    # --batch-size 2: both samples in ONE model(batch) call (batch-wide F and stop step) -> byte-identical records
+    out_b2 = cli.run_test(cfg, str(ckpt), out_dir=str(tmp_path / "out_b2"), batch_size=2)
+    for fn in sorted(os.listdir(out_dir)):
+        assert open(os.path.join(out_dir, fn), "rb").read() == open(os.path.join(out_b2, fn), "rb").read()
     from faceformer_amd import datasets as D
     ds = D.ABCDataset_Parallel(str(root), ["test.txt"], cfg.model)
     for i in range(2):
