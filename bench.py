@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--no-x3-line", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C128 / E32 / D / A lines of the N = 1 run")
     ap.add_argument("--other-steps", type=int, default=2, help="timed passes of each `other_configs` entry")
-    ap.add_argument("--other-list", default="C128,E32,D,A", help="which `other_configs` entries to measure")
+    ap.add_argument("--other-list", default="C128,E32,D,A,D64,A64", help="which `other_configs` entries to measure")
     ap.add_argument("--chain", type=int, default=-1,
                     help="chain launches (FF_CHAIN): 1 on, 0 off, -1 the package default")
     ap.add_argument("--chain-max-rows", type=int, default=0, help="FF_CHAIN row limit of a whole-step chain (0: 1024)")
@@ -675,6 +675,35 @@ def main():
                 ent.update(ex)
                 ent["launches_per_decode_step"] = sum(ex["kernel_launches_per_step"].values()) / max(1, sd1)
             other[name] = ent
+            # The throughput form of the same configuration: 64 wireframes per call (the reference's forward_eval takes a batch;
+            # its stop rule waits for EVERY wireframe's EOS).  A one-wireframe decode is 53 dependent launches per step at the
+            # ~7 us floor of a dependent one-tile launch (accepted); 64 sequences per step fill the same launches.
+            if (name + "64") in want:
+                b64 = make_wireframes([n1] * 64, L1, T1, "seq2seq", seeds=list(range(wfseed, wfseed + 64)))
+                if mask_seed is not None:
+                    b64["extra_mask"] = make_extra_mask(dict(kind="seq2seq", extra_mask_seed=mask_seed), b64)
+                b64 = to_dev(b64)
+
+                def st64():
+                    with torch.no_grad():
+                        return m1(dict(b64))["predict"]
+                d64, p64 = timed(st64, fence, 1, K1)
+                sd64 = steps_executed(p64)
+                sec64 = d64 / K1
+                fa64 = 64 * alg_flops_per_wireframe(n1, T1, F=1)
+                e64 = {"workload": what + " -- 64 such wireframes (seeds %d..%d) in ONE call" % (wfseed, wfseed + 63),
+                       "value": 64 * sd64 / sec64, "unit": "edges/s", "ms_per_step": 1e3 * sec64, "ms_per_wireframe": 1e3 * sec64 / 64,
+                       "steps": K1, "warmup": 1, "decode_steps": sd64, "dtype": "f32", "path_roofline": path_roofline(fa64, sec64),
+                       "bounds": {"mfma": {"alg_tflop": fa64 / 1e12, "bound_ms": 1e3 * fa64 / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                                           "frac": fa64 / (PEAK_F32_MFMA_TFLOPS * 1e12) / sec64},
+                                  "weight_stream": {"bytes": sd64 * wbytes, "bound_ms": 1e3 * sd64 * wbytes / (PEAK_HBM_TBS * 1e12),
+                                                    "frac": sd64 * wbytes / (PEAK_HBM_TBS * 1e12) / sec64}}}
+                if not args.no_roofline:
+                    roof, ex = gemm_roofline(profile_once(lib, L, st64), 1e3 * sec64, bracket_us)
+                    e64["roofline"] = roof
+                    e64.update(ex)
+                other[name + "64"] = e64
+                del b64
             del m1, b1
         result["other_configs"] = other
 

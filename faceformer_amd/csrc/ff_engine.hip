@@ -311,7 +311,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   // `planes` (optional): the bf16 planes of the [plane_rows, K] weight whose rows [row0, row0 + N) are W
   auto gemm_ln = [&](const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                      float* C, int ldc, int M, int N, int K, int act, const float* st_in, const float* table, int ldt,
-                     int tcols, float* st_out, const void* planes = nullptr, int plane_rows = 0, int row0 = 0) -> int {
+                     int tcols, float* st_out, const void* planes = nullptr, int plane_rows = 0, int row0 = 0,
+                     const float* colsum = nullptr) -> int {
     ff_gemm_ln_desc d;
     memset(&d, 0, sizeof(d));
     d.A = A; d.lda = lda; d.W = W; d.ldw = ldw; d.bias = bias; d.residual = res; d.ldr = ldr; d.C = C; d.ldc = ldc;
@@ -321,7 +322,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     d.ln_stats_out = st_out;
     if (planes && x3_wins(prm, M, N, K) && (!st_in || K == 512) && (!table || (tcols & 3) == 0) && !ff_chain_recording() &&
         !ff_flow_recording())
-      return ff_gemm_x3_ln(&d, planes, plane_rows, row0, st);
+      return ff_gemm_x3_ln(&d, planes, plane_rows, row0, st_in ? colsum : nullptr, st);
     return ff_gemm_f32_ln(&d, st);
   };
 
@@ -331,9 +332,9 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     const ff_layer_weights& w2 = m->dec[l2];
     if (prune_last && l2 == nd - 1 && t > 1)
       return gemm_ln(buf.x, E, w2.ln1_w + (size_t)E * E, E, w2.ln1_b + E, nullptr, 0, buf.qkv + E, 3 * E, R, 2 * E, E, 0,
-                     buf.lnstat, w2.ln1_pos + E, 2 * E, E, nullptr, w2.ln1_planes, 3 * E, E);
+                     buf.lnstat, w2.ln1_pos + E, 2 * E, E, nullptr, w2.ln1_planes, 3 * E, E, w2.ln1_csum);
     return gemm_ln(buf.x, E, w2.ln1_w, E, w2.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat, w2.ln1_pos, 2 * E,
-                   2 * E, nullptr, w2.ln1_planes, 3 * E, 0);
+                   2 * E, nullptr, w2.ln1_planes, 3 * E, 0, w2.ln1_csum);
   };
   // runs `ops` (a few dependent projections) as ONE flow launch when possible, operator by operator otherwise
   auto flow_or_launch = [&](bool want_flow, auto&& ops) -> int {
@@ -417,7 +418,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
                              buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.self_out_planes, E, 0));
         // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
         return gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
-                       w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr, w.ln2_planes, E, 0);
+                       w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr, w.ln2_planes, E, 0, w.ln2_csum);
       }));
     } else {
       FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
@@ -457,7 +458,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
                              buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.cross_out_planes, E, 0));
         // ---- feed forward (transformer.py:253-255) ----
         FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln3_w, E, w.ln3_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl, FFd, E, 1,
-                             stat, nullptr, 0, 0, nullptr, w.ln3_planes, FFd, 0));
+                             stat, nullptr, 0, 0, nullptr, w.ln3_planes, FFd, 0, w.ln3_csum));
         FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
                              Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat, w.lin2_planes, E, 0));
         return with_next ? first_proj(l + 1) : FF_OK;

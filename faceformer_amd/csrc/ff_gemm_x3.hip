@@ -61,6 +61,9 @@ struct X3Args {
   long long plane_stride;  // elements between two planes of Wp
   int w_rows, w_row0;      // the planes describe a [w_rows, K] weight; the product uses rows [w_row0, w_row0 + N)
   int bal;                 // whole tiles: the blocks that get one tile more are dealt out over the XCDs and CUs
+  // hybrid launch (hyb = 1): hw whole tiles per CU on `ha` of its block slots + the remaining tiles cut into hs K-pieces
+  // each, one piece per CU on a further slot; cus = CUs the plan was made for, nA = blocks that run whole tiles
+  int hyb, hw, hs, ha, cus, nA;
   float* ws;               // [grid][BM * 128] partial accumulators in register order
   unsigned int* flags;     // [grid]: 1 = slot holds a partial tile
   int upt;                 // units (32 k) per tile
@@ -71,6 +74,7 @@ struct X3Args {
   const float* rowtab;     // MODE 1: C[m][n] += rowtab[(m / rowtab_div) * ld_rowtab + n] for n < rowtab_cols
   int ld_rowtab, rowtab_div, rowtab_cols;
   float* ln_out;           // MODE 2: [M][N/32][2] segment statistics of the stored C rows
+  const float* colsum;     // MODE 3: [w_rows] row sums of the folded weight (sum_k W'[n][k])
 };
 
 // x (two floats) -> packed bf16 pairs of the three terms
@@ -149,9 +153,10 @@ __device__ __forceinline__ float x3_fmul(float a, float b) {
 constexpr int X3_BN = 128, X3_BK = 16;
 constexpr int X3_STAT_BYTES = 16384;   // MODE 1: one 4 KB patch per wave (32 rows x 16 segments x (mean, M2))
 
-// BM: 128 (4 x 1 waves) or 64 (2 x 2 waves).  MODE: 0 plain, 1 LayerNorm consumer, 2 statistics producer.
+// BM: 128 (4 x 1 waves) or 64 (2 x 2 waves).  MODE: 0 plain, 1 LayerNorm consumer (rows normalised before the split),
+// 2 statistics producer, 3 LayerNorm consumer with the normalisation applied in the EPILOGUE (see x3_ln_linear).
 template <int BM, int MODE>
-__global__ __launch_bounds__(256, MODE == 1 ? 2 : 3) void gemm_x3_kernel(X3Args g) {
+__global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3_kernel(X3Args g) {
   constexpr int BN = X3_BN, BK = X3_BK;
   constexpr int WN = 128 / BM;              // waves along N: 1 or 2
   constexpr int NI = BN / WN / 32;          // 32-column accumulators per wave: 4 or 2
@@ -171,20 +176,37 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 3) void gemm_x3_kernel(X3Args 
   // contributed beginning part of the LAST tile first (kind 1: hand the raw accumulators over), then whole tiles (kind 0),
   // then the owned end part of the FIRST tile (kind 2: add the partials of the lower-numbered blocks, finish the tile)
   const int G = gridDim.x;
-  const int lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int upt = g.upt;
-  // which blocks get one allotment more: the first `rem` logical blocks -- or (whole tiles, g.bal) the first rem / 8 blocks of
-  // EVERY XCD, which the dispatcher puts on different CUs.  (Logical blocks are XCD-contiguous: with "the first rem" two of
-  // the eight XCDs got all the extra tiles and a 1.25-round launch ran like a 2-round one.)
-  int before = lb < g.rem ? lb : g.rem, mine = lb < g.rem ? 1 : 0;
-  if (g.bal && (G & 7) == 0) {
-    const int x = blockIdx.x & 7, i = blockIdx.x >> 3, r8 = g.rem >> 3, rx = g.rem & 7;
-    const int lim = r8 + (x < rx ? 1 : 0);
-    before = x * r8 + (x < rx ? x : rx) + (i < lim ? i : lim);
-    mine = i < lim ? 1 : 0;
+  int lb, u0, u1;
+  if (g.hyb) {
+    // Hybrid: block ids are dealt to the CUs round-robin (id % CUs): the first nA ids run the whole tiles of "their" CU
+    // (tiles [cu * hw, (cu + 1) * hw), shared between the CU's `ha` whole-tile blocks), the others one K-piece of a remaining
+    // tile each.  A CU then carries hw + 1 / hs tiles instead of hw + 1, and the pieces' exchange overlaps its whole tiles.
+    lb = blockIdx.x;
+    if (lb < g.nA) {
+      const int cu = lb % g.cus, slot = lb / g.cus;
+      const int first = cu * g.hw + (slot ? (g.hw + 1) / 2 : 0);
+      const int cnt = g.ha == 1 ? g.hw : (slot ? g.hw / 2 : (g.hw + 1) / 2);
+      u0 = first * upt; u1 = u0 + cnt * upt;
+    } else {
+      const int j = lb - g.nA, ups = upt / g.hs;
+      u0 = (g.cus * g.hw + j / g.hs) * upt + (j % g.hs) * ups; u1 = u0 + ups;
+    }
+  } else {
+    lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    // which blocks get one allotment more: the first `rem` logical blocks -- or (whole tiles, g.bal) the first rem / 8 blocks of
+    // EVERY XCD, which the dispatcher puts on different CUs.  (Logical blocks are XCD-contiguous: with "the first rem" two of
+    // the eight XCDs got all the extra tiles and a 1.25-round launch ran like a 2-round one.)
+    int before = lb < g.rem ? lb : g.rem, mine = lb < g.rem ? 1 : 0;
+    if (g.bal && (G & 7) == 0) {
+      const int x = blockIdx.x & 7, i = blockIdx.x >> 3, r8 = g.rem >> 3, rx = g.rem & 7;
+      const int lim = r8 + (x < rx ? 1 : 0);
+      before = x * r8 + (x < rx ? x : rx) + (i < lim ? i : lim);
+      mine = i < lim ? 1 : 0;
+    }
+    u0 = (lb * g.base + before) * g.gran;
+    u1 = u0 + (g.base + mine) * g.gran;
   }
-  const int u0 = (lb * g.base + before) * g.gran;
-  const int u1 = u0 + (g.base + mine) * g.gran;
   if (u0 >= u1) return;
   const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
   const int ja = u0 - k0 * upt;
@@ -400,9 +422,14 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 3) void gemm_x3_kernel(X3Args 
       return;
     }
     if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
-      const int ab = (k0 * upt) / g.gran;   // allotment that starts the tile (unit ranges: gran = 1)
-      const int big = g.rem * (g.base + 1);
-      const int c0 = ab < big ? ab / (g.base + 1) : g.rem + (ab - big) / g.base;
+      int c0;
+      if (g.hyb) {
+        c0 = lb - (g.hs - 1);               // the other pieces of this tile: the hs - 1 block ids below this one
+      } else {
+        const int ab = (k0 * upt) / g.gran;   // allotment that starts the tile (unit ranges: gran = 1)
+        const int big = g.rem * (g.base + 1);
+        c0 = ab < big ? ab / (g.base + 1) : g.rem + (ab - big) / g.base;
+      }
       for (int c = c0; c < lb; ++c) {
         while (__hip_atomic_load(g.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
           __builtin_amdgcn_s_sleep(1);
@@ -436,36 +463,62 @@ __global__ __launch_bounds__(256, MODE == 1 ? 2 : 3) void gemm_x3_kernel(X3Args 
     const bool rowok = m < g.M;
     const int mc = rowok ? m : g.M - 1;
     const int nb0 = e_n0 + wn * NI * 32 + 4 * half;
-    const bool has_tab = MODE == 1 && g.rowtab != nullptr;
+    const bool has_tab = (MODE == 1 || MODE == 3) && g.rowtab != nullptr;
     const float* xrow = nullptr;   // residual row, or (MODE 1) the row of the position table
     int xlim = 0;
     if (g.res) { xrow = g.res + (size_t)mc * g.ldr; xlim = g.N; }
     else if (has_tab) { xrow = g.rowtab + (size_t)(mc / g.rowtab_div) * g.ld_rowtab; xlim = g.rowtab_cols; }
-    // two 32-column groups at a time (8 + 8 operand registers of 16 bytes): with all of a 128-column row's operands in
-    // flight at once the register allocator spills loop-invariant addresses INTO the K loop
-    constexpr int GQ = NI == 4 ? 4 : 8;
+    // MODE 3: LayerNorm(x) W'^T = rstd (x W'^T - mean colsum(W')): the K loop multiplied the RAW rows; this row's statistics are
+    // merged here from the producer's 16 segment statistics (Chan's update, as stats_merge) and applied to the finished sums.
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if (MODE == 3) {
+      f32x4 sv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sv[i] = gload16(g.ln_in + (size_t)mc * 32 + 4 * i);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(sv[i]));
+      float sm = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sm += sv[i][0] + sv[i][2]; m2 += sv[i][1] + sv[i][3]; }
+      ln_mean = sm * (1.0f / 16.0f);
+      float dev = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d0 = sv[i][0] - ln_mean, d1 = sv[i][2] - ln_mean; dev += d0 * d0 + d1 * d1; }
+      ln_rstd = 1.0f / sqrtf((m2 + 32.f * dev) * (1.0f / 512.0f) + g.ln_eps);
+    }
+    // a few 32-column groups at a time: with all of a 128-column row's operands in flight at once the register allocator
+    // spills loop-invariant addresses INTO the K loop
+    constexpr int GQ = (NI == 4 || MODE == 3) ? 4 : 8;
 #pragma unroll
     for (int h = 0; h < NQ / GQ; ++h) {
-      f32x4 xv[GQ], bv[GQ];
+      f32x4 xv[GQ], bv[GQ], cv[GQ];
 #pragma unroll
       for (int j = 0; j < GQ; ++j) {
         const int q = h * GQ + j;
         const int n = nb0 + (q >> 2) * 32 + (q & 3) * 8;
         xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (xrow && n + 3 < xlim) xv[j] = gload16(xrow + n);
         if (g.bias && n + 3 < g.N) bv[j] = gload16(g.bias + n);
+        if (MODE == 3 && n + 3 < g.N) cv[j] = gload16(g.colsum + g.w_row0 + n);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int j = 0; j < GQ; ++j) asm volatile("" : "+v"(xv[j]), "+v"(bv[j]));
+      for (int j = 0; j < GQ; ++j) {
+        asm volatile("" : "+v"(xv[j]), "+v"(bv[j]));
+        if (MODE == 3) asm volatile("" : "+v"(cv[j]));
+      }
 #pragma unroll
       for (int j = 0; j < GQ; ++j) {
         const int q = h * GQ + j, ni = q >> 2, qq = q & 3;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float v = acc[ni][4 * qq + i] + bv[j][i];
-          if (MODE == 1) {           // position-table term in front of the activation, no residual
+          float v = acc[ni][4 * qq + i];
+          if (MODE == 3) v = (v - ln_mean * cv[j][i]) * ln_rstd;
+          v += bv[j][i];
+          if (MODE == 1 || MODE == 3) {   // position-table term in front of the activation, no residual
             v += xv[j][i];
             if (g.act == 1) v = fmaxf(v, 0.f);
           } else {
@@ -653,6 +706,7 @@ int x3_acquire(hipStream_t st, X3Args* out) {
 
 // tuning / tests: force the launch shape (0 auto, 1 whole tiles, 2 unit ranges)
 int g_x3_force_shape = 0;
+int g_x3_hybrid = 1;   // 0: never the hybrid launch (ff_set_x3_tuning(3))
 
 template <int BM, int MODE>
 int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
@@ -683,7 +737,7 @@ int x3_launch(X3Args g, int mode, hipStream_t st) {
   const int M = g.M, N = g.N, K = g.K;
   constexpr int BM = 64;
   const int cus = 256;
-  const int slots = cus * (mode == 1 ? 2 : 3);
+  const int slots = cus * ((mode == 1 || mode == 3) ? 2 : 3);   // (the LayerNorm consumers: registers / the statistics patch)
   g.tiles_n = ff_cdiv(N, X3_BN);
   g.tiles_m = ff_cdiv(M, BM);
   g.upt = K / 32;
@@ -692,8 +746,21 @@ int x3_launch(X3Args g, int mode, hipStream_t st) {
   FF_CHECK_ARG(units < (1L << 30), "ff_gemm_x3: problem too large");
   int shape = g_x3_force_shape ? g_x3_force_shape : 1;
   if (units < 2) shape = 1;
+  const int spc = (mode == 1 || mode == 3) ? 2 : 3;   // block slots per CU
   long grid;
-  if (shape == 1) {        // whole tiles: contiguous runs of tiles per block
+  // Hybrid (the default whenever it applies): hw = tiles / CUs whole tiles per CU and the r = tiles % CUs remaining tiles cut
+  // into hs K-pieces so that r * hs <= CUs.  Measured on the decode's N = 512 projections a launch of 2.06 tiles per CU then
+  // costs ~2.2 tile times instead of 3 (profiles/r04/gemm_x3_hybrid.txt).
+  const long hw = tiles / cus, hr = tiles % cus;
+  int hs = 0;
+  for (int c = 8; c >= 2; c >>= 1)
+    if (hr * c <= cus && g.upt % c == 0 && g.upt / c >= 2) { hs = c; break; }
+  if (!g_x3_force_shape && g_x3_hybrid && hw >= 1 && hr > 0 && hs > 0) {
+    g.hyb = 1; g.hw = (int)hw; g.hs = hs; g.cus = cus;
+    g.ha = (spc == 2 || hw == 1) ? 1 : 2;
+    g.nA = cus * g.ha;
+    grid = g.nA + hr * hs;
+  } else if (shape == 1) {        // whole tiles: contiguous runs of tiles per block
     grid = tiles < slots ? tiles : slots;
     g.gran = g.upt;
     g.base = (int)(tiles / grid);
@@ -710,6 +777,7 @@ int x3_launch(X3Args g, int mode, hipStream_t st) {
   ff_prof_add_bytes(FF_CAT_GEMM_X3, 4.0 * (double)M * K + 6.0 * (double)N * K + 4.0 * (double)M * N * (g.res ? 2 : 1));
   if (mode == 1) return x3_launch_mode<BM, 1>(g, (int)grid, st);
   if (mode == 2) return x3_launch_mode<BM, 2>(g, (int)grid, st);
+  if (mode == 3) return x3_launch_mode<BM, 3>(g, (int)grid, st);
   return x3_launch_mode<BM, 0>(g, (int)grid, st);
 }
 
@@ -751,6 +819,7 @@ extern "C" int ff_x3_prepare_stream(hipStream_t st) {
 extern "C" int ff_set_x3_tuning(int shape) {
   FF_CHECK_ARG(shape >= 0 && shape <= 2, "ff_set_x3_tuning: shape in {0, 1, 2}");
   g_x3_force_shape = shape;
+  g_x3_hybrid = 1;
   ff_tuning_changed();
   return FF_OK;
 }
@@ -773,7 +842,15 @@ extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split,
   return x3_launch(g, 0, (hipStream_t)stream);
 }
 
-extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int plane_rows, int row0, ff_stream_t stream) {
+// x3_ln_linear -- why the consumer's normalisation may move into the epilogue.  LN(x) W'^T = rstd (x W'^T - mean s), s = the row
+// sums of W': the K loop then is the PLAIN loop (no statistics patch in LDS, no normalising VALU work), and the row statistics
+// are merged where registers are free.  The price is numerical: the rounding error of the product is that of x W'^T, not of
+// ((x - mean) rstd) W'^T, i.e. it grows by the factor (1 + |mean| / sigma) of the ROW.  On this model's LayerNorm inputs
+// |mean| / sigma is 0.06 (median) / 0.15 (maximum over 50 836 rows of a gain-4 decode) and the two forms are equally far from
+// fp64 (5.2e-7 vs 5.1e-7 relative); callers whose rows can have |mean| >> sigma pass w_colsum = NULL and get the
+// normalise-first form (MODE 1).
+extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
+                             ff_stream_t stream) {
   FF_CHECK_ARG(d != nullptr, "ff_gemm_x3_ln: null descriptor");
   const int M = d->M, N = d->N, K = d->K;
   if (M == 0 || N == 0) return FF_OK;
@@ -799,5 +876,7 @@ extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int
   g.ln_in = d->ln_stats_in; g.ln_eps = d->ln_eps;
   g.rowtab = d->row_table; g.ld_rowtab = d->ld_row_table; g.rowtab_div = d->row_div > 0 ? d->row_div : 1; g.rowtab_cols = d->row_cols;
   g.ln_out = d->ln_stats_out;
-  return x3_launch(g, d->ln_stats_in ? 1 : (d->ln_stats_out ? 2 : 0), (hipStream_t)stream);
+  g.colsum = w_colsum;
+  FF_CHECK_ARG(!w_colsum || (ff_aligned16(w_colsum) && (row0 & 3) == 0), "ff_gemm_x3_ln: w_colsum must be 16-byte aligned, row0 %% 4 == 0");
+  return x3_launch(g, d->ln_stats_in ? (w_colsum ? 3 : 1) : (d->ln_stats_out ? 2 : 0), (hipStream_t)stream);
 }

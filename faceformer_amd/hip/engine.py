@@ -25,11 +25,13 @@ class PathEngine:
     (SURVEY.md Appendix B).  Tensors are referenced, not copied: in-place weight updates are seen.
     """
 
-    def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5, bf16_split_planes=False, fold_layernorm=True):
+    def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5, bf16_split_planes=False, fold_layernorm=True,
+                 ln_in_epilogue=True):
         self._lib = _L.load()
         self._keep = {}
         self._planes = {}
         self._want_planes = bool(bf16_split_planes)
+        self.ln_in_epilogue = bool(ln_in_epilogue)
         self._folded = {}
         m = _L.Model()
         get = self._get
@@ -115,10 +117,16 @@ class PathEngine:
                     if bf16_split_planes and E % 32 == 0:
                         # planes of the FOLDED weights: the steps that take the 3 x bf16 projections keep the LayerNorm
                         # folding (ff_gemm_x3_ln) instead of launching their LayerNorms
-                        for field, key in (("ln1_planes", (i, 1)), ("ln2_planes", (i, 2)), ("ln3_planes", (i, 3))):
+                        for field, cfield, key in (("ln1_planes", "ln1_csum", (i, 1)), ("ln2_planes", "ln2_csum", (i, 2)),
+                                                   ("ln3_planes", "ln3_csum", (i, 3))):
                             pl = split_weight(self._folded[key][0])
                             self._planes[(i, field)] = pl
                             setattr(lw, field, pl.data_ptr())
+                            if ln_in_epilogue:
+                                # row sums of the folded weight (fp64 sum, rounded once): LN(x) W'^T = rstd (x W'^T - mean s)
+                                cs = self._folded[key][0].double().sum(dim=1).float().contiguous()
+                                self._planes[(i, cfield)] = cs
+                                setattr(lw, cfield, cs.data_ptr())
                 m.proj_fold_w, m.proj_fold_b, _ = self._fold(
                     ("proj",), tensors["project.weight"], tensors["project.bias"],
                     tensors["decoder.norm.weight"], tensors["decoder.norm.bias"], None, 0)

@@ -68,6 +68,7 @@ class LayerWeights(C.Structure):
         ("ln2_w", fptr), ("ln2_b", fptr), ("ln2_pos", fptr),
         ("ln3_w", fptr), ("ln3_b", fptr),
         ("ln1_planes", fptr), ("ln2_planes", fptr), ("ln3_planes", fptr),
+        ("ln1_csum", fptr), ("ln2_csum", fptr), ("ln3_csum", fptr),
     ]
 
 
@@ -132,7 +133,7 @@ SIGNATURES = {
     "ff_split_weight_bf16x3": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, fptr]),
     "ff_gemm_x3": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_int,
                              C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
-    "ff_gemm_x3_ln": (C.c_int, [C.POINTER(GemmLnDesc), fptr, C.c_int, C.c_int, fptr]),
+    "ff_gemm_x3_ln": (C.c_int, [C.POINTER(GemmLnDesc), fptr, C.c_int, C.c_int, fptr, fptr]),
     "ff_set_x3_tuning": (C.c_int, [C.c_int]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),

@@ -150,9 +150,10 @@ def linear_ln(x, weight, bias=None, act=0, residual=None, stats_in=None, eps=1e-
 
 @_on_tensor_device
 def linear_x3_ln(x, planes, bias=None, act=0, residual=None, stats_in=None, eps=1e-5, row_table=None, row_div=1,
-                 row_cols=0, want_stats=False, out=None, row0=0, rows=0):
+                 row_cols=0, want_stats=False, out=None, row0=0, rows=0, colsum=None):
     """ff_gemm_x3_ln: linear_ln() on the bf16 matrix cores with fp32 accuracy; `planes` = split_weight(folded weight).
-    row0 / rows: use only weight rows [row0, row0 + rows) of the planes (bias, table and output then have `rows` columns)."""
+    row0 / rows: use only weight rows [row0, row0 + rows) of the planes (bias, table and output then have `rows` columns).
+    colsum ([plane rows] row sums of the folded weight): apply the normalisation in the epilogue (plain K loop)."""
     _check_planes(planes, "planes")
     plane_rows, K = planes.size(2), planes.size(1) * 16
     N = rows or plane_rows
@@ -180,7 +181,9 @@ def linear_x3_ln(x, planes, bias=None, act=0, residual=None, stats_in=None, eps=
     if want_stats:
         stats = torch.full((M, N // 32, 2), float("nan"), device=x.device, dtype=torch.float32)
         d.ln_stats_out = _p(stats)
-    _L.check(_L.load().ff_gemm_x3_ln(C.byref(d), planes.data_ptr(), plane_rows, row0, _stream()), "ff_gemm_x3_ln")
+    if colsum is not None:
+        _dev(colsum, "colsum")
+    _L.check(_L.load().ff_gemm_x3_ln(C.byref(d), planes.data_ptr(), plane_rows, row0, _p(colsum), _stream()), "ff_gemm_x3_ln")
     return (out, stats) if want_stats else out
 
 

@@ -65,6 +65,10 @@ class SurfaceFormerBase(nn.Module):
         # product's, tests/test_hip_ops.py), LayerNorm folding included (ff_gemm_x3_ln), and 1.3-1.6x the f32-MFMA kernel
         # from ~3000 rows on (profiles/r04/gemm_x3_variants.txt).  0 = off.
         self.x3_min_rows = X3_MIN_ROWS_DEFAULT
+        # ... their LayerNorm applied in the consumer's EPILOGUE (rstd (x W'^T - mean colsum(W'))): the K loop then is the plain
+        # split product.  Error factor (1 + |mean| / sigma) of the row -- 0.06 median, 0.15 maximum on this model's LayerNorm
+        # inputs; False = rows normalised before the product (ff_gemm_x3.hip: x3_ln_linear).  Read when the engine is bound.
+        self.x3_ln_in_epilogue = True
         self._engine_obj = None
 
     def _reset_parameters(self):
@@ -113,7 +117,8 @@ class SurfaceFormerBase(nn.Module):
         """PathEngine bound to this module's parameters (rebuilt when they moved, e.g. after .to())."""
         self._check_supported()
         eng = self._engine_obj
-        if eng is None or not eng.pointers_current() or eng.has_planes != (self.x3_min_rows > 0):
+        if eng is None or not eng.pointers_current() or eng.has_planes != (self.x3_min_rows > 0) or \
+                eng.ln_in_epilogue != bool(getattr(self, "x3_ln_in_epilogue", True)):
             tensors = {k: v for k, v in self.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             dev = tensors["project.weight"].device
             if dev.type != "cuda":
@@ -122,7 +127,8 @@ class SurfaceFormerBase(nn.Module):
                     "device through libfaceformer_hip.so (no CPU fallback). Move the model with "
                     ".cuda()." % dev)
             eng = PathEngine(tensors, self.num_head, self.num_token, self.encoder.norm.eps,
-                             bf16_split_planes=self.x3_min_rows > 0, fold_layernorm=True)
+                             bf16_split_planes=self.x3_min_rows > 0, fold_layernorm=True,
+                             ln_in_epilogue=getattr(self, "x3_ln_in_epilogue", True))
             self._engine_obj = eng
         return eng
 

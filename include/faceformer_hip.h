@@ -168,13 +168,19 @@ int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void
  * ln_stats_in / row_table / ln_stats_out; reference transformer.py:242-253), the weight given as the planes of the
  * FOLDED weight (ff_fold_layernorm_linear, then ff_split_weight_bf16x3); desc->W / ldw / tile are ignored.  The planes
  * describe a [plane_rows, K] weight of which the product uses rows [row0, row0 + N) (plane_rows = 0: exactly N rows).
+ * w_colsum (optional, with ln_stats_in): [plane_rows] row sums of the folded weight -- the normalisation is then applied in the
+ * epilogue, LN(x) W'^T = rstd (x W'^T - mean colsum), and the K loop runs at the plain kernel's speed; its rounding error
+ * carries the factor (1 + |mean| / sigma) of the row (ff_gemm_x3.hip: x3_ln_linear), NULL = rows normalised before the product.
  * ln_stats_in needs K = 512 (ln_nseg = 16).  N % 4 == 0, ldc / ldr / ld_row_table % 4 == 0, row_cols % 4 == 0,
  * 16-byte aligned operands (the kernel moves 16-byte pieces).  ff_decode uses it on the steps that take the 3 x bf16
  * projections, so that those steps launch no stand-alone LayerNorm either. */
-int ff_gemm_x3_ln(const ff_gemm_ln_desc* desc, const void* w_planes, int plane_rows, int row0, ff_stream_t stream);
+int ff_gemm_x3_ln(const ff_gemm_ln_desc* desc, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
+                  ff_stream_t stream);
 
-/* Launch shape of the 3 x bf16 kernel (process-wide; tests and tools/): 0 = the default (whole tiles), 1 = whole tiles,
- * 2 = equal K-unit ranges per block (cut tiles exchanged between blocks and summed in block order). */
+/* Launch shape of the 3 x bf16 kernel (process-wide; tests and tools/): 0 = the default -- whole tiles, and when the tile
+ * count is not a multiple of the CU count the remaining tiles cut into 2 / 4 / 8 K-pieces, one piece per CU, summed by the
+ * block that holds the tile's last piece in ascending piece order --, 1 = whole tiles only, 2 = equal K-unit ranges per
+ * block (every tile that straddles two blocks exchanged the same way). */
 int ff_set_x3_tuning(int shape);
 
 /* Launch-shape tuning of the stream-K kernel (process-wide; tests and tools/): a block is never handed
@@ -301,6 +307,9 @@ typedef struct ff_layer_weights {
      planes of the out-proj / linear2 weights above) the steps that take the 3 x bf16 projections keep the LayerNorm folding
      (ff_gemm_x3_ln) at every size */
   const void *ln1_planes, *ln2_planes, *ln3_planes;
+  /* optional: row sums of ln1_w / ln2_w / ln3_w ([3E], [E], [FF]): with them ff_decode's split-product steps apply the
+     LayerNorm in the consumer's epilogue (ff_gemm_x3_ln, w_colsum) */
+  const float *ln1_csum, *ln2_csum, *ln3_csum;
 } ff_layer_weights;
 
 typedef struct ff_model {

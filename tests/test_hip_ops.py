@@ -248,11 +248,14 @@ def test_gemm_x3_emits_layernorm_segment_statistics(hip_lib, ops, x3_tuning, M, 
     assert ((stats[..., 1].double() - want[..., 1]).abs() / want[..., 1].clamp_min(1e-6)).max() < 1e-5
 
 
+@pytest.mark.parametrize("in_epilogue", [False, True], ids=["normalise_first", "normalise_in_epilogue"])
 @pytest.mark.parametrize("M,N,div", [(37, 1536, 5), (300, 512, 7), (1300, 1536, 64), (5000, 1024, 256), (9216, 1536, 256),
                                      (4352, 512, 256)])
-def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, x3_tuning, M, N, div):
+def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, x3_tuning, M, N, div, in_epilogue):
     """ff_gemm_x3_ln, consumer side: act((LN(x) + pos[row // div]) W^T + b) from raw x, its segment statistics, the planes of
-    the folded weight, the folded bias and the pos W^T table -- against the unfused arithmetic in float64."""
+    the folded weight, the folded bias and the pos W^T table -- against the unfused arithmetic in float64; rows normalised
+    before the product, and the plain product with rstd (x W'^T - mean colsum(W')) in the epilogue (rows with |mean| / sigma
+    around 0.75 here: the second form's bound carries that factor)."""
     K = 512
     g = torch.Generator().manual_seed(M * 3 + N + K)
     x = (1.5 + 2.0 * torch.randn(M, K, generator=g)) * (1.0 + torch.rand(M, 1, generator=g))   # row-dependent scale / mean
@@ -265,7 +268,9 @@ def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops,
     xd, Wd = x.cuda(), W.cuda()
     Wf, bf, P = ops.fold_layernorm_linear(Wd, b.cuda(), gamma.cuda(), beta.cuda(), pos.cuda(), pos_cols)
     stats = _seg_stats(xd.double()).float().contiguous()
-    out = ops.linear_x3_ln(xd, ops.split_weight(Wf), bf, act=1, stats_in=stats, row_table=P, row_div=div, row_cols=pos_cols)
+    colsum = Wf.double().sum(dim=1).float().contiguous() if in_epilogue else None
+    out = ops.linear_x3_ln(xd, ops.split_weight(Wf), bf, act=1, stats_in=stats, row_table=P, row_div=div, row_cols=pos_cols,
+                           colsum=colsum)
     x64 = x.double()
     ln = torch.nn.functional.layer_norm(x64, (K,), gamma.double(), beta.double(), 1e-5)
     rows = torch.arange(M) // div

@@ -166,6 +166,10 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
     stats = compare_with_golden(case, z, out)
     print(name, min_rows, stats)
     _record_margin(name, "bf16x3 from %d rows" % min_rows, stats)
+    model.x3_ln_in_epilogue = False     # rows normalised before the product (the engine re-binds)
+    stats = compare_with_golden(case, z, run_traced(model, case, batch_to(batch, "cuda")))
+    _record_margin(name, "bf16x3 from %d rows, LN before product" % min_rows, stats)
+    model.x3_ln_in_epilogue = True
     from faceformer_amd.hip import lib as L
     model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
     stats = compare_with_golden(case, z, run_traced(model, case, batch_to(batch, "cuda")))
