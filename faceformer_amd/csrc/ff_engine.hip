@@ -292,8 +292,11 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   const bool x3_bound = prm->x3_min_rows > 0 && nd > 0 && m->dec[0].in_proj_planes != nullptr;
   const bool x3_folds = x3_bound && m->dec[0].ln1_planes != nullptr && m->dec[0].ln2_planes != nullptr &&
                         m->dec[0].ln3_planes != nullptr && E == 512;
+  // f32 only: since round 4 the LDS-DMA kernel of the f32 family carries the folded forms at every size too (K = E = 512), so
+  // the steps fold at every size as well (128 wireframes per call: 5 053 -> 301 LayerNorm launches, 206 -> 214 k selections/s).
   const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows
-                       : (x3_folds ? (1 << 30) : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288));
+                       : ((x3_folds || (!x3_bound && E == 512)) ? (1 << 30)
+                          : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288));
   // Flow launches (FF_FLOW): the dependent projections between two attention operators -- out-proj -> q-proj and
   // out-proj -> linear1 -> linear2 -> the next layer's q|k|v -- run inside ONE persistent launch each, tile by tile behind
   // row-panel dependency counters (ff_gemm.hip: gemm_flow_kernel).  They need the LayerNorm-folded forms, so a step that takes

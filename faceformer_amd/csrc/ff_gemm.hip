@@ -1581,6 +1581,11 @@ extern "C" int ff_set_gemm_tuning(int min_units, int two_per_cu_units, int fix_t
 }
 
 namespace {
+// rows from which the automatic choice hands a launch to the LDS-DMA kernel (FF_DMA_MIN_ROWS overrides: probes).  Measured
+// (profiles/r04/dma_threshold_ab.txt, gemm_dma_f32.txt): +3-8 % over the 64x64 / 128x64 families from ~8 k rows, LayerNorm-folded
+// forms +6-12 % from ~9 k rows, equal around 4-6 k, slower below; config B 59.9 -> 59.4 ms, 128 wireframes per call 206 -> 214 k/s
+// (with the LayerNorms folded at every size, which the 128x64 kernel could not).
+const long g_dma_min_rows = getenv("FF_DMA_MIN_ROWS") ? atol(getenv("FF_DMA_MIN_ROWS")) : 4096;
 int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
   const bool split128 = !g.A2 || (g.n_split % 128) == 0;
   if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
@@ -1589,6 +1594,13 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
   if (ff_chain_recording()) return ff_chain_record_gemm(g, batch);   // operator of a chain launch (ff_chain.hip)
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
   ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (g.res ? 2 : 1)));
+  // tile 11 / automatic from g_dma_min_rows rows on: the LDS-DMA kernel (ff_gemm_x3.hip: gemm_dma_f32_kernel)
+  const bool dma_ok = ff_gemm_dma_f32_ok(g, batch);
+  if (tile == 11) {
+    FF_CHECK_ARG(dma_ok, "ff_gemm_f32: tile 11 needs K %% 32 == 0, K >= 64, N %% 4 == 0, leading dimensions %% 4, 16-byte aligned operands, batch 1");
+    return ff_gemm_dma_f32(g, st);
+  }
+  if (tile == 7 && dma_ok && (long)M >= g_dma_min_rows && !ff_chain_recording()) return ff_gemm_dma_f32(g, st);
   switch (tile) {
     case 1: return launch_generic<64, 64, 32, 32>(g, batch, st);
     case 2: return launch_pipe<64, 64, 32, 32>(g, batch, st);
@@ -1636,7 +1648,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 10, "ff_gemm_f32: tile must be 0..10");
+  FF_CHECK_ARG(tile >= 0 && tile <= 11, "ff_gemm_f32: tile must be 0..11");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
@@ -1657,8 +1669,8 @@ extern "C" int ff_gemm_f32_ln(const ff_gemm_ln_desc* d, ff_stream_t stream) {
   FF_CHECK_ARG(ff_aligned16(d->A) && ff_aligned16(d->W), "ff_gemm_f32_ln: A/W must be 16-byte aligned");
   FF_CHECK_ARG(!d->residual || d->ldr >= N, "ff_gemm_f32_ln: bad ldr");
   FF_CHECK_ARG(d->act == 0 || d->act == 1, "ff_gemm_f32_ln: act must be 0 or 1");
-  FF_CHECK_ARG(d->tile == 0 || d->tile == 3 || d->tile == 6 || d->tile == 7 || d->tile == 8,
-               "ff_gemm_f32_ln: tile must be 0, 3, 6, 7 or 8 (the kernels that carry the LayerNorm fusion)");
+  FF_CHECK_ARG(d->tile == 0 || d->tile == 3 || d->tile == 6 || d->tile == 7 || d->tile == 8 || d->tile == 11,
+               "ff_gemm_f32_ln: tile must be 0, 3, 6, 7, 8 or 11 (the kernels that carry the LayerNorm fusion)");
   FF_CHECK_ARG(!(d->ln_stats_in && d->ln_stats_out), "ff_gemm_f32_ln: statistics in AND out in one launch are not supported");
   FF_CHECK_ARG(!d->ln_stats_in || (d->ln_nseg > 0 && d->ln_nseg * 32 == K && d->ln_eps >= 0.f),
                "ff_gemm_f32_ln: ln_nseg * 32 must equal K (the statistics describe whole rows of A)");

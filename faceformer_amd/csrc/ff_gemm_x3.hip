@@ -51,6 +51,8 @@ struct X3Args {
   const float* A;
   const float* A2;
   const unsigned short* Wp;  // [3][K/16][N][16] bf16 (see "plane layout" above)
+  const float* W;            // gemm_dma_f32_kernel: the fp32 weight rows themselves
+  int ldw;
   const float* bias;
   const float* res;
   float* C;
@@ -673,6 +675,504 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
   }
 }
 
+// ---- the same launch structure on the f32 matrix cores ------------------------------------------------------------------------
+// gemm_dma_f32_kernel: v_mfma_f32_32x32x2_f32 fed the way gemm_x3_kernel is fed -- BOTH operands as fp32 rows by LDS-DMA (no
+// staging registers, no ds_write), fragments of slice s + 1 read in the MFMA gaps of slice s, transposed accumulators, 16-byte
+// epilogue accesses, whole tiles + hybrid remainder, the same LayerNorm-folded forms (MODE 1 normalises the eight floats of its
+// row per slice in registers).  A 16-wide slice is 16 MFMAs of 64 cycles per wave against 6 fragment reads and 3 DMA pieces, 36 KB
+// of LDS; three blocks per CU (at the 128 registers of four, the epilogue's operands push loop addresses into scratch).  W is the nn.Linear weight itself ([N, K] fp32 rows, ld = ldw): no planes.
+// Operand k order inside a slice: MFMA e of 8 takes k = e from the lanes 0..31 and k = 8 + e from the lanes 32..63 of BOTH
+// operands (a lane holds floats 8 half .. 8 half + 7 of its row).
+template <int BM, int MODE>
+__global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
+  constexpr int BN = X3_BN, BK = X3_BK;
+  constexpr int WN = 128 / BM;              // waves along N: 1 or 2
+  constexpr int NI = BN / WN / 32;          // 32-column accumulators per wave: 4 or 2
+  constexpr int NPA = BM / 64;              // A pieces (16 rows x 64 B) per wave and slice
+  constexpr int NPW = BN / 64;              // W pieces (16 rows x 64 B) per wave and slice
+  constexpr int NP = NPA + NPW;             // DMA pieces per wave and slice
+  constexpr int A_REG = BM * 64, SLOT = A_REG + BN * 64;
+  constexpr int NMF = 8 * NI;               // MFMAs per wave and slice
+  constexpr int NRD = 2 + 2 * NI;           // fragment reads per wave and slice
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nsl = g.K / BK;
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+
+  // ---- this block's unit range and its segments of the flat (tile, slice) sequence ----
+  // contributed beginning part of the LAST tile first (kind 1: hand the raw accumulators over), then whole tiles (kind 0),
+  // then the owned end part of the FIRST tile (kind 2: add the partials of the lower-numbered blocks, finish the tile)
+  const int G = gridDim.x;
+  const int upt = g.upt;
+  int lb, u0, u1;
+  if (g.hyb) {
+    // Hybrid: block ids are dealt to the CUs round-robin (id % CUs): the first nA ids run the whole tiles of "their" CU
+    // (tiles [cu * hw, (cu + 1) * hw), shared between the CU's `ha` whole-tile blocks), the others one K-piece of a remaining
+    // tile each.  A CU then carries hw + 1 / hs tiles instead of hw + 1, and the pieces' exchange overlaps its whole tiles.
+    lb = blockIdx.x;
+    if (lb < g.nA) {
+      const int cu = lb % g.cus, slot = lb / g.cus;
+      const int first = cu * g.hw + (slot ? (g.hw + 1) / 2 : 0);
+      const int cnt = g.ha == 1 ? g.hw : (slot ? g.hw / 2 : (g.hw + 1) / 2);
+      u0 = first * upt; u1 = u0 + cnt * upt;
+    } else {
+      const int j = lb - g.nA, ups = upt / g.hs;
+      u0 = (g.cus * g.hw + j / g.hs) * upt + (j % g.hs) * ups; u1 = u0 + ups;
+    }
+  } else {
+    lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    // which blocks get one allotment more: the first `rem` logical blocks -- or (whole tiles, g.bal) the first rem / 8 blocks of
+    // EVERY XCD, which the dispatcher puts on different CUs.  (Logical blocks are XCD-contiguous: with "the first rem" two of
+    // the eight XCDs got all the extra tiles and a 1.25-round launch ran like a 2-round one.)
+    int before = lb < g.rem ? lb : g.rem, mine = lb < g.rem ? 1 : 0;
+    if (g.bal && (G & 7) == 0) {
+      const int x = blockIdx.x & 7, i = blockIdx.x >> 3, r8 = g.rem >> 3, rx = g.rem & 7;
+      const int lim = r8 + (x < rx ? 1 : 0);
+      before = x * r8 + (x < rx ? x : rx) + (i < lim ? i : lim);
+      mine = i < lim ? 1 : 0;
+    }
+    u0 = (lb * g.base + before) * g.gran;
+    u1 = u0 + (g.base + mine) * g.gran;
+  }
+  if (u0 >= u1) return;
+  const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
+  const int ja = u0 - k0 * upt;
+  const int jb = u1 - k1 * upt;
+  const bool has_c = jb < upt;
+  const bool has_o = ja > 0 && !(k0 == k1 && has_c);
+  const int kf0 = k0 + (ja > 0 ? 1 : 0);
+  const int nfull = (k1 + (has_c ? 0 : 1) - kf0) > 0 ? (k1 + (has_c ? 0 : 1) - kf0) : 0;
+  const int nseg = (has_c ? 1 : 0) + nfull + (has_o ? 1 : 0);
+  auto segment = [&](int p, int& tile, int& j0, int& n, int& kind) {
+    if (has_c && p == 0) {
+      tile = k1; j0 = 2 * (k1 == k0 ? ja : 0); n = 2 * jb - j0; kind = 1;
+    } else {
+      const int q = p - (has_c ? 1 : 0);
+      if (q < nfull) { tile = kf0 + q; j0 = 0; n = nsl; kind = 0; }
+      else { tile = k0; j0 = 2 * ja; n = nsl - j0; kind = 2; }
+    }
+  };
+  auto tile_origin = [&](int id, int& m0, int& n0) {
+    const int r = id % tiles_mn;
+    m0 = (r / g.tiles_n) * BM; n0 = (r % g.tiles_n) * BN;
+  };
+
+  // ---- loader: uniform base pointers (advance per slice) + per-lane BYTE offsets (change per tile) ----
+  int ld_p = 0, ld_j = 0, ld_end = 0;
+  unsigned a_off[2] = {0, 0}, w_off[2] = {0, 0};   // (a fixed bound: an array of dependent size makes the DMA builtin's arguments type-dependent,
+                                       //  and the host pass then drops the whole kernel instantiation without a diagnostic)
+  const char* a_base = nullptr;
+  const char* w_base = nullptr;
+  auto set_tile = [&](int id, int j0) {
+    int m0, n0;
+    tile_origin(id, m0, n0);
+    const float* Asrc = (g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A;
+    a_base = reinterpret_cast<const char*>(Asrc) + (size_t)j0 * (BK * 4);
+    w_base = reinterpret_cast<const char*>(g.W) + (size_t)j0 * (BK * 4);
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {   // piece = 16 rows x 64 B; lane: row lane / 4, 16-byte slot lane % 4 (swizzled by (row >> 2) & 3)
+      const int lr = 16 * (wave * NPA + q) + (lane >> 2);
+      int row = m0 + lr;
+      row = row < g.M ? row : g.M - 1;
+      a_off[q] = ((unsigned)row * g.lda + 4 * ((lane & 3) ^ ((lr >> 2) & 3))) * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {   // W pieces: the same 16 rows x 64 B form
+      const int lr = 16 * (wave * NPW + q) + (lane >> 2);
+      int row = n0 + lr;
+      row = row < g.N ? row : g.N - 1;
+      w_off[q] = ((unsigned)(g.w_row0 + row) * g.ldw + 4 * ((lane & 3) ^ ((lr >> 2) & 3))) * 4;
+    }
+  };
+  auto issue_piece = [&](int k, int slot) {   // piece k of the slice the loader stands on -> ring slot `slot`
+    unsigned char* base = lds + slot * SLOT;
+    if (k < NPA) {
+      __builtin_amdgcn_global_load_lds(a_base + a_off[k < NPA ? k : 0], X3_LDS_PTR(base + (wave * NPA + k) * 1024), 16, 0, 0);
+    } else {
+      const int q = k - NPA;
+      __builtin_amdgcn_global_load_lds(w_base + w_off[q < NPW ? q : 0], X3_LDS_PTR(base + A_REG + (wave * NPW + (q < NPW ? q : 0)) * 1024), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    if (++ld_j == ld_end) {
+      if (ld_p + 1 < nseg) {
+        int tile, j0, n, kind;
+        segment(++ld_p, tile, j0, n, kind);
+        set_tile(tile, j0);
+        ld_j = j0; ld_end = j0 + n;
+      } else {
+        ld_j = ld_end - 1;   // past the end: the last slice again (never read)
+      }
+    } else { a_base += BK * 4; w_base += BK * 4; }
+  };
+  auto issue = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) issue_piece(k, slot);
+    advance();
+  };
+
+  // ---- fragment addresses (bytes inside a slot) ----
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned fw_r0 = A_REG + (wn * NI * 32 + l32) * 64 + (((2 * half) ^ ((l32 >> 2) & 3)) * 16);       // + ni * 2048
+  const unsigned fw_r1 = A_REG + (wn * NI * 32 + l32) * 64 + (((2 * half + 1) ^ ((l32 >> 2) & 3)) * 16);
+  const unsigned fa_r0 = (32 * wm + l32) * 64 + (((2 * half) ^ ((l32 >> 2) & 3)) * 16);         // floats k = 8 half .. + 3
+  const unsigned fa_r1 = (32 * wm + l32) * 64 + (((2 * half + 1) ^ ((l32 >> 2) & 3)) * 16);
+
+  u32x4 wf[2][2][NI];   // [set][16-byte half of the lane's 8 floats][ni]
+  u32x4 af[2][2];       // [set][half]: the lane's 8 floats of its A row (MODE 1: normalised in place)
+  f32x16 acc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+  auto read_w = [&](u32x4 (&dst)[2][NI], unsigned slot_addr, int r) {   // r = j * NI + ni, a constant after unrolling
+    const int j = r / NI, ni = r % NI;
+    if (ni == 0) dst[j][0] = x3_lds_read16<0>(slot_addr + (j ? fw_r1 : fw_r0));
+    else dst[j][NI > 1 ? 1 : 0] = x3_lds_read16<2048>(slot_addr + (j ? fw_r1 : fw_r0));
+  };
+
+  // ---- MODE 1: (mean, rstd) of this lane's row for the tile being computed and the next one ----
+  float mean_c = 0.f, rstd_c = 1.f, mean_n = 0.f, rstd_n = 1.f;
+  float mean_s = 0.f, rstd_s = 1.f;   // what the split in flight uses
+  const unsigned stat_lds = lds0 + 3 * SLOT + wave * 4096;
+  auto stats_fetch = [&](int p) {     // DMA the segment statistics of segment p's rows (this wave's 32) into the wave's patch
+    if (MODE != 1 || p >= nseg) return;
+    int tile, j0, n, kind, m0, n0;
+    segment(p, tile, j0, n, kind);
+    tile_origin(tile, m0, n0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {     // piece = 8 rows x 128 B
+      int row = m0 + 32 * wm + 8 * q + (lane >> 3);
+      row = row < g.M ? row : g.M - 1;
+      __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + (lane & 7) * 4,
+                                       X3_LDS_PTR(lds + 3 * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
+    }
+  };
+  auto stats_merge = [&](float& mean, float& rstd) {   // Chan's update for 16 equal parts (as ff_ln_finish of the f32 family)
+    if (MODE != 1) return;
+    u32x4 s[8];
+    s[0] = x3_lds_read16<0>(stat_lds + l32 * 128);   s[1] = x3_lds_read16<16>(stat_lds + l32 * 128);
+    s[2] = x3_lds_read16<32>(stat_lds + l32 * 128);  s[3] = x3_lds_read16<48>(stat_lds + l32 * 128);
+    s[4] = x3_lds_read16<64>(stat_lds + l32 * 128);  s[5] = x3_lds_read16<80>(stat_lds + l32 * 128);
+    s[6] = x3_lds_read16<96>(stat_lds + l32 * 128);  s[7] = x3_lds_read16<112>(stat_lds + l32 * 128);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7])::"memory");
+    float sm = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 v = __builtin_bit_cast(f32x4, s[i]);
+      sm += v[0] + v[2]; m2 += v[1] + v[3];
+    }
+    mean = sm * (1.0f / 16.0f);
+    float dev = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 v = __builtin_bit_cast(f32x4, s[i]);
+      const float d0 = v[0] - mean, d1 = v[2] - mean;
+      dev += d0 * d0 + d1 * d1;
+    }
+    const float var = (m2 + 32.f * dev) * (1.0f / 512.0f);
+    rstd = 1.0f / sqrtf(var + g.ln_eps);
+  };
+
+  // MODE 1: (x - mean) * rstd on float pair p (0..3) of the 8 floats in `dst` (the reference's order of operations)
+  auto norm_pair = [&](u32x4 (&dst)[2], int p) {
+    f32x4 v = __builtin_bit_cast(f32x4, dst[p >> 1]);
+    const int c = 2 * (p & 1);
+    v[c] = x3_fmul(x3_fsub(v[c], mean_s), rstd_s);
+    v[c + 1] = x3_fmul(x3_fsub(v[c + 1], mean_s), rstd_s);
+    dst[p >> 1] = __builtin_bit_cast(u32x4, v);
+    asm volatile("" : "+v"(dst[p >> 1]));
+  };
+
+  // ---- compute-side segment state ----
+  int cp_p = 0, cp_cnt = 0, cp_n = 0, cp_kind = 0;
+  int e_m0 = 0, e_n0 = 0;
+  auto begin_segment = [&](int p) {
+    int id, j0;
+    segment(p, id, j0, cp_n, cp_kind);
+    cp_cnt = 0;
+    tile_origin(id, e_m0, e_n0);
+  };
+
+  // End of a segment: hand the partial tile over (kind 1), or finish the tile -- after adding the partials of the
+  // lower-numbered blocks (kind 2) -- with bias / activation / table / residual, the store and (MODE 2) the statistics.
+  // Every global access of this path is inline assembly with its own waits: accesses the compiler knows about leave an
+  // "unknown" wait-count state at the join with the K loop (it then opens every slice with s_waitcnt vmcnt(0)), and the
+  // stores must not be waited for at all -- they drain behind the next tile's first slices.
+  auto gload16 = [&](const float* ptr) -> f32x4 {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+  };
+  auto end_segment = [&]() {
+    constexpr int NQ = 4 * NI;   // 16-byte accumulator groups per lane
+    if (cp_kind == 1) {
+      f32x4* wp = reinterpret_cast<f32x4*>(g.ws + (size_t)lb * (BM * BN)) + tid;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wp + (ni * 4 + q) * 256), "v"(v) : "memory");
+          acc[ni][4 * q] = 0.f; acc[ni][4 * q + 1] = 0.f; acc[ni][4 * q + 2] = 0.f; acc[ni][4 * q + 3] = 0.f;
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) __hip_atomic_store(g.flags + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
+      int c0;
+      if (g.hyb) {
+        c0 = lb - (g.hs - 1);               // the other pieces of this tile: the hs - 1 block ids below this one
+      } else {
+        const int ab = (k0 * upt) / g.gran;   // allotment that starts the tile (unit ranges: gran = 1)
+        const int big = g.rem * (g.base + 1);
+        c0 = ab < big ? ab / (g.base + 1) : g.rem + (ab - big) / g.base;
+      }
+      for (int c = c0; c < lb; ++c) {
+        while (__hip_atomic_load(g.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const f32x4* rp = reinterpret_cast<const f32x4*>(g.ws + (size_t)c * (BM * BN)) + tid;
+        constexpr int TQ = 8;   // 8 x 16 bytes in flight per lane and round trip (all 16 of a 128-row tile would spill)
+#pragma unroll
+        for (int h = 0; h < NQ / TQ; ++h) {
+          f32x4 t[TQ];
+#pragma unroll
+          for (int j = 0; j < TQ; ++j)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[j]) : "v"(rp + (h * TQ + j) * 256) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) {
+            asm volatile("" : "+v"(t[j]));
+            const int q = h * TQ + j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[q >> 2][4 * (q & 3) + i] += t[j][i];
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();  // every thread is past its flag polls
+      if (tid < lb - c0) __hip_atomic_store(g.flags + c0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // This lane: row m, columns n0 + (wn * NI + ni) * 32 + 8 q + 4 half + {0..3}.  ALL epilogue operands of the tile are
+    // requested in one go (the fragments of the next slice are not live here: they are read again behind the epilogue),
+    // every result is finished in its accumulator registers, then the stores go out back to back.  A lane reads and
+    // writes the same elements, so a residual that aliases C stays correct.
+    const int m = e_m0 + 32 * wm + l32;
+    const bool rowok = m < g.M;
+    const int mc = rowok ? m : g.M - 1;
+    const int nb0 = e_n0 + wn * NI * 32 + 4 * half;
+    const bool has_tab = (MODE == 1 || MODE == 3) && g.rowtab != nullptr;
+    const float* xrow = nullptr;   // residual row, or (MODE 1) the row of the position table
+    int xlim = 0;
+    if (g.res) { xrow = g.res + (size_t)mc * g.ldr; xlim = g.N; }
+    else if (has_tab) { xrow = g.rowtab + (size_t)(mc / g.rowtab_div) * g.ld_rowtab; xlim = g.rowtab_cols; }
+    // MODE 3: LayerNorm(x) W'^T = rstd (x W'^T - mean colsum(W')): the K loop multiplied the RAW rows; this row's statistics are
+    // merged here from the producer's 16 segment statistics (Chan's update, as stats_merge) and applied to the finished sums.
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if (MODE == 3) {
+      f32x4 sv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sv[i] = gload16(g.ln_in + (size_t)mc * 32 + 4 * i);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(sv[i]));
+      float sm = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sm += sv[i][0] + sv[i][2]; m2 += sv[i][1] + sv[i][3]; }
+      ln_mean = sm * (1.0f / 16.0f);
+      float dev = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d0 = sv[i][0] - ln_mean, d1 = sv[i][2] - ln_mean; dev += d0 * d0 + d1 * d1; }
+      ln_rstd = 1.0f / sqrtf((m2 + 32.f * dev) * (1.0f / 512.0f) + g.ln_eps);
+    }
+    // a few 32-column groups at a time: with all of a 128-column row's operands in flight at once the register allocator
+    // spills loop-invariant addresses INTO the K loop
+    constexpr int GQ = (NI == 4 || MODE == 3) ? 4 : 8;
+#pragma unroll
+    for (int h = 0; h < NQ / GQ; ++h) {
+      f32x4 xv[GQ], bv[GQ], cv[GQ];
+#pragma unroll
+      for (int j = 0; j < GQ; ++j) {
+        const int q = h * GQ + j;
+        const int n = nb0 + (q >> 2) * 32 + (q & 3) * 8;
+        xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xrow && n + 3 < xlim) xv[j] = gload16(xrow + n);
+        if (g.bias && n + 3 < g.N) bv[j] = gload16(g.bias + n);
+        if (MODE == 3 && n + 3 < g.N) cv[j] = gload16(g.colsum + g.w_row0 + n);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < GQ; ++j) {
+        asm volatile("" : "+v"(xv[j]), "+v"(bv[j]));
+        if (MODE == 3) asm volatile("" : "+v"(cv[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < GQ; ++j) {
+        const int q = h * GQ + j, ni = q >> 2, qq = q & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[ni][4 * qq + i];
+          if (MODE == 3) v = (v - ln_mean * cv[j][i]) * ln_rstd;
+          v += bv[j][i];
+          if (MODE == 1 || MODE == 3) {   // position-table term in front of the activation, no residual
+            v += xv[j][i];
+            if (g.act == 1) v = fmaxf(v, 0.f);
+          } else {
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            v += xv[j][i];
+          }
+          acc[ni][4 * qq + i] = v;
+        }
+      }
+    }
+    if (MODE == 2) {   // (mean, M2) of this row's 32 stored values per column group: 16 here, 16 in the lane 32 away
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm += acc[ni][e];
+        sm += __shfl_xor(sm, 32, FF_WAVE);
+        const float mean = sm * (1.0f / 32.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float d = acc[ni][e] - mean; m2 += d * d; }
+        m2 += __shfl_xor(m2, 32, FF_WAVE);
+        const int seg = (e_n0 >> 5) + wn * NI + ni;
+        if (half == 0 && rowok && seg * 32 < g.N) {
+          const f32x2 st2 = f32x2{mean, m2};
+          asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g.ln_out + ((size_t)m * (g.N >> 5) + seg) * 2), "v"(st2) : "memory");
+        }
+      }
+    }
+    if (rowok) {
+      float* cp = g.C + (size_t)m * g.ldc + nb0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (nb0 + (q >> 2) * 32 + (q & 3) * 8 + 3 < g.N) {
+          const f32x4 v = {acc[q >> 2][4 * (q & 3)], acc[q >> 2][4 * (q & 3) + 1], acc[q >> 2][4 * (q & 3) + 2], acc[q >> 2][4 * (q & 3) + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(cp + (q >> 2) * 32 + (q & 3) * 8), "v"(v) : "memory");
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+  };
+
+  // ---- prologue: slices 0, 1, 2 in flight; 0 and 1 landed; fragments of slice 0 in set 0 ----
+  {
+    int tile, j0, n, kind;
+    segment(0, tile, j0, n, kind);
+    set_tile(tile, j0);
+    ld_j = j0; ld_end = j0 + n;
+  }
+  if (MODE == 1) {   // statistics of segment 0 (and 1): fetched and merged before the first split
+    stats_fetch(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    stats_merge(mean_c, rstd_c);
+    stats_fetch(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    stats_merge(mean_n, rstd_n);
+    stats_fetch(2);
+    mean_s = mean_c; rstd_s = rstd_c;
+  }
+  issue(0); issue(1); issue(2);
+  begin_segment(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70 | NP);   // vmcnt(NP): all but the youngest slice
+  __builtin_amdgcn_s_barrier();
+  {
+    af[0][0] = x3_lds_read16(lds0 + fa_r0);
+    af[0][1] = x3_lds_read16(lds0 + fa_r1);
+#pragma unroll
+    for (int r = 0; r < 2 * NI; ++r) read_w(wf[0], lds0, r);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1])::"memory");
+    if (MODE == 1) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) norm_pair(af[0], p);
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+
+  // where the normalisation (MODE 1) and the DMA pieces go among the MFMA gaps
+  constexpr int SP0 = 3;              // the two A reads are the oldest of the 4 reads issued by then
+  constexpr int DM0 = NRD + 2;        // first DMA piece
+  int s0 = 0, s1 = 1;   // ring slots of slice s, s + 1  (slice s + 3 goes to slot s0)
+  const int total = 2 * (u1 - u0);
+  for (int s = 0; s < total; s += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned nb = lds0 + s1 * SLOT;   // slot of slice s + 1
+      if (MODE == 1) {   // the rows split in this iteration belong to the next segment's tile when this is the segment's last slice
+        const bool nx = cp_cnt + 1 == cp_n;
+        mean_s = nx ? mean_n : mean_c; rstd_s = nx ? rstd_n : rstd_c;
+      }
+      // NMF MFMAs of slice s; in their gaps: the reads of slice s + 1 (one per gap), (MODE 1) its normalisation, the DMA of s + 3
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        const int e = i / NI, ni = i % NI;
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, wf[u][e >> 2][ni])[e & 3],
+                                                       __builtin_bit_cast(f32x4, af[u][e >> 2])[e & 3], acc[ni], 0, 0, 0);
+        if (i == 0) af[u ^ 1][0] = x3_lds_read16(nb + fa_r0);
+        else if (i == 1) af[u ^ 1][1] = x3_lds_read16(nb + fa_r1);
+        else if (i < NRD) read_w(wf[u ^ 1], nb, i - 2);
+        if (MODE == 1) {
+          if (i == SP0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[u ^ 1][0]), "+v"(af[u ^ 1][1])::"memory");
+          if (i >= SP0 && i < SP0 + 4) norm_pair(af[u ^ 1], i - SP0);
+        }
+        if (i >= DM0 && i < DM0 + NP) issue_piece(i - DM0, s0);
+        if (i == NMF - 1) advance();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // slice s + 2 has landed (own pieces), every fragment of slice s + 1 is in registers
+      __builtin_amdgcn_s_waitcnt(0x0070 | NP);   // vmcnt(NP) lgkmcnt(0)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("" : "+v"(af[u ^ 1][j]));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[u ^ 1][j][ni]));
+      }
+      if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
+        end_segment();
+        if (++cp_p < nseg) begin_segment(cp_p);
+        // 64-row tiles: the fragments of slice s + 1 are read AGAIN here (their slot is untouched until the barrier below),
+        // so the values read inside the loop are dead across the epilogue and its operands do not compete with them for the
+        // 168 registers of three waves per SIMD.  (128-row tiles keep them live: the second copy of the read-and-split code
+        // costs that kernel more registers than it frees.)  Either way no register that an asynchronous ds_read has not
+        // filled yet may be spilled: tools/check_x3_asm.py looks for scratch accesses inside the MFMA runs of every build.
+        if (NI == 2) {
+          af[u ^ 1][0] = x3_lds_read16(nb + fa_r0);
+          af[u ^ 1][1] = x3_lds_read16(nb + fa_r1);
+#pragma unroll
+          for (int r = 0; r < 2 * NI; ++r) read_w(wf[u ^ 1], nb, r);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[u ^ 1][0]), "+v"(af[u ^ 1][1])::"memory");
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[u ^ 1][j][ni]));
+          mean_s = mean_n; rstd_s = rstd_n;   // (MODE 1: these rows belong to the segment that starts now)
+          if (MODE == 1) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) norm_pair(af[u ^ 1], p);
+          }
+        }
+        if (MODE == 1) {       // statistics: the next segment's become current, the one after is merged from the patch
+          mean_c = mean_n; rstd_c = rstd_n;
+          stats_merge(mean_n, rstd_n);
+          stats_fetch(cp_p + 2);
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      { const int tmp = s0; s0 = s1; s1 = 3 - s0 - tmp; }   // (s0, s1, s2) -> (s1, s2, s0)
+    }
+  }
+}
+
 // Partial-tile workspace: one per (device, stream), as in ff_gemm.hip.
 constexpr int X3_MAX_GRID = 768;
 constexpr size_t X3_WS_BYTES = (size_t)X3_MAX_GRID * 64 * 128 * sizeof(float);   // one 32 KB partial tile per block
@@ -723,6 +1223,21 @@ int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
   FF_CHECK_LAUNCH();
   return FF_OK;
 }
+template <int BM, int MODE>
+int dma_f32_launch_mode(const X3Args& g, int grid, hipStream_t st) {
+  static bool attr_set[16] = {};
+  constexpr int bytes = 3 * (BM * 64 + X3_BN * 64) + (MODE == 1 ? X3_STAT_BYTES : 0);
+  int dev = 0;
+  FF_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_f32_kernel<BM, MODE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm_dma_f32_kernel<BM, MODE>), dim3(grid), dim3(256), bytes, st, g);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
 
 // Launch shape: WHOLE TILES, always (round 4).  Measured over the decode's shapes (profiles/r04/gemm_x3_variants.txt): once the
 // blocks that get one tile more are dealt out over the XCDs and CUs, whole tiles are as fast as or faster than equal K-unit
@@ -733,11 +1248,13 @@ int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
 // and the register allocator then spills INTO the K loop (a spill of a fragment register that an asynchronous ds_read has
 // not filled yet stores garbage, and every reload costs a full vmcnt drain); where it compiled cleanly it was within +-7 %
 // of the 64-row tile.
-int x3_launch(X3Args g, int mode, hipStream_t st) {
+int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
   const int M = g.M, N = g.N, K = g.K;
   constexpr int BM = 64;
   const int cus = 256;
-  const int slots = cus * ((mode == 1 || mode == 3) ? 2 : 3);   // (the LayerNorm consumers: registers / the statistics patch)
+  // block slots per CU: registers / the statistics patch of the LayerNorm consumers decide
+  const int spc = f32 ? 3 : ((mode == 1 || mode == 3) ? 2 : 3);
+  const int slots = cus * spc;
   g.tiles_n = ff_cdiv(N, X3_BN);
   g.tiles_m = ff_cdiv(M, BM);
   g.upt = K / 32;
@@ -746,7 +1263,6 @@ int x3_launch(X3Args g, int mode, hipStream_t st) {
   FF_CHECK_ARG(units < (1L << 30), "ff_gemm_x3: problem too large");
   int shape = g_x3_force_shape ? g_x3_force_shape : 1;
   if (units < 2) shape = 1;
-  const int spc = (mode == 1 || mode == 3) ? 2 : 3;   // block slots per CU
   long grid;
   // Hybrid (the default whenever it applies): hw = tiles / CUs whole tiles per CU and the r = tiles % CUs remaining tiles cut
   // into hs K-pieces so that r * hs <= CUs.  Measured on the decode's N = 512 projections a launch of 2.06 tiles per CU then
@@ -757,7 +1273,7 @@ int x3_launch(X3Args g, int mode, hipStream_t st) {
     if (hr * c <= cus && g.upt % c == 0 && g.upt / c >= 2) { hs = c; break; }
   if (!g_x3_force_shape && g_x3_hybrid && hw >= 1 && hr > 0 && hs > 0) {
     g.hyb = 1; g.hw = (int)hw; g.hs = hs; g.cus = cus;
-    g.ha = (spc == 2 || hw == 1) ? 1 : 2;
+    g.ha = (spc == 2 || hw == 1) ? 1 : 2;   // (one slot stays for the K-piece blocks)
     g.nA = cus * g.ha;
     grid = g.nA + hr * hs;
   } else if (shape == 1) {        // whole tiles: contiguous runs of tiles per block
@@ -773,6 +1289,11 @@ int x3_launch(X3Args g, int mode, hipStream_t st) {
     g.rem = (int)(units % grid);
   }
   FF_RETURN_IF(x3_acquire(st, &g));
+  if (f32) {   // (the caller opened the f32 family's profiling scope)
+    if (mode == 1) return dma_f32_launch_mode<BM, 1>(g, (int)grid, st);
+    if (mode == 2) return dma_f32_launch_mode<BM, 2>(g, (int)grid, st);
+    return dma_f32_launch_mode<BM, 0>(g, (int)grid, st);
+  }
   FFProfScope prof(FF_CAT_GEMM_X3, 2.0 * M * N * K, st);
   ff_prof_add_bytes(FF_CAT_GEMM_X3, 4.0 * (double)M * K + 6.0 * (double)N * K + 4.0 * (double)M * N * (g.res ? 2 : 1));
   if (mode == 1) return x3_launch_mode<BM, 1>(g, (int)grid, st);
@@ -797,6 +1318,33 @@ int x3_check_common(const float* A, int lda, const void* w_planes, const float* 
 }
 
 }  // namespace
+
+// ---- f32 family: the dispatcher of ff_gemm.hip hands eligible launches to gemm_dma_f32_kernel ----
+bool ff_gemm_dma_f32_ok(const GemmArgs& a, int batch) {
+  if (batch != 1 || a.K < 64 || (a.K % 32) != 0 || (a.N & 3) != 0 || a.N < 4) return false;
+  if ((a.lda & 3) || (a.ldw & 3) || (a.ldc & 3) || (a.res && (a.ldr & 3))) return false;
+  if (!ff_aligned16(a.A) || !ff_aligned16(a.W) || !ff_aligned16(a.C) || (a.A2 && !ff_aligned16(a.A2)) ||
+      (a.bias && !ff_aligned16(a.bias)) || (a.res && !ff_aligned16(a.res))) return false;
+  if (a.A2 && (a.n_split % 128) != 0) return false;
+  if ((size_t)a.M * a.lda >= ((size_t)1 << 30) || (size_t)a.N * a.ldw >= ((size_t)1 << 30)) return false;
+  if (a.ln_in && (a.K != 512 || a.ln_nseg != 16 || !ff_aligned16(a.ln_in))) return false;
+  if (a.rowtab && ((a.rowtab_cols & 3) || (a.ld_rowtab & 3) || !ff_aligned16(a.rowtab) || a.res)) return false;
+  if (a.ln_out && (a.N & 31)) return false;
+  return true;
+}
+int ff_gemm_dma_f32(const GemmArgs& a, hipStream_t st) {
+  X3Args g;
+  memset(&g, 0, sizeof(g));
+  g.A = a.A; g.A2 = a.A2; g.lda = a.lda;
+  g.W = a.W; g.ldw = a.ldw; g.bias = a.bias; g.res = a.res; g.ldr = a.ldr;
+  g.C = a.C; g.ldc = a.ldc;
+  g.M = a.M; g.N = a.N; g.K = a.K; g.n_split = a.A2 ? a.n_split : a.N; g.act = a.act;
+  g.w_rows = a.N; g.w_row0 = 0;
+  g.ln_in = a.ln_in; g.ln_eps = a.ln_eps;
+  g.rowtab = a.rowtab; g.ld_rowtab = a.ld_rowtab; g.rowtab_div = a.rowtab_div > 0 ? a.rowtab_div : 1; g.rowtab_cols = a.rowtab_cols;
+  g.ln_out = a.ln_out;
+  return x3_launch(g, a.ln_in ? 1 : (a.ln_out ? 2 : 0), st, true);
+}
 
 extern "C" size_t ff_split_weight_bytes(int N, int K) { return (size_t)3 * N * K * sizeof(unsigned short); }
 

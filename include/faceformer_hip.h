@@ -92,7 +92,9 @@ int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div
  * K in {128, 256, 512, 1024} split over four or eight waves; 7 hands it every launch of at most 1024 rows);
  * 9 = pipelined 128x64 with 16-wide K slices (two blocks per CU; 7 hands it the plain projections of at
  * least 4096 rows whose tile count fills the resident block slots evenly), 10 = pipelined 128x128 with
- * 16-wide slices (measurement only).
+ * 16-wide slices (measurement only), 11 = the LDS-DMA kernel (both operands by global_load_lds, transposed accumulators,
+ * 64 x 128 tiles at three blocks per CU, whole tiles + remaining tiles cut into K pieces; K % 32 == 0, K >= 64, N % 4 == 0,
+ * leading dimensions % 4, 16-byte aligned operands; 7 hands it the launches of at least FF_DMA_MIN_ROWS rows).
  * Kernels 6/7 keep an internal 8 MB workspace per (device, stream), allocated at the first launch on
  * that stream.
  * ------------------------------------------------------------------------------------------- */

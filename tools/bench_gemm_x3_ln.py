@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--ms", default="3072,6144,9216,32768,65536")
     args = ap.parse_args()
     E, FF = 512, 1024
-    print("%8s | %-22s | %8s %8s %8s | %8s" % ("M", "projection", "plain", "folded", "fold-epi", "f32 fold"))
+    print("%8s | %-22s | %8s %8s %8s | %8s %8s %8s" % ("M", "projection", "plain", "folded", "fold-epi", "f32 fold", "f32 dma", "dma fold"))
     for M in [int(v) for v in args.ms.split(",")]:
         x = torch.randn(M, E, device="cuda")
         h = torch.randn(M, FF, device="cuda")
@@ -51,14 +51,19 @@ def main():
                                                      row_cols=(t_.size(1) if t_ is not None else 0), out=out), iters)
                 t32 = timeit(lambda: ops.linear_ln(a, w, b, act=act, stats_in=stats, row_table=t_, row_div=256,
                                                    row_cols=(t_.size(1) if t_ is not None else 0), out=out), iters)
+                t11 = timeit(lambda: ops.linear_ln(a, w, b, act=act, stats_in=stats, row_table=t_, row_div=256,
+                                                   row_cols=(t_.size(1) if t_ is not None else 0), out=out, tile=11), iters)
                 cs = w.double().sum(1).float().contiguous()
                 te = timeit(lambda: ops.linear_x3_ln(a, planes, b, act=act, stats_in=stats, row_table=t_, row_div=256,
                                                      row_cols=(t_.size(1) if t_ is not None else 0), out=out, colsum=cs), iters)
             else:
                 tf = timeit(lambda: ops.linear_x3_ln(a, planes, b, residual=res, want_stats=True, out=out), iters)
                 t32 = timeit(lambda: ops.linear_ln(a, w, b, residual=res, want_stats=True, out=out), iters)
+                t11 = timeit(lambda: ops.linear_ln(a, w, b, residual=res, want_stats=True, out=out, tile=11), iters)
                 te = tf
-            print("%8d | %-22s | %8.1f %8.1f %8.1f | %8.1f" % (M, name, flops / tp / 1e12, flops / tf / 1e12, flops / te / 1e12, flops / t32 / 1e12))
+            tpl = timeit(lambda: ops.linear(a, w, b, act=act, residual=res, out=out, tile=11), iters)
+            print("%8d | %-22s | %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f" % (M, name, flops / tp / 1e12, flops / tf / 1e12, flops / te / 1e12,
+                                                                          flops / t32 / 1e12, flops / tpl / 1e12, flops / t11 / 1e12))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Build-container check of ff_gemm_x3.hip's code generation: no scratch access and no s_waitcnt vmcnt(0) inside the MFMA runs
-of any gemm_x3_kernel instantiation.  (The K loop reads its fragments with inline-assembly ds_reads the compiler does not
+of any gemm_x3_kernel / gemm_dma_f32_kernel instantiation.  (The K loop reads its fragments with inline-assembly ds_reads the compiler does not
 track: a spill of such a register before the loop's own lgkmcnt wait would store garbage; a vmcnt(0) would drain the LDS-DMA
 pipeline every slice.)    python tools/check_x3_asm.py"""
 import os
@@ -19,7 +19,7 @@ def main():
                         os.path.join(ROOT, "faceformer_amd", "csrc", "ff_gemm_x3.hip")], check=True, stderr=subprocess.DEVNULL)
         s = open(out).read()
     bad = 0
-    for n in re.findall(r"^(_ZN12_GLOBAL__N_114gemm_x3_kernelILi\d+ELi\dEEEvNS_6X3ArgsE):", s, re.M):
+    for n in re.findall(r"^(_ZN12_GLOBAL__N_1\d+gemm_(?:x3|dma_f32)_kernelILi\d+ELi\dEEEvNS_6X3ArgsE):", s, re.M):
         a = s.index("\n" + n + ":")
         b = s.index("s_endpgm", a)
         body = s[a:b].split("\n")
@@ -36,7 +36,7 @@ def main():
         regs = re.search(re.escape(n) + r"\.num_vgpr, (\d+)", s).group(1)
         scratch = re.search(r"ScratchSize: (\d+)", s[b:b + 4000]).group(1)
         tag = re.search(r"ILi(\d+)ELi(\d)E", n)
-        print("gemm_x3_kernel<%s, %s>: %s VGPRs, %s B scratch (rare paths), MFMA runs %s, scratch ops inside %d, vmcnt(0) inside %d"
+        print(("gemm_dma_f32_kernel" if "dma_f32" in n else "gemm_x3_kernel") + "<%s, %s>: %s VGPRs, %s B scratch (rare paths), MFMA runs %s, scratch ops inside %d, vmcnt(0) inside %d"
               % (tag.group(1), tag.group(2), regs, scratch, [y - x for x, y in runs], sc, vm))
         bad += sc + vm
     return 1 if bad else 0
