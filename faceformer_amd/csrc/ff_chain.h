@@ -22,6 +22,7 @@ struct ff_chain_op {
   } u;
 };
 
+#ifdef FF_EXPERIMENTAL
 bool ff_chain_recording();
 void ff_chain_next_is_independent();   // hint: the next recorded operator may run in the same phase as the previous one
 bool ff_chain_gemm_ok(const GemmArgs& g, int batch);
@@ -41,3 +42,23 @@ int ff_flow_end(hipStream_t st, int* launched);
 bool ff_flow_recording();
 int ff_gemm_flow_launch(const ff_chain_op* dev_ops, int nops, unsigned* ctr, unsigned* done, unsigned* err, int panel_stride,
                         hipStream_t st);
+#else
+// Default build: the persistent-launch experiments (chain / flow launches, step graphs) are compiled OUT -- built, parity-tested
+// and measured slower than launch-per-operator in round 3.  `python -m faceformer_amd.hip.build --experimental`
+// builds libfaceformer_hip_exp.so with them; ff_decode of the default library refuses FF_CHAIN / FF_FLOW / FF_GRAPH.
+inline bool ff_chain_recording() { return false; }
+inline void ff_chain_next_is_independent() {}
+inline bool ff_chain_gemm_ok(const GemmArgs&, int) { return false; }
+inline int ff_chain_record_gemm(const GemmArgs&, int) { return FF_ERR_ARG; }
+inline int ff_chain_record_attention(const ff_attn_desc&) { return FF_ERR_ARG; }
+inline int ff_chain_record_layernorm(const LnArgs&) { return FF_ERR_ARG; }
+inline int ff_chain_record_pointer(const PointerArgs&) { return FF_ERR_ARG; }
+inline int ff_chain_prepare(size_t, hipStream_t) { return FF_OK; }
+inline int ff_chain_begin() { return FF_ERR_ARG; }
+inline void ff_chain_abort() {}
+inline int ff_chain_end(hipStream_t, int* launched) { if (launched) *launched = 0; return FF_OK; }
+inline int ff_chain_check(hipStream_t) { return FF_OK; }
+inline int ff_flow_begin() { return FF_ERR_ARG; }
+inline int ff_flow_end(hipStream_t, int* launched) { if (launched) *launched = 0; return FF_OK; }
+inline bool ff_flow_recording() { return false; }
+#endif

@@ -18,6 +18,7 @@
 //   * residency  = the grid never exceeds the CU count and nothing else is queued on the stream, so every workgroup is
 //                  resident; every poll loop is bounded, a timeout poisons the release word (later boundaries fall
 //                  through) and is reported by ff_decode as an error instead of hanging the device.
+#ifdef FF_EXPERIMENTAL   // (default builds carry none of this: ff_chain.h)
 #include <mutex>
 #include <vector>
 
@@ -515,3 +516,5 @@ int ff_chain_check(hipStream_t st) {
   }
   return FF_OK;
 }
+
+#endif  // FF_EXPERIMENTAL

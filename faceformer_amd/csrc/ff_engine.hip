@@ -685,6 +685,12 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_CHECK_ARG(memory && mask && kv_len && predict && workspace, "ff_decode: null pointer");
   FF_CHECK_ARG(p->variant != FF_PARALLEL || num_input, "ff_decode: num_input required for the parallel variant");
   FF_CHECK_ARG(p->variant != FF_SEQ2SEQ || p->F == 1, "ff_decode: seq2seq decodes one sequence per wireframe");
+#ifndef FF_EXPERIMENTAL
+  FF_CHECK_ARG(!(p->flags & (FF_CHAIN | FF_FLOW | FF_GRAPH)),
+               "ff_decode: FF_CHAIN / FF_FLOW / FF_GRAPH are compiled into the experimental build of the library only "
+               "(python -m faceformer_amd.hip.build --experimental -> libfaceformer_hip_exp.so; measured slower than "
+               "launch-per-operator, DESIGN.md 8)");
+#endif
   FF_CHECK_ARG(!p->stop_fn || (p->flags & FF_NO_STOP) || p->sync_every > 0, "ff_decode: stop_fn needs sync_every > 0");
   // The callback's cadence is a CONTRACT with callers that replay it elsewhere (an idle rank of a sharded decode joins the
   // same host collectives: faceformer_amd/dist.py check_points): the counters of the first n = enq - sync_every steps when

@@ -838,6 +838,7 @@ struct FlowSync {
   int nodep;         // FF_FLOW_NODEP=1 (timing experiments only: WRONG results): operators run without waiting / signalling
 };
 
+#ifdef FF_EXPERIMENTAL
 template <int MODE>
 __device__ __forceinline__ void flow_op(const ff_chain_op* opp_v, unsigned* wait_ctr, unsigned wait_target,
                                         unsigned* done_ctr, unsigned* signal_ctr, unsigned* err) {
@@ -873,6 +874,7 @@ __global__ __launch_bounds__(256, 2) void gemm_flow_kernel(const ff_chain_op* __
     __syncthreads();   // the LDS ring is refilled by the next operator's prologue
   }
 }
+#endif  // FF_EXPERIMENTAL
 
 // ---- stream-K form of the persistent kernel -----------------------------------------------------------------
 // The persistent kernel hands out WHOLE tiles, so a launch whose tile count is not a multiple of the
@@ -1694,6 +1696,7 @@ extern "C" int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split
                              1, 0, 0, 0, stream);
 }
 
+#ifdef FF_EXPERIMENTAL
 // Flow launch of `nops` recorded 64x64-tile projections (descriptors already on the device); called by ff_chain.hip.
 int ff_gemm_flow_launch(const ff_chain_op* dev_ops, int nops, unsigned* ctr, unsigned* done, unsigned* err, int panel_stride,
                         hipStream_t st) {
@@ -1711,3 +1714,4 @@ int ff_gemm_flow_launch(const ff_chain_op* dev_ops, int nops, unsigned* ctr, uns
   FF_CHECK_LAUNCH();
   return FF_OK;
 }
+#endif  // FF_EXPERIMENTAL

@@ -68,6 +68,14 @@ void ff_prof_close(hipStream_t st) {
   if (!g_prof.recs.empty() && g_prof.recs.back().b) (void)hipEventRecord(g_prof.recs.back().b, st);
 }
 
+extern "C" int ff_has_experimental(void) {
+#ifdef FF_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int ff_profile_begin(void) {
   g_prof.recs.clear();
   g_prof.next = 0;

@@ -2,6 +2,9 @@
 plain C-ABI shared object (see include/faceformer_hip.h) linked only against the HIP runtime.
 
     python -m faceformer_amd.hip.build [--force] [--verbose]
+    python -m faceformer_amd.hip.build --experimental    -> libfaceformer_hip_exp.so: the same library with -DFF_EXPERIMENTAL, i.e.
+        with the persistent-launch experiments of round 3 (chain launches, flow launches, step graphs) compiled in; load it
+        with FF_HIP_LIB=<path> (tests/test_parity_golden.py runs their parity tests when the loaded library has them)
 """
 import hashlib
 import os
@@ -29,17 +32,25 @@ def _hipcc():
     return exe
 
 
-def _digest(paths):
+def _digest(paths, flags=None):
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS if flags is None else flags).encode())
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, experimental=False):
     """Compile every HIP source for gfx950 and link the shared library; returns its path."""
+    global FLAGS
+    build_dir, lib_path, flags = BUILD_DIR, LIB_PATH, FLAGS
+    if experimental:
+        build_dir, lib_path, flags = BUILD_DIR + "_exp", LIB_PATH.replace(".so", "_exp.so"), FLAGS + ["-DFF_EXPERIMENTAL"]
+    return _build(build_dir, lib_path, flags, force, verbose)
+
+
+def _build(BUILD_DIR, LIB_PATH, FLAGS, force, verbose):
     os.makedirs(BUILD_DIR, exist_ok=True)
     headers = [os.path.join(INCLUDE, "faceformer_hip.h"), os.path.join(CSRC, "ff_common.h"), os.path.join(CSRC, "ff_device.h"), os.path.join(CSRC, "ff_chain.h")]
     hipcc = _hipcc()
@@ -49,7 +60,7 @@ def build(force=False, verbose=False):
         spath = os.path.join(CSRC, src)
         obj = os.path.join(BUILD_DIR, src.replace(".hip", ".o"))
         stamp = obj + ".sha"
-        dig = _digest([spath] + headers)
+        dig = _digest([spath] + headers, FLAGS)
         old = open(stamp).read() if os.path.exists(stamp) else ""
         if force or not os.path.exists(obj) or old != dig:
             cmd = [hipcc] + FLAGS + ["-c", spath, "-o", obj]
@@ -69,5 +80,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv,
+                 experimental="--experimental" in sys.argv)
     print(path)

@@ -112,6 +112,7 @@ SIGNATURES = {
     "ff_version": (C.c_int, []),
     "ff_last_error": (C.c_char_p, []),
     "ff_device_count": (C.c_int, []),
+    "ff_has_experimental": (C.c_int, []),
     "ff_profile_begin": (C.c_int, []),
     "ff_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "ff_profile_bytes": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

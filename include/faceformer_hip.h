@@ -44,6 +44,10 @@ int ff_version(void);
 const char* ff_last_error(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int ff_device_count(void);
+/* 1 when the library was built with -DFF_EXPERIMENTAL (python -m faceformer_amd.hip.build --experimental): the persistent-launch
+ * experiments of round 3 -- chain launches, flow launches, step graphs (ff_decode flags FF_CHAIN / FF_FLOW / FF_GRAPH) -- are
+ * compiled in; 0 for the default library, whose ff_decode refuses those flags. */
+int ff_has_experimental(void);
 
 /* Measurement hooks (bench.py roofline leg; not on the product path).  Between begin and end every
  * op launch of this library is bracketed by a hipEvent pair on its stream; end() synchronises the
@@ -355,6 +359,8 @@ enum ff_decode_flags {
                                 produces a LayerNorm input leaves per-row segment statistics, the GEMM that consumes
                                 it normalises its A rows while staging them (ff_gemm_f32_ln).  Needs the folded
                                 weights (ln1_w ... proj_fold_b) and E, FF multiples of 64, 128 <= E <= 512; otherwise ignored */
+  /* The three flags below exist in the EXPERIMENTAL build only (ff_has_experimental): built, parity-tested on every golden and
+     measured slower than launch-per-operator; the default library's ff_decode returns FF_ERR_ARG for them. */
   FF_CHAIN = 64,             /* chain launches (ff_chain.hip): a decode step with at most chain_max_rows active rows, and the
                                 last layer's newest-position tail + pointer head of every larger step, run as ONE persistent
                                 launch whose operators are separated by grid-wide phase boundaries instead of kernel boundaries

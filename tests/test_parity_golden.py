@@ -178,7 +178,7 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
 
 @pytest.mark.parametrize("chain_rows", [0, 64, 1 << 20])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_parity_with_chain_launches(hip_lib, name, chain_rows):
+def test_golden_parity_with_chain_launches(experimental_lib, name, chain_rows):
     """FF_CHAIN: decode steps with at most `chain_rows` active rows (0 = the default 1024; 1 << 20 = every step of every
     golden) run as ONE persistent launch whose operators -- the same device code with agent-coherent accesses -- are
     separated by grid-wide phase boundaries; larger steps hand their last-layer tail + pointer head to a chain launch.
@@ -199,7 +199,7 @@ def test_golden_parity_with_chain_launches(hip_lib, name, chain_rows):
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak", "par_full_n40_gain4",
                                   "seq_small_gain4", "seq_small_eos", "par_small_extramask", "par_full_B256_default"])
-def test_golden_parity_with_step_graphs(hip_lib, name):
+def test_golden_parity_with_step_graphs(experimental_lib, name):
     """FF_GRAPH: the first decode of an argument set launches plainly, the second captures its steps into hipGraphs (and
     runs them), later ones replay.  Every pass must meet the golden's bars, and the three passes must agree bit for bit
     (the same kernels with the same arguments) -- including the stop step of the early-stopping goldens, which the host
@@ -233,7 +233,7 @@ def test_golden_parity_with_step_graphs(hip_lib, name):
 
 @pytest.mark.parametrize("flow_rows", [0, 1])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_parity_with_flow_launches(hip_lib, name, flow_rows):
+def test_golden_parity_with_flow_launches(experimental_lib, name, flow_rows):
     """FF_FLOW: the dependent projections between two attention operators run inside one persistent launch each, tile by tile
     behind row-panel dependency counters (steps with at least `flow_rows` active rows; 0 = the default 1025, 1 = every step of
     every golden incl. the two-row ones).  Same bars as the launch-per-operator path."""
@@ -272,11 +272,29 @@ def test_engine_options_do_not_change_results(hip_lib, name, flags, chunk, sync,
     host sync period are pure scheduling choices."""
     case, z = load_golden(name)
     sd, batch = case_weights_and_batch(case)
+    if (flags & 64) and not hip_lib.ff_has_experimental():
+        pytest.skip("FF_CHAIN: the experimental build only")
     model = build_model(case, sd, "cuda")
     model.decode_flags, model.chunk_wireframes, model.sync_every = flags, chunk, sync
     model.chunk_seqs, model.num_streams = cseq, nstr
     out = run_traced(model, case, batch_to(batch, "cuda"))
     compare_with_golden(case, z, out)
+
+
+def test_default_library_refuses_the_experimental_launch_forms(hip_lib):
+    """FF_CHAIN / FF_FLOW / FF_GRAPH are compiled into libfaceformer_hip_exp.so only: the default library says so."""
+    if hip_lib.ff_has_experimental():
+        pytest.skip("experimental build loaded")
+    from faceformer_amd.hip import lib as L
+    case, z = load_golden("par_small_gain4")
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    for flag in (L.FF_CHAIN, L.FF_FLOW, L.FF_GRAPH):
+        model.decode_flags = model.decode_flags | flag
+        with pytest.raises(L.HipExtensionError, match="experimental build"):
+            with torch.no_grad():
+                model(batch_to(batch, "cuda"))
+        model.decode_flags = model.decode_flags & ~flag
 
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_full_n40_default", "seq_small_default"])
