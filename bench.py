@@ -160,7 +160,16 @@ def gemm_roofline(prof, wall_ms, empty_us, traffic=None, traffic_src=None):
     return roof, extra
 
 
-def x3_roofline(prof, wall_ms):
+def _committed_traffic(fname):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", fname)))
+    if not cands:
+        return None, None
+    with open(cands[-1]) as f:
+        return json.load(f)["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+
+
+def x3_roofline(prof, wall_ms, with_traffic=False):
     """`roofline` of the 3 x bf16 split projection kernel (the package default's dominant kernel) from one profiled pass:
     algorithmic fp32 flops (2MNK) of its launches / their summed duration net of the event bracket, against the bf16 matrix
     peak divided by the six bf16 products an fp32 product costs."""
@@ -174,7 +183,9 @@ def x3_roofline(prof, wall_ms):
     return {
         "kernel": "gemm_x3_kernel (ff_gemm_x3.hip): fp32-accurate product as six bf16 MFMA partial products per K slice",
         "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
-        "traffic": None, "alg_bytes_per_launch": alg_bytes[i3] / max(1, cnt[i3]), "launches_per_step": cnt[i3],
+        "traffic": _committed_traffic("traffic_x3.json")[0] if with_traffic else None,
+        "traffic_unit": "HBM bytes per launch", "traffic_source": _committed_traffic("traffic_x3.json")[1] if with_traffic else None,
+        "alg_bytes_per_launch": alg_bytes[i3] / max(1, cnt[i3]), "launches_per_step": cnt[i3],
         "avg_launch_us": 1e3 * net[i3] / max(1, cnt[i3]), "alg_flop_per_launch": work[i3] / max(1, cnt[i3]),
         "share_of_kernel_time": net[i3] / sum(net) if sum(net) > 0 else None,
         "event_bracket_us_per_launch": bracket_us,
@@ -544,7 +555,8 @@ def main():
             def once3():
                 with torch.no_grad():
                     model(dict(batch))
-            roof3 = x3_roofline(profile_once(lib, L, once3), 1e3 * dt3 / args.steps)
+            roof3 = x3_roofline(profile_once(lib, L, once3), 1e3 * dt3 / args.steps,
+                                with_traffic=(not cfgE and args.edges == 256 and W == 1))
         model.x3_min_rows = 0
         step()      # (re-binds the engine without the bf16 planes for the profiling leg below)
         fence()

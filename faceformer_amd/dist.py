@@ -358,7 +358,8 @@ def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominan
     for k, i in enumerate(mine):
         n = int(inputs["num_input"][i]) if "num_input" in inputs else int((~inputs["input_mask"][i]).sum())
         fn = FZ.parse_parallel_faces if parallel else FZ.parse_faces
-        pf, lf = fn(pred[k], labels[k], n, model.token)
+        # (parallel: the wireframe's own anchor sequences, not the batch-wide padding-anchor rows behind them)
+        pf, lf = fn(pred[k][:n] if parallel else pred[k], labels[k], n, model.token)
         if is_coedge and edges is not None:
             pf = FZ.postprocess_faces(pf, edges[i], pairings[i] if pairings else {}, tol)
             lf = FZ.postprocess_faces(lf, edges[i], pairings[i] if pairings else {}, tol)

@@ -44,6 +44,10 @@ def decode_batch(model, batch):
 def record_of(cfg, raw, item, pred, parallel):
     """(JSON text, (precision, recall, type accuracy)) of one decoded sample (reference trainer.py:118-136, 210-300)."""
     parse = FZ.parse_parallel_faces if parallel else FZ.parse_faces
+    if parallel:
+        # the wireframe's OWN anchor sequences: in a batch `predict` is padded to F = max(num_input) rows per wireframe with
+        # padding-anchor sequences (reference model_para.py:204-205), which the reference's one-sample test batches never contain
+        pred = pred[: int(item["num_input"])]
     pf, lf = parse(pred, item["label"], len(raw["edges"]), cfg.model.token)
     if cfg.post_process.is_coedge:
         pairings = raw.get("pairings", {})

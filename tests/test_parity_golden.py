@@ -554,6 +554,8 @@ def test_external_stop_rule_through_the_c_callback(hip_lib, name, period):
 
     def broken(counts):
         raise RuntimeError("rule failed")
+    if not cps:      # a period so long that this decode has no check point: the rule is never asked
+        return
     with pytest.raises(RuntimeError, match="rule failed"):
         if parallel:
             eng.decode(memory, mask, kv_len, variant, F=max(ni), num_input=ni, **dict(kw, stop_callback=broken))

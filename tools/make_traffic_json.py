@@ -38,6 +38,20 @@ def main():
     }
     with open(os.path.join(d, "traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
+    # the package-default form's dominant kernel (its own PMC passes: pmc_fetch_x3.md / pmc_write_x3.md)
+    fx, wx = os.path.join(d, "pmc_fetch_x3.md"), os.path.join(d, "pmc_write_x3.md")
+    if os.path.exists(fx) and os.path.exists(wx):
+        fetch, write = table(fx, "FETCH_SIZE"), table(wx, "WRITE_SIZE")
+        names = [k for k in fetch if k.startswith("gemm_x3")]
+        if names:
+            n = sum(fetch[k][0] for k in names)
+            f = sum(fetch[k][1] for k in names) / n
+            w = sum(write[k][1] for k in names if k in write) / max(1, sum(write[k][0] for k in names if k in write))
+            with open(os.path.join(d, "traffic_x3.json"), "w") as fh:
+                json.dump({"kernel": "3 x bf16 split GEMM (" + ", ".join("%s x%d" % (k, fetch[k][0]) for k in names) + ")",
+                           "source": "%s/pmc_fetch_x3.md + pmc_write_x3.md (command in %s/command_x3.txt)" % (d, d),
+                           "dispatches": n, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+                           "gfx950_fetch_correction": 2.0, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}, fh, indent=1)
     print(json.dumps(out, indent=1))
 
 
