@@ -359,7 +359,8 @@ def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominan
         n = int(inputs["num_input"][i]) if "num_input" in inputs else int((~inputs["input_mask"][i]).sum())
         fn = FZ.parse_parallel_faces if parallel else FZ.parse_faces
         # (parallel: the wireframe's own anchor sequences, not the batch-wide padding-anchor rows behind them)
-        pf, lf = fn(pred[k][:n] if parallel else pred[k], labels[k], n, model.token)
+        own = FZ.apply_own_stop_rule(pred[k][:n] if parallel else pred[k], model.token, parallel)   # as a one-sample decode leaves them
+        pf, lf = fn(own, labels[k], n, model.token)
         if is_coedge and edges is not None:
             pf = FZ.postprocess_faces(pf, edges[i], pairings[i] if pairings else {}, tol)
             lf = FZ.postprocess_faces(lf, edges[i], pairings[i] if pairings else {}, tol)

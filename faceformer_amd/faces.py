@@ -64,6 +64,29 @@ def _parallel_rows(rows, token, num_edges):
     return faces
 
 
+def apply_own_stop_rule(predict, token, parallel, eos=None):
+    """Tokens of ONE wireframe as a one-sample decode leaves them: zero behind the step at which the reference's loop would
+    have stopped had the batch held only this wireframe.  In a batch the loop runs until EVERY wireframe is done (parallel
+    model: the first step at which no sequence of the batch selects an edge, model_para.py:232; seq2seq: all EOS emitted,
+    model.py:207-210), so a sequence that had not produced its terminator when its own wireframe's rule fired keeps decoding and
+    may still produce one -- the one-sample decode (the reference's test loader, trainer.py:51) never sees those tokens.
+    predict: [F, T] (parallel: the wireframe's own anchor rows) or [T] (seq2seq).  Returns a copy."""
+    p = np.array(predict, dtype=np.int64, copy=True)
+    ntok = _tok(token, "len", 4)
+    if parallel:
+        rows = p.reshape(-1, p.shape[-1])
+        for j in range(1, rows.shape[1]):
+            if (rows[:, j] < ntok).all():
+                rows[:, j + 1:] = 0
+                break
+        return rows.reshape(p.shape)
+    e = _tok(token, "EOS", 3) if eos is None else eos
+    hit = np.nonzero(p[1:] == e)[0]
+    if hit.size:
+        p[hit[0] + 2:] = 0
+    return p
+
+
 def parse_parallel_faces(predicts, labels, num_edges, token):
     """One face per row: tokens up to and including the first face-type token (a special token in
     [face_type_offset, len)); the face type is that token minus the offset; edge indices are the

@@ -10,8 +10,9 @@ under logs/<name>/<version>/json/, printing the running mean decode time and pre
 
 --batch-size N (extension; the reference's test loader is fixed at 1, trainer.py:51): N samples per `model(batch)`
 call, i.e. the micro-batched engine -- 128 wireframes per call run at 0.84 of the f32 matrix peak, one at 0.63
-(DESIGN.md 5).  The records do not depend on N: a wireframe's parsed faces read its own sequences up to their
-own terminators, which neither the batch-wide anchor padding F nor the batch-wide stop step touches.
+(DESIGN.md 5).  The records do not depend on N: a wireframe's faces are parsed from its OWN anchor rows (not the
+batch-wide padding-anchor rows behind them) up to its OWN stop step (faces.apply_own_stop_rule: in a batch the
+reference's loop runs on until every wireframe is done), i.e. from exactly the tokens a one-sample decode leaves.
 
 Under torch.distributed.run every rank decodes a contiguous share of the samples on its own GPU; the JSON
 records are all-gathered (faceformer_amd.dist.gather_json_records: RCCL on GPUs, gloo on CPU) and rank 0
@@ -48,6 +49,8 @@ def record_of(cfg, raw, item, pred, parallel):
         # the wireframe's OWN anchor sequences: in a batch `predict` is padded to F = max(num_input) rows per wireframe with
         # padding-anchor sequences (reference model_para.py:204-205), which the reference's one-sample test batches never contain
         pred = pred[: int(item["num_input"])]
+    # ... and their tokens up to the wireframe's OWN stop step (in a batch the loop runs on until every wireframe is done)
+    pred = FZ.apply_own_stop_rule(pred, cfg.model.token, parallel)
     pf, lf = parse(pred, item["label"], len(raw["edges"]), cfg.model.token)
     if cfg.post_process.is_coedge:
         pairings = raw.get("pairings", {})

@@ -130,3 +130,21 @@ def test_coedge_branch_end_to_end_on_reference_tokens():
         assert [[t, list(f)] for t, f in met["predictions"]] == smp["pred_faces"]
         assert sorted([t, list(f)] for t, f in met["labels"]) == sorted(smp["label_faces"])
         assert met["precision"] == smp["precision"] and met["recall"] == smp["recall"]
+
+
+def test_own_stop_rule_restores_the_one_sample_tokens():
+    """In a batch the reference's loop runs until every wireframe is done; a one-sample decode stops at the wireframe's own
+    rule.  apply_own_stop_rule cuts a wireframe's rows back to what the one-sample decode leaves (main.py --batch-size N,
+    dist.decode_to_face_json): parallel = the first step at which none of its sequences selects an edge, seq2seq = its EOS."""
+    import types
+    tok = types.SimpleNamespace(PAD=0, SOS=1, SEP=2, EOS=3, DIR0=4, DIR1=5, len=4, face_type_offset=1)
+    rows = np.array([[5, 6, 2, 9, 1, 0], [6, 7, 0, 8, 2, 0]])          # step 2: both below 4 -> the own loop stops there
+    cut = FZ.apply_own_stop_rule(rows, tok, True)
+    assert cut.tolist() == [[5, 6, 2, 0, 0, 0], [6, 7, 0, 0, 0, 0]] and rows[0, 3] == 9     # a copy
+    keep = np.array([[5, 6, 7, 2, 9, 9], [6, 7, 0, 8, 1, 0]])          # never all below 4 in one step: untouched
+    assert FZ.apply_own_stop_rule(keep, tok, True).tolist() == keep.tolist()
+    assert FZ.apply_own_stop_rule(np.array([1, 7, 8, 3, 9, 3, 0]), tok, False).tolist() == [1, 7, 8, 3, 0, 0, 0]
+    # the sequence that had not terminated at the own stop step parses to the same (typeless) face either way
+    a, _ = FZ.parse_parallel_faces(cut, cut, 8, tok)
+    b, _ = FZ.parse_parallel_faces(FZ.apply_own_stop_rule(cut, tok, True), cut, 8, tok)
+    assert a == b
