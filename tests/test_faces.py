@@ -139,6 +139,7 @@ def test_own_stop_rule_restores_the_one_sample_tokens():
     import types
     tok = types.SimpleNamespace(PAD=0, SOS=1, SEP=2, EOS=3, DIR0=4, DIR1=5, len=4, face_type_offset=1)
     rows = np.array([[5, 6, 2, 9, 1, 0], [6, 7, 0, 8, 2, 0]])          # step 2: both below 4 -> the own loop stops there
+    FZ = F
     cut = FZ.apply_own_stop_rule(rows, tok, True)
     assert cut.tolist() == [[5, 6, 2, 0, 0, 0], [6, 7, 0, 0, 0, 0]] and rows[0, 3] == 9     # a copy
     keep = np.array([[5, 6, 7, 2, 9, 9], [6, 7, 0, 8, 1, 0]])          # never all below 4 in one step: untouched
