@@ -33,10 +33,11 @@ def main():
         runs.append((start, prev))
         sc = sum(sum(1 for l in body[x:y] if "scratch_" in l) for x, y in runs)
         vm = sum(sum(1 for l in body[x:y] if "vmcnt(0)" in l) for x, y in runs)
-        regs = re.search(re.escape(n) + r"\.num_vgpr, (\d+)", s).group(1)
-        scratch = re.search(r"ScratchSize: (\d+)", s[b:b + 4000]).group(1)
+        desc = s[s.index(".amdhsa_kernel " + n):]
+        regs = re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1)
+        scratch = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1)
         tag = re.search(r"ILi(\d+)ELi(\d)E", n)
-        print(("gemm_dma_f32_kernel" if "dma_f32" in n else "gemm_x3_kernel") + "<%s, %s>: %s VGPRs, %s B scratch (rare paths), MFMA runs %s, scratch ops inside %d, vmcnt(0) inside %d"
+        print(("gemm_dma_f32_kernel" if "dma_f32" in n else "gemm_x3_kernel") + "<%s, %s>: %s VGPRs, %s B scratch (tile-end paths), MFMA runs %s, scratch ops inside %d, vmcnt(0) inside %d"
               % (tag.group(1), tag.group(2), regs, scratch, [y - x for x, y in runs], sc, vm))
         bad += sc + vm
     return 1 if bad else 0
