@@ -1271,10 +1271,11 @@ int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
   int hs = 0;
   for (int c = 8; c >= 2; c >>= 1)
     if (hr * c <= cus && g.upt % c == 0 && g.upt / c >= 2) { hs = c; break; }
-  if (!g_x3_force_shape && g_x3_hybrid && hw >= 1 && hr > 0 && hs > 0) {
+  static const int small_split = getenv("FF_X3_SMALL_SPLIT") ? atoi(getenv("FF_X3_SMALL_SPLIT")) : 0;   // (probe: K-pieces for launches below one tile per CU)
+  if (!g_x3_force_shape && g_x3_hybrid && ((hw >= 1 && hr > 0) || (small_split && hw == 0 && hr * 2 <= cus)) && hs > 0) {
     g.hyb = 1; g.hw = (int)hw; g.hs = hs; g.cus = cus;
     g.ha = (spc == 2 || hw == 1) ? 1 : 2;   // (one slot stays for the K-piece blocks)
-    g.nA = cus * g.ha;
+    g.nA = hw == 0 ? 0 : cus * g.ha;
     grid = g.nA + hr * hs;
   } else if (shape == 1) {        // whole tiles: contiguous runs of tiles per block
     grid = tiles < slots ? tiles : slots;
