@@ -326,7 +326,7 @@ struct RkState {
   f32x16 o0, o1;
 };
 
-__global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles, int w_old, int w_young) {
+__global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles, int w_old, int w_young, int phase_knob) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Ks = lds;                       // [key][64], 16-byte chunks XOR-swizzled with (key & 15)
   float* const Vs = lds + RK_KEYS * 64;        // [key][64]
@@ -404,6 +404,11 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
     if (tid < tiles_max * 32) Ms[tid] = (tid >= nk || mbyte != 0) ? -INFINITY : 0.f;
     __syncthreads();   // (waits for the LDS-DMA: it counts in vmcnt)
     FF_EXP_ASTAMP(1);
+    // probe knobs (FF_RK_PHASE): de-phase the two waves of a SIMD -- 1: the younger waves (4..7) at priority 1, 2: they start
+    // ~1500 cycles late, 3: both, 4: the OLDER waves at priority 1
+    if ((phase_knob & 1) && phase_knob < 4 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (phase_knob == 4 && wave < 4) __builtin_amdgcn_s_setprio(1);
+    if ((phase_knob & 2) && phase_knob < 4 && wave >= 4) __builtin_amdgcn_s_sleep(23);
 
     auto process = [&](int qt, int kt0, int kt1, bool fetched, RkState& st) {
       const int qi = qt * 32 + l32;
@@ -671,8 +676,9 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     const int nblocks = P <= 256 ? P * c : 256;
     static const int w_old = getenv("FF_RK_SPLIT_OLD") ? atoi(getenv("FF_RK_SPLIT_OLD")) : 1;      // (probe knobs: tools/run_r04_attn.sh)
     static const int w_young = getenv("FF_RK_SPLIT_YOUNG") ? atoi(getenv("FF_RK_SPLIT_YOUNG")) : 1;
+    static const int phase_knob = getenv("FF_RK_PHASE") ? atoi(getenv("FF_RK_PHASE")) : 0;
     hipLaunchKernelGGL(attention_resident_kernel, dim3(nblocks), dim3(64 * RK_NW), lds_bytes, st, d, P, c, qt32,
-                       w_old > 0 ? w_old : 1, w_young > 0 ? w_young : 1);
+                       w_old > 0 ? w_old : 1, w_young > 0 ? w_young : 1, phase_knob);
     FF_CHECK_LAUNCH();
     return FF_OK;
   }

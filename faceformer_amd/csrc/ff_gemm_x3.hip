@@ -1206,7 +1206,6 @@ int x3_acquire(hipStream_t st, X3Args* out) {
 
 // tuning / tests: force the launch shape (0 auto, 1 whole tiles, 2 unit ranges)
 int g_x3_force_shape = 0;
-int g_x3_hybrid = 1;   // 0: never the hybrid launch (ff_set_x3_tuning(3))
 
 template <int BM, int MODE>
 int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
@@ -1272,7 +1271,7 @@ int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
   for (int c = 8; c >= 2; c >>= 1)
     if (hr * c <= cus && g.upt % c == 0 && g.upt / c >= 2) { hs = c; break; }
   static const int small_split = getenv("FF_X3_SMALL_SPLIT") ? atoi(getenv("FF_X3_SMALL_SPLIT")) : 0;   // (probe: K-pieces for launches below one tile per CU)
-  if (!g_x3_force_shape && g_x3_hybrid && ((hw >= 1 && hr > 0) || (small_split && hw == 0 && hr * 2 <= cus)) && hs > 0) {
+  if (!g_x3_force_shape && ((hw >= 1 && hr > 0) || (small_split && hw == 0 && hr * 2 <= cus)) && hs > 0) {
     g.hyb = 1; g.hw = (int)hw; g.hs = hs; g.cus = cus;
     g.ha = (spc == 2 || hw == 1) ? 1 : 2;   // (one slot stays for the K-piece blocks)
     g.nA = hw == 0 ? 0 : cus * g.ha;
@@ -1368,7 +1367,6 @@ extern "C" int ff_x3_prepare_stream(hipStream_t st) {
 extern "C" int ff_set_x3_tuning(int shape) {
   FF_CHECK_ARG(shape >= 0 && shape <= 2, "ff_set_x3_tuning: shape in {0, 1, 2}");
   g_x3_force_shape = shape;
-  g_x3_hybrid = 1;
   ff_tuning_changed();
   return FF_OK;
 }
