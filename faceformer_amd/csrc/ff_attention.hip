@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
         s[r] = v;
         tmax = fmaxf(tmax, v);
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
+      tmax = ff_halves_max(tmax);
       const float m_new = fmaxf(m_run, tmax);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = ff_exp2(m_run - m_safe);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
     }
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, FF_WAVE);
+  const float l_tot = ff_halves_sum(l_run);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (q_valid) {
     float* op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
@@ -296,7 +296,7 @@ constexpr int RK_KEYS = 288;                     // 9 key tiles
 constexpr int RK_NW = 8;
 constexpr int RK_REC = 34 * 64;                  // one partial record: O[32 regs][64 lanes], m[64], l[64]
 constexpr int RK_LDS_FLOATS = RK_KEYS * 128 + RK_KEYS;
-static_assert(2 * RK_NW * RK_REC <= RK_KEYS * 128, "records must fit the K/V area");
+static_assert(RK_NW * RK_REC <= RK_KEYS * 128, "records must fit the K/V area");
 
 // V operand reads of the K/V-resident kernel, issued by hand (see the P.V loop): rows r = 2 PR, 2 PR + 1 of the accumulator layout
 // ((r & 3) + 8 (r >> 2) key rows of 64 floats past `va`), columns l32 and 32 + l32 -> dst[0..3].
@@ -326,7 +326,8 @@ struct RkState {
   f32x16 o0, o1;
 };
 
-__global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles, int w_old, int w_young, int phase_knob) {
+__global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles, int w_old, int w_young, int phase_knob,
+                                                                          float* __restrict__ scratch) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Ks = lds;                       // [key][64], 16-byte chunks XOR-swizzled with (key & 15)
   float* const Vs = lds + RK_KEYS * 64;        // [key][64]
@@ -410,90 +411,148 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
     if (phase_knob == 4 && wave < 4) __builtin_amdgcn_s_setprio(1);
     if ((phase_knob & 2) && phase_knob < 4 && wave >= 4) __builtin_amdgcn_s_sleep(23);
 
+    // ---- one query tile x key tiles [kt0, kt1), software-pipelined inside the wave ----
+    // The matrix pipe is the unit to keep busy: an item is 33 + 32 MFMAs (64 cycles each) and ~600 cycles of softmax VALU work
+    // between them, and two waves per SIMD that alternate MFMAs fall into lock step -- both in the softmax at the same time,
+    // the pipe idle (phase probe, round 3: 9.9 k cycles per pair of items for 8.2 k of MFMA time, and the younger wave of a SIMD
+    // finishes 11-25 k cycles after the older one).  So the wave itself overlaps them: while the P.V products of key tile kt
+    // issue, the VALU turns the scores of tile kt+1 (computed just before) into weights.  Two score register sets (sa / sb)
+    // alternate roles; the arithmetic and its order per query are unchanged (rescale by alpha(kt+1) follows P.V(kt)).
+    auto s_tile = [&](int kt, f32x16& s) {
+      // S^T tile: 32 keys x 32 queries.  K fragments: one ds_read_b128 per four MFMAs, read by hand two groups ahead (left to the
+      // compiler each group was "read, wait, 4 MFMAs").  Chunk cg of row l32 lives at byte ka0 ^ (cg << 4), ka0 = row base |
+      // ((8 half) ^ (l32 & 15)) << 4.  The additive key bias (0 / -inf) is the first product: A = bias of key l32 at k = 0,
+      // B = 1 at k = 0 (0 + x is exact, -inf absorbs: the same values as adding it afterwards, without 16 LDS reads in the softmax).
+      const unsigned ka0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(Ks + (kt * 32 + l32) * 64) +
+                           ((unsigned)((half * 8) ^ (l32 & 15)) << 4);
+      f32x4 kf[2];
+      float msv;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(msv) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const float*)(Ms + kt * 32 + l32)) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0]) : "v"(ka0) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(kf[1]) : "v"(ka0 ^ 16u) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(msv));
+      f32x16 z;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) z[e] = 0.f;
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(half == 0 ? msv : 0.f, half == 0 ? 1.f : 0.f, z, 0, 0, 0);
+#pragma unroll
+      for (int cg = 0; cg < 8; ++cg) {
+        if (cg + 1 < 8) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kf[cg & 1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[cg & 1]));
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg & 1].x, qraw[cg].x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg & 1].y, qraw[cg].y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg & 1].z, qraw[cg].z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cg & 1].w, qraw[cg].w, s, 0, 0, 0);
+        if (cg + 2 < 8) asm volatile("ds_read_b128 %0, %1" : "=v"(kf[cg & 1]) : "v"(ka0 ^ ((unsigned)(cg + 2) << 4)) : "memory");
+      }
+    };
+    // the softmax of one score tile in four pieces (so that they can sit between the MFMA groups of the previous tile's P.V):
+    //   rows [r0, r1): causal mask + running tile max;  then max over the halves, new running max, alpha;
+    //   rows [r0, r1): weights + their sum;              then (after the previous P.V): l, m, rescale of O
+    struct Soft { float tmax, m_new, m_safe, alpha, psum; };
+    auto soft_max_rows = [&](f32x16& s, Soft& sv, int r0, int r1) {
+#pragma unroll
+      for (int r = r0; r < r1; ++r) sv.tmax = fmaxf(sv.tmax, s[r]);
+      asm volatile("" : "+v"(sv.tmax));   // (here, not sunk to the use)
+    };
+    auto soft_scale = [&](const RkState& st, Soft& sv) {
+      sv.tmax = ff_halves_max(sv.tmax);
+      sv.m_new = fmaxf(st.m, sv.tmax);
+      sv.m_safe = (sv.m_new == -INFINITY) ? 0.f : sv.m_new;
+      sv.alpha = ff_exp2(st.m - sv.m_safe);
+      asm volatile("" : "+v"(sv.alpha), "+v"(sv.m_safe));
+    };
+    auto soft_exp_rows = [&](f32x16& s, Soft& sv, int r0, int r1) {
+#pragma unroll
+      for (int r = r0; r < r1; ++r) {
+        const float pp = ff_exp2(s[r] - sv.m_safe);
+        s[r] = pp;
+        sv.psum += pp;
+        asm volatile("" : "+v"(s[r]));    // (here: the optimiser sinks the exponentials to their use behind the P.V loop otherwise)
+      }
+    };
+    auto soft_commit = [&](RkState& st, const Soft& sv) {
+      st.l = st.l * sv.alpha + sv.psum;
+      st.m = sv.m_new;
+      if (!__all(sv.alpha == 1.0f)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st.o0[e] *= sv.alpha; st.o1[e] *= sv.alpha; }
+      }
+    };
+    // O^T += V^T P^T for key tile kt (weights in p); with `soft`: the scores sn of tile kt + 1 become weights meanwhile.
+    // The V values of two key rows (four reads) are in flight ahead of the four MFMAs that take them (left to the compiler every
+    // MFMA had its own read-and-wait in front of it: the kernel sits at the register limit, loads sink to their uses).
+    auto pv_tile = [&](int kt, const f32x16& p, const bool soft, f32x16& sn, RkState& st) {
+      const unsigned va = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(Vs + (kt * 32 + 4 * half) * 64 + l32);
+      float x[2][4];
+      Soft sv;
+      sv.tmax = -INFINITY; sv.psum = 0.f; sv.m_new = 0.f; sv.m_safe = 0.f; sv.alpha = 1.f;
+      rk_read_v<0>(x[0], va);
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {   // pair pr: accumulator rows r = 2 pr, 2 pr + 1
+        if (pr + 1 < 8) {
+          rk_read_v_dyn(x[(pr + 1) & 1], va, pr + 1);
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[pr & 1][0]), "+v"(x[pr & 1][1]), "+v"(x[pr & 1][2]), "+v"(x[pr & 1][3]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[pr & 1][0]), "+v"(x[pr & 1][1]), "+v"(x[pr & 1][2]), "+v"(x[pr & 1][3]));
+        }
+        st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][0], p[2 * pr], st.o0, 0, 0, 0);
+        st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][1], p[2 * pr], st.o1, 0, 0, 0);
+        st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][2], p[2 * pr + 1], st.o0, 0, 0, 0);
+        st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][3], p[2 * pr + 1], st.o1, 0, 0, 0);
+        if (soft) {   // (constant after inlining) the next tile's softmax, a slice per MFMA group
+          if (pr < 2) soft_max_rows(sn, sv, 8 * pr, 8 * pr + 8);
+          else if (pr == 2) soft_scale(st, sv);
+          else if (pr < 7) soft_exp_rows(sn, sv, 4 * (pr - 3), 4 * (pr - 3) + 4);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (soft) soft_commit(st, sv);
+    };
     auto process = [&](int qt, int kt0, int kt1, bool fetched, RkState& st) {
-      const int qi = qt * 32 + l32;
       if (!fetched) fetch_q(qt);
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) qraw[cc] *= qscale;   // in place: one register set for the queries
       st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { st.o0[e] = 0.f; st.o1[e] = 0.f; }
-      for (int kt = kt0; kt < kt1; ++kt) {
-        // S^T tile: 32 keys x 32 queries
-        f32x16 sacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-        const float* krow_p = Ks + (kt * 32 + l32) * 64;
-#pragma unroll
-        for (int cg = 0; cg < 8; ++cg) {
-          const f32x4 kf = *reinterpret_cast<const f32x4*>(krow_p + (((half * 8 + cg) ^ (l32 & 15)) << 2));
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qraw[cg].x, sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qraw[cg].y, sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qraw[cg].z, sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qraw[cg].w, sacc, 0, 0, 0);
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int keyl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = sacc[r] + Ms[keyl];
-          if (d.causal && keyl > qi) v = -INFINITY;
-          sacc[r] = v;
-          tmax = fmaxf(tmax, v);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
-        const float m_new = fmaxf(st.m, tmax);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = ff_exp2(st.m - m_safe);
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pp = ff_exp2(sacc[r] - m_safe);
-          sacc[r] = pp;
-          psum += pp;
-        }
-        st.l = st.l * alpha + psum;
-        st.m = m_new;
-        if (!__all(alpha == 1.0f)) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
-        }
-        // The V values of two key rows (four reads) are in flight ahead of the four MFMAs that take them.  Left to the compiler
-        // every MFMA had its own read-and-wait in front of it (the kernel sits at the register limit, loads sink to their uses):
-        // one LDS latency per MFMA.  So the reads are issued by hand, one pair of rows ahead.
-        const unsigned va = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(Vs + (kt * 32 + 4 * half) * 64 + l32);
-        float x[2][4];
-        rk_read_v<0>(x[0], va);
-#pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {   // pair pr: accumulator rows r = 2 pr, 2 pr + 1
-          if (pr + 1 < 8) {
-            rk_read_v_dyn(x[(pr + 1) & 1], va, pr + 1);
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[pr & 1][0]), "+v"(x[pr & 1][1]), "+v"(x[pr & 1][2]), "+v"(x[pr & 1][3]));
-          } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[pr & 1][0]), "+v"(x[pr & 1][1]), "+v"(x[pr & 1][2]), "+v"(x[pr & 1][3]));
-          }
-          st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][0], sacc[2 * pr], st.o0, 0, 0, 0);
-          st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][1], sacc[2 * pr], st.o1, 0, 0, 0);
-          st.o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][2], sacc[2 * pr + 1], st.o0, 0, 0, 0);
-          st.o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[pr & 1][3], sacc[2 * pr + 1], st.o1, 0, 0, 0);
-        }
+      f32x16 sa, sb;
+      s_tile(kt0, sa);
+      {
+        Soft sv;
+        sv.tmax = -INFINITY; sv.psum = 0.f;
+        soft_max_rows(sa, sv, 0, 16);
+        soft_scale(st, sv);
+        soft_exp_rows(sa, sv, 0, 16);
+        soft_commit(st, sv);
+      }
+      for (int kt = kt0;;) {
+        if (kt + 1 >= kt1) { pv_tile(kt, sa, false, sa, st); break; }
+        s_tile(kt + 1, sb);
+        pv_tile(kt, sa, true, sb, st);
+        ++kt;
+        if (kt + 1 >= kt1) { pv_tile(kt, sb, false, sb, st); break; }
+        s_tile(kt + 1, sa);
+        pv_tile(kt, sb, true, sa, st);
+        ++kt;
       }
       if (vtail && kt1 == ntiles) {   // wave-uniform: this range ends with the query tile's last full key tile
         float sj[4];
         float tmax = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int key = ntiles * 32 + (j < tail ? j : 0);
-          const float* kr = Ks + key * 64;
+          // rows past the tail are rows of the same (loaded, finite) key tile; their score is replaced below.  ONE address
+          // register + immediates: key & 15 = j < 4, so chunk (8 half + cg) ^ j = 8 half + (cg ^ j)
+          const int key = ntiles * 32 + j;
+          const float* kr = Ks + (ntiles * 32) * 64 + half * 32;
           float acc = 0.f;
 #pragma unroll
           for (int cg = 0; cg < 8; ++cg) {
-            const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + (((half * 8 + cg) ^ (key & 15)) << 2));
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + j * 64 + ((cg ^ j) << 2));
             acc += (kf.x * qraw[cg].x + kf.y * qraw[cg].y) + (kf.z * qraw[cg].z + kf.w * qraw[cg].w);
           }
-          acc += __shfl_xor(acc, 32, FF_WAVE);           // the two lane halves hold the two halves of the head dimension
+          acc = ff_halves_sum(acc);                      // the two lane halves hold the two halves of the head dimension
           float v = acc + Ms[key];
-          if (d.causal && key > qi) v = -INFINITY;
           if (j >= tail) v = -INFINITY;
           sj[j] = v;
           tmax = fmaxf(tmax, v);
@@ -530,7 +589,7 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
     auto store_out = [&](int qt, const RkState& st) {
       bool qv;
       const size_t qrow = query_row(qt, qv);
-      const float l_tot = st.l + __shfl_xor(st.l, 32, FF_WAVE);
+      const float l_tot = ff_halves_sum(st.l);
       const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
       if (qv) {
         float* op = d.o + qrow * d.ldo + h * FF_HEAD_DIM + 4 * half;
@@ -544,8 +603,13 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
       }
     };
 
-    RkState cur, first;
-    bool has_first = false, has_last = false;
+    // A wave's range may begin inside a query tile (FIRST partial) and end inside another (LAST partial).  The last one stays in
+    // registers until the barrier; the first one leaves for the wave's record in global memory at once (fire-and-forget 16-byte
+    // stores, read back by the merging wave of the same block after the barrier): holding it cost 34 registers for the whole item
+    // loop, which the second score register set of the software pipeline needs.
+    RkState cur;
+    float* const grec = scratch + (size_t)(blockIdx.x * RK_NW + wave) * RK_REC;
+    bool has_last = false;
     int last_k = -1, last_kt0 = 0;
     for (int it = ia; it < ib;) {   // wave-uniform control flow
       const int k = it / ntiles, kt0 = it - k * ntiles;
@@ -555,8 +619,13 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
       if (kt0 == 0 && kt1 == ntiles) {
         store_out(rank + k * c, cur);
       } else if (it < ib) {          // more items follow: this is the wave's FIRST partial
-        first = cur;
-        has_first = true;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          *reinterpret_cast<f32x4*>(grec + (g4 * 64 + lane) * 4) = f32x4{cur.o0[g4 * 4], cur.o0[g4 * 4 + 1], cur.o0[g4 * 4 + 2], cur.o0[g4 * 4 + 3]};
+          *reinterpret_cast<f32x4*>(grec + ((4 + g4) * 64 + lane) * 4) = f32x4{cur.o1[g4 * 4], cur.o1[g4 * 4 + 1], cur.o1[g4 * 4 + 2], cur.o1[g4 * 4 + 3]};
+        }
+        grec[32 * 64 + lane] = cur.m;
+        grec[33 * 64 + lane] = cur.l;
       } else {                       // the wave's LAST partial stays in `cur`
         has_last = true; last_k = k; last_kt0 = kt0;
       }
@@ -567,26 +636,26 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
 #endif
     __syncthreads();                 // every wave is done with K / V: the area now carries the partial records
     FF_EXP_ASTAMP(3);
-    auto put = [&](const RkState& st, int slot) {
-      float* rec = lds + (wave * 2 + slot) * RK_REC;
+    if (has_last) {                  // the last partial: LDS record of this wave
+      float* rec = lds + wave * RK_REC;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { rec[e * 64 + lane] = st.o0[e]; rec[(16 + e) * 64 + lane] = st.o1[e]; }
-      rec[32 * 64 + lane] = st.m;
-      rec[33 * 64 + lane] = st.l;
-    };
-    if (has_first) put(first, 0);
-    if (has_last) put(cur, 1);
-    __syncthreads();
+      for (int e = 0; e < 16; ++e) { rec[e * 64 + lane] = cur.o0[e]; rec[(16 + e) * 64 + lane] = cur.o1[e]; }
+      rec[32 * 64 + lane] = cur.m;
+      rec[33 * 64 + lane] = cur.l;
+    }
+    __syncthreads();                 // (also orders the first partials' global stores before the reads below: same workgroup)
     if (has_last && last_kt0 == 0) {  // this wave holds the first keys of a cut query tile: merge in ascending key order
       const int kend = (last_k + 1) * ntiles;
+      // the piece of wave w2 inside this tile is its FIRST partial (global record) if its range goes on past the tile
+      auto grec_of = [&](int w2) { return scratch + (size_t)(blockIdx.x * RK_NW + w2) * RK_REC; };
       float m_star = cur.m;
       for (int w2 = wave + 1; w2 < RK_NW; ++w2) {
         int a2, b2;
         range_of(w2, a2, b2);
         if (a2 >= kend) break;
         if (b2 == a2) continue;
-        const float* rec = lds + (w2 * 2 + (b2 > kend ? 0 : 1)) * RK_REC;
-        m_star = fmaxf(m_star, rec[32 * 64 + lane]);
+        const float mj = b2 > kend ? grec_of(w2)[32 * 64 + lane] : lds[w2 * RK_REC + 32 * 64 + lane];
+        m_star = fmaxf(m_star, mj);
       }
       const float ms = (m_star == -INFINITY) ? 0.f : m_star;
       const float sc0 = ff_exp2(cur.m - ms);
@@ -598,13 +667,26 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
         range_of(w2, a2, b2);
         if (a2 >= kend) break;
         if (b2 == a2) continue;
-        const float* rec = lds + (w2 * 2 + (b2 > kend ? 0 : 1)) * RK_REC;
-        const float scj = ff_exp2(rec[32 * 64 + lane] - ms);
-        cur.l += rec[33 * 64 + lane] * scj;
+        if (b2 > kend) {
+          const float* rec = grec_of(w2);
+          const float scj = ff_exp2(rec[32 * 64 + lane] - ms);
+          cur.l += rec[33 * 64 + lane] * scj;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          cur.o0[e] += rec[e * 64 + lane] * scj;
-          cur.o1[e] += rec[(16 + e) * 64 + lane] * scj;
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(rec + (g4 * 64 + lane) * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(rec + ((4 + g4) * 64 + lane) * 4);
+            cur.o0[g4 * 4 + 0] += a.x * scj; cur.o0[g4 * 4 + 1] += a.y * scj; cur.o0[g4 * 4 + 2] += a.z * scj; cur.o0[g4 * 4 + 3] += a.w * scj;
+            cur.o1[g4 * 4 + 0] += b.x * scj; cur.o1[g4 * 4 + 1] += b.y * scj; cur.o1[g4 * 4 + 2] += b.z * scj; cur.o1[g4 * 4 + 3] += b.w * scj;
+          }
+        } else {
+          const float* rec = lds + w2 * RK_REC;
+          const float scj = ff_exp2(rec[32 * 64 + lane] - ms);
+          cur.l += rec[33 * 64 + lane] * scj;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            cur.o0[e] += rec[e * 64 + lane] * scj;
+            cur.o1[e] += rec[(16 + e) * 64 + lane] * scj;
+          }
         }
       }
       cur.m = m_star;
@@ -658,7 +740,7 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   const int qt32 = ff_cdiv(d.nq, 32);
   // (the pair's K/V load is a fixed cost of every block: it pays from ~2 query tiles per CU on -- measured: config B
   //  from t = 8, never for the single-sequence decode, whose 8 pairs have at most 9 query tiles each)
-  const bool resident_ok = d.nk <= RK_KEYS && d.nk > 0;
+  const bool resident_ok = d.nk <= RK_KEYS && d.nk > 0 && !d.causal;   // (cross-attention and encoder: no causal mask in that kernel)
   if (g_attention_algo == 3 ? resident_ok : (g_attention_algo == 0 && resident_ok && qt32 >= 4 && gh * qt32 >= 512)) {
     static std::atomic<bool> attr_done[16] = {};   // idempotent per-device attribute; host threads may race here
     int dev = 0;
@@ -677,8 +759,10 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     static const int w_old = getenv("FF_RK_SPLIT_OLD") ? atoi(getenv("FF_RK_SPLIT_OLD")) : 1;      // (probe knobs: tools/run_r04_attn.sh)
     static const int w_young = getenv("FF_RK_SPLIT_YOUNG") ? atoi(getenv("FF_RK_SPLIT_YOUNG")) : 1;
     static const int phase_knob = getenv("FF_RK_PHASE") ? atoi(getenv("FF_RK_PHASE")) : 0;
+    float* scratch = nullptr;   // first partial records: one per wave
+    FF_RETURN_IF(ff_stream_scratch(st, (size_t)nblocks * RK_NW * RK_REC * sizeof(float), &scratch));
     hipLaunchKernelGGL(attention_resident_kernel, dim3(nblocks), dim3(64 * RK_NW), lds_bytes, st, d, P, c, qt32,
-                       w_old > 0 ? w_old : 1, w_young > 0 ? w_young : 1, phase_knob);
+                       w_old > 0 ? w_old : 1, w_young > 0 ? w_young : 1, phase_knob, scratch);
     FF_CHECK_LAUNCH();
     return FF_OK;
   }

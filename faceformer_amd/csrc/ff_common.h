@@ -71,6 +71,8 @@ void ff_tuning_changed();
 
 // partial-tile workspace of the 3 x bf16 kernel for (current device, stream): allocate now (ff_gemm_x3.hip)
 extern "C" int ff_x3_prepare_stream(hipStream_t st);
+// ... and the same area as scratch memory for another kernel of that stream (at most 24 MB)
+int ff_stream_scratch(hipStream_t st, size_t bytes, float** out);
 
 // ---- device helpers --------------------------------------------------------------------------
 __device__ __forceinline__ float ff_wave_sum(float v) {
@@ -82,6 +84,18 @@ __device__ __forceinline__ float ff_wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, FF_WAVE));
   return v;
+}
+
+// Exchange between the two 32-lane halves of a wave without the LDS crossbar: v_permlane32_swap leaves (lower half's value, upper
+// half's value) in every lane; `__shfl_xor(v, 32)` is a ds_bpermute round trip (>100 cycles, and a lgkmcnt event in the middle of
+// hand-counted LDS reads).  Bitwise the results of v + __shfl_xor(v, 32) / fmaxf(v, __shfl_xor(v, 32)) (both are commutative).
+__device__ __forceinline__ float ff_halves_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float ff_halves_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 // Bijective XCD-aware remap of a linear block id: blocks are dispatched round-robin over the 8

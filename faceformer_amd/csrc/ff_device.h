@@ -258,12 +258,12 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
       float x[16], sm = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) { x[c] = patch[l32 * 33 + half * 16 + c]; sm += x[c]; }
-      sm += __shfl_xor(sm, 32, FF_WAVE);
+      sm = ff_halves_sum(sm);
       const float mean = sm * (1.0f / 32.0f);
       float m2 = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) { const float d = x[c] - mean; m2 += d * d; }
-      m2 += __shfl_xor(m2, 32, FF_WAVE);
+      m2 = ff_halves_sum(m2);
       const int r = m0 + l32;
       if (half == 0 && r < g.M) {
         ff_st8<COH>(g.ln_out + ((size_t)r * (g.N >> 5) + (n0 >> 5)) * 2, f32x2{mean, m2});
@@ -460,7 +460,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
       s[r] = v;
       tmax = fmaxf(tmax, v);
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, FF_WAVE));
+    tmax = ff_halves_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = ff_exp2(m_run - m_safe);
@@ -500,7 +500,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
           const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + c * 4);
           dot += kv.x * qreg[c * 4 + 0] + kv.y * qreg[c * 4 + 1] + kv.z * qreg[c * 4 + 2] + kv.w * qreg[c * 4 + 3];
         }
-        dot += __shfl_xor(dot, 32, FF_WAVE);
+        dot = ff_halves_sum(dot);
         float sv = dot + Mt[jj];
         if (d.causal && (32 + jj) > qi) sv = -INFINITY;
         sj[jj] = sv;
@@ -553,7 +553,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (j < ks) { sc[j] = ff_exp2(sc[j] - ms); l_sum += rec0[j * PATCH + 33 * 64 + lane] * sc[j]; }
-    const float l_all = l_sum + __shfl_xor(l_sum, 32, FF_WAVE);
+    const float l_all = ff_halves_sum(l_sum);
     const float inv_c = l_all > 0.f ? 1.0f / l_all : 0.f;
     const int quads = q_valid ? 8 / ks : 0;   // groups of four output registers per wave (ks = 2, 4, 8)
     for (int qd = 0; qd < quads; ++qd) {
@@ -574,7 +574,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
     return;   // (the key-split form never carries short tails: nothing below applies)
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, FF_WAVE);
+  const float l_tot = ff_halves_sum(l_run);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (q_valid) {
 #pragma unroll
@@ -652,8 +652,8 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (i < qtail) {
-        const float s0 = a0[i] + __shfl_xor(a0[i], 32, FF_WAVE);
-        const float s1 = a1[i] + __shfl_xor(a1[i], 32, FF_WAVE);
+        const float s0 = ff_halves_sum(a0[i]);
+        const float s1 = ff_halves_sum(a1[i]);
         const int qx = q_tiles * 32 + i;
         const size_t xr = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
         ff_st4<COH>(d.o + xr * d.ldo + h * FF_HEAD_DIM + 32 * half + l32, half ? s1 : s0);

@@ -165,12 +165,12 @@ __device__ __forceinline__ void ff_emit_ln_stats(const float (&v)[16], float* pa
   float x[16], sm = 0.f;
 #pragma unroll
   for (int c = 0; c < 16; ++c) { x[c] = patch[l32 * 33 + half * 16 + c]; sm += x[c]; }
-  sm += __shfl_xor(sm, 32, FF_WAVE);
+  sm = ff_halves_sum(sm);
   const float mean = sm * (1.0f / 32.0f);
   float m2 = 0.f;
 #pragma unroll
   for (int c = 0; c < 16; ++c) { const float d = x[c] - mean; m2 += d * d; }
-  m2 += __shfl_xor(m2, 32, FF_WAVE);
+  m2 = ff_halves_sum(m2);
   const int row = row0 + l32;
   if (half == 0 && row < M) {
     ff_st8<COH>(ln_out + ((size_t)row * nseg_out + seg) * 2, f32x2{mean, m2});
@@ -1452,12 +1452,12 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
       float x[16], sm = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) { x[c] = patch[l32 * 33 + half * 16 + c]; sm += x[c]; }
-      sm += __shfl_xor(sm, 32, FF_WAVE);
+      sm = ff_halves_sum(sm);
       const float mean = sm * (1.0f / 32.0f);
       float m2 = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) { const float d = x[c] - mean; m2 += d * d; }
-      m2 += __shfl_xor(m2, 32, FF_WAVE);
+      m2 = ff_halves_sum(m2);
       const int r = m0 + l32;
       if (half == 0 && r < g.M) *reinterpret_cast<f32x2*>(g.ln_out + ((size_t)r * (g.N >> 5) + (n0 >> 5)) * 2) = f32x2{mean, m2};
     }

@@ -537,12 +537,12 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
         float sm = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sm += acc[ni][e];
-        sm += __shfl_xor(sm, 32, FF_WAVE);
+        sm = ff_halves_sum(sm);
         const float mean = sm * (1.0f / 32.0f);
         float m2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const float d = acc[ni][e] - mean; m2 += d * d; }
-        m2 += __shfl_xor(m2, 32, FF_WAVE);
+        m2 = ff_halves_sum(m2);
         const int seg = (e_n0 >> 5) + wn * NI + ni;
         if (half == 0 && rowok && seg * 32 < g.N) {
           const f32x2 st2 = f32x2{mean, m2};
@@ -1037,12 +1037,12 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
         float sm = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sm += acc[ni][e];
-        sm += __shfl_xor(sm, 32, FF_WAVE);
+        sm = ff_halves_sum(sm);
         const float mean = sm * (1.0f / 32.0f);
         float m2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const float d = acc[ni][e] - mean; m2 += d * d; }
-        m2 += __shfl_xor(m2, 32, FF_WAVE);
+        m2 = ff_halves_sum(m2);
         const int seg = (e_n0 >> 5) + wn * NI + ni;
         if (half == 0 && rowok && seg * 32 < g.N) {
           const f32x2 st2 = f32x2{mean, m2};
@@ -1362,6 +1362,16 @@ extern "C" int ff_split_weight_bf16x3(const float* W, int ldw, int N, int K, voi
 extern "C" int ff_x3_prepare_stream(hipStream_t st) {
   X3Args g;
   return x3_acquire(st, &g);
+}
+
+// The same per-(device, stream) area as scratch memory of other kernels on that stream (stream order keeps the users apart):
+// the K/V-resident attention kernel parks its first partial records there (ff_attention.hip).
+int ff_stream_scratch(hipStream_t st, size_t bytes, float** out) {
+  FF_CHECK_ARG(bytes <= X3_WS_BYTES, "ff_stream_scratch: %zu bytes requested, the area has %zu", bytes, X3_WS_BYTES);
+  X3Args g;
+  FF_RETURN_IF(x3_acquire(st, &g));
+  *out = g.ws;
+  return FF_OK;
 }
 
 extern "C" int ff_set_x3_tuning(int shape) {
