@@ -234,8 +234,10 @@ typedef struct ff_attn_desc {
 
 int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
 /* Kernel selection for ff_attention (tuning / tests): 0 automatic, 1 block-shared LDS staging,
- * 2 wave-independent with in-block key splitting, 3 K/V-resident (key sets of at most 288 rows; larger ones fall
- * back to the automatic choice between 1 and 2).  Returns the previous value. */
+ * 2 wave-independent with in-block key splitting, 3 K/V-resident (key sets of at most 288 rows without a causal mask;
+ * other launches fall back to the automatic choice between 1 and 2).  Returns the previous value.
+ * The K/V-resident kernel parks partial (max, sum, O) records in the stream's scratch area (the one ff_gemm_prepare_stream
+ * allocates: 24 MB per (device, stream), shared with the projection kernels of that stream in stream order). */
 int ff_set_attention_algo(int algo);
 
 /* ---------------------------------------------------------------------------------------------

@@ -84,4 +84,10 @@ CASES = [
     dict(name="par_full_E512_T38_gain4", kind="parallel", model=_m(FULL, 512, 38), recipe="gain4",
          wseed=0, n_edges=[512, 64], seeds=[41, 42],
          keep_logit_rows=[0, 1, 300, 511, 512, 540, 575, 576, 800, 1023], slow=True),
+    # --- round 4: the LONGEST key set with a long prefix --------------------------------------------------------
+    # ours-perspective.yml sizes with num_lines=1024: one 1024-edge wireframe, all 37 decode steps -- S = 1028 keys x
+    # t*F query rows for every t up to 37 (until now covered at op level and by the 3-step par_full_E1024_gain4 only)
+    dict(name="par_full_E1024_T38_gain4", kind="parallel", model=_m(FULL, 1024, 38), recipe="gain4",
+         wseed=0, n_edges=[1024], seeds=[51],
+         keep_logit_rows=[0, 1, 2, 300, 511, 512, 800, 1023], slow=True),
 ]
