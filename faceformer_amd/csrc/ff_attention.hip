@@ -327,7 +327,7 @@ struct RkState {
 };
 
 __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_attn_desc d, int P, int c, int q_tiles, int w_old, int w_young, int phase_knob,
-                                                                          float* __restrict__ scratch) {
+                                                                          float* __restrict__ scratch, int rot_on) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Ks = lds;                       // [key][64], 16-byte chunks XOR-swizzled with (key & 15)
   float* const Vs = lds + RK_KEYS * 64;        // [key][64]
@@ -353,9 +353,13 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
       // piece = 4 key rows x 256 B of one operand = one wave-instruction (lane: row lane/16, 16-byte slot lane%16);
       // the LDS image is lane-linear, so K's bank swizzle (slot ^ (row & 15)) is applied to the SOURCE column.
       // Rows past d.nk read the last row again (finite values; their softmax weight is exactly 0).
+      // The c blocks of a pair sit on the same XCD and read the SAME rows: started together on the same piece they queue on
+      // the same L2 channels, so block `rank` starts rot = rank / c of the way round (destination = piece id, only the order moves).
       const int npieces = tiles_max * 8;
       const int prow = lane >> 4, pos = lane & 15;
-      for (int p = wave; p < npieces; p += RK_NW) {
+      const int rot = (P <= nblk && rot_on) ? (int)(((long)rank * npieces) / c) : 0;
+      for (int q = wave; q < npieces; q += RK_NW) {
+        const int p = q + rot < npieces ? q + rot : q + rot - npieces;
         const int row = 4 * p + prow;
         const int rc = row < d.nk ? row : d.nk - 1;
         const size_t krow = (size_t)rc * d.k_stride;
@@ -759,10 +763,11 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     static const int w_old = getenv("FF_RK_SPLIT_OLD") ? atoi(getenv("FF_RK_SPLIT_OLD")) : 1;      // (probe knobs: tools/run_r04_attn.sh)
     static const int w_young = getenv("FF_RK_SPLIT_YOUNG") ? atoi(getenv("FF_RK_SPLIT_YOUNG")) : 1;
     static const int phase_knob = getenv("FF_RK_PHASE") ? atoi(getenv("FF_RK_PHASE")) : 0;
+    static const int rot_on = getenv("FF_RK_ROTATE") ? atoi(getenv("FF_RK_ROTATE")) : 1;   // (probe: 0 = every block loads K / V in the same order)
     float* scratch = nullptr;   // first partial records: one per wave
     FF_RETURN_IF(ff_stream_scratch(st, (size_t)nblocks * RK_NW * RK_REC * sizeof(float), &scratch));
     hipLaunchKernelGGL(attention_resident_kernel, dim3(nblocks), dim3(64 * RK_NW), lds_bytes, st, d, P, c, qt32,
-                       w_old > 0 ? w_old : 1, w_young > 0 ? w_young : 1, phase_knob, scratch);
+                       w_old > 0 ? w_old : 1, w_young > 0 ? w_young : 1, phase_knob, scratch, rot_on);
     FF_CHECK_LAUNCH();
     return FF_OK;
   }
