@@ -81,7 +81,8 @@ def test_gemm_bias_act_residual(ops, M, N, K, tile):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024), (4100, 1024, 512),
-                                   (64, 260, 512), (130, 96, 64), (7680, 512, 512), (8448, 1536, 512), (9216, 512, 1024)])
+                                   (64, 260, 512), (130, 96, 64), (7680, 512, 512), (8448, 1536, 512), (9216, 512, 1024),
+                                   (6400, 512, 512), (6400, 1536, 512), (6656, 512, 1024)])   # K-pieces beyond one per CU
 def test_gemm_dma_kernel(ops, M, N, K):
     """Tile 11: the LDS-DMA kernel of the f32 family (both operands by DMA, transposed accumulators, whole tiles + the hybrid
     remainder split): bias, ReLU, aliased residual, ragged edges in M and N, an output wider than N, determinism."""
@@ -245,7 +246,9 @@ def x3_tuning(request, ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 512, 512), (77, 1536, 512), (333, 512, 1024), (64, 260, 512), (130, 96, 64),
-                                   (2304, 512, 512), (5000, 1024, 512), (9216, 1536, 512), (4608, 512, 1024)])
+                                   (2304, 512, 512), (5000, 1024, 512), (9216, 1536, 512), (4608, 512, 1024),
+                                   # more than half a round of tiles left over: K-pieces beyond one per CU (no-wait exchange)
+                                   (6400, 512, 512), (6400, 1536, 512), (6400, 512, 1024)])
 def test_gemm_x3_every_tile_and_launch_shape(ops, x3_tuning, M, N, K):
     """Whole tiles and equal K-unit ranges (cut tiles exchanged between blocks): same result up to the summation order,
     deterministic, ragged edges in M and N."""
@@ -266,7 +269,7 @@ def test_gemm_x3_every_tile_and_launch_shape(ops, x3_tuning, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(37, 512, 512), (300, 512, 1024), (1300, 512, 512), (5000, 512, 512), (640, 128, 256),
-                                   (9216, 512, 1024)])
+                                   (9216, 512, 1024), (6400, 512, 512), (6656, 512, 1024)])
 def test_gemm_x3_emits_layernorm_segment_statistics(hip_lib, ops, x3_tuning, M, N, K):
     """ff_gemm_x3_ln, producer side: C = A W^T + b + residual plus (mean, M2) per row and 32-column segment of the stored C."""
     g = torch.Generator().manual_seed(M + N + K)
@@ -285,7 +288,7 @@ def test_gemm_x3_emits_layernorm_segment_statistics(hip_lib, ops, x3_tuning, M, 
 
 @pytest.mark.parametrize("in_epilogue", [False, True], ids=["normalise_first", "normalise_in_epilogue"])
 @pytest.mark.parametrize("M,N,div", [(37, 1536, 5), (300, 512, 7), (1300, 1536, 64), (5000, 1024, 256), (9216, 1536, 256),
-                                     (4352, 512, 256)])
+                                     (4352, 512, 256), (6400, 1536, 256), (6400, 512, 256)])
 def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, x3_tuning, M, N, div, in_epilogue):
     """ff_gemm_x3_ln, consumer side: act((LN(x) + pos[row // div]) W^T + b) from raw x, its segment statistics, the planes of
     the folded weight, the folded bias and the pos W^T table -- against the unfused arithmetic in float64; rows normalised
