@@ -473,21 +473,10 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
     // MODE 3: LayerNorm(x) W'^T = rstd (x W'^T - mean colsum(W')): the K loop multiplied the RAW rows; this row's statistics are
     // merged here from the producer's 16 segment statistics (Chan's update, as stats_merge) and applied to the finished sums.
     float ln_mean = 0.f, ln_rstd = 1.f;
-    if (MODE == 3) {
-      f32x4 sv[8];
+    f32x4 sv[MODE == 3 ? 8 : 1];
+    if (MODE == 3) {   // (requested together with the first operand group below: one round trip instead of two)
 #pragma unroll
       for (int i = 0; i < 8; ++i) sv[i] = gload16(g.ln_in + (size_t)mc * 32 + 4 * i);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(sv[i]));
-      float sm = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { sm += sv[i][0] + sv[i][2]; m2 += sv[i][1] + sv[i][3]; }
-      ln_mean = sm * (1.0f / 16.0f);
-      float dev = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { const float d0 = sv[i][0] - ln_mean, d1 = sv[i][2] - ln_mean; dev += d0 * d0 + d1 * d1; }
-      ln_rstd = 1.0f / sqrtf((m2 + 32.f * dev) * (1.0f / 512.0f) + g.ln_eps);
     }
     // a few 32-column groups at a time: with all of a 128-column row's operands in flight at once the register allocator
     // spills loop-invariant addresses INTO the K loop
@@ -511,6 +500,18 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
       for (int j = 0; j < GQ; ++j) {
         asm volatile("" : "+v"(xv[j]), "+v"(bv[j]));
         if (MODE == 3) asm volatile("" : "+v"(cv[j]));
+      }
+      if (MODE == 3 && h == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(sv[i]));
+        float sm = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sm += sv[i][0] + sv[i][2]; m2 += sv[i][1] + sv[i][3]; }
+        ln_mean = sm * (1.0f / 16.0f);
+        float dev = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d0 = sv[i][0] - ln_mean, d1 = sv[i][2] - ln_mean; dev += d0 * d0 + d1 * d1; }
+        ln_rstd = 1.0f / sqrtf((m2 + 32.f * dev) * (1.0f / 512.0f) + g.ln_eps);
       }
 #pragma unroll
       for (int j = 0; j < GQ; ++j) {
