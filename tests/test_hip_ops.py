@@ -364,7 +364,10 @@ def ref_attention(q, k, v, mask=None, causal=False):
 
 @pytest.mark.parametrize("G,H,nq,nk", [(2, 2, 33, 33), (1, 8, 260, 260), (3, 2, 5, 100), (4, 1, 1, 1),
                                        (2, 8, 140, 70), (1, 2, 64, 64), (1, 1, 65, 129),
-                                       (600, 2, 35, 36), (530, 2, 36, 64), (515, 2, 68, 40), (520, 2, 40, 40), (513, 2, 37, 33)])   # short-tail paths
+                                       (600, 2, 35, 36), (530, 2, 36, 64), (515, 2, 68, 40), (520, 2, 40, 40), (513, 2, 37, 33),   # short-tail paths
+                                       # more (group, head) pairs than workgroups AND query tiles cut between the waves of a block:
+                                       # the K/V-resident kernel's first partial records (global scratch) with several pairs per block
+                                       (130, 2, 300, 100), (40, 8, 200, 260)])
 def test_attention_group_major_with_mask(ops, attn_algo, G, H, nq, nk):
     """Encoder-style layout: rows = g*len + i; padding mask + kv_len."""
     E = H * 64
