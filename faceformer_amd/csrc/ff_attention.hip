@@ -771,8 +771,13 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     FF_CHECK_LAUNCH();
     return FF_OK;
   }
+  // (long key sets -- beyond the resident kernel's 288 rows: the 300 ... 1024-edge wireframes of the config-E mix -- cross over
+  //  earlier: a wave walks all key tiles of its unit one after the other.  Measured, profiles/r04/attention_long_keys.txt: 512
+  //  units of 516 / 1028 keys 39 / 63 us (wave) vs 51 / 89 (block-shared), 600 units of 304 keys 39 vs 31, 1024 units of 1028
+  //  keys 114 vs 94, 1200 units of 304 keys 70 vs 54)
+  const long wave_units_max = d.nk > RK_KEYS ? 576 : 1536;
   const bool use_wave = g_attention_algo == 2 ||
-                        (g_attention_algo == 0 && (gh * ff_cdiv(d.nq, 32) < 1536 || d.nq <= 64));
+                        (g_attention_algo == 0 && (gh * ff_cdiv(d.nq, 32) < wave_units_max || d.nq <= 64));
   if (use_wave) {
     // wave-independent kernel: units = (group, head, 32-query tile); the key tiles are dealt round-robin to ks waves
     // (ks = 1, 2, 4, 8: a power of two up to the tile count, idle waves allowed) while the launch would otherwise

@@ -48,11 +48,12 @@ if "--seq" in sys.argv:   # single-sequence decode (seq2seq variant): t queries;
     ops.set_attention_algo(0)
     sys.exit(0)
 if "--long" in sys.argv:   # key sets of the 512 / 1024-edge wireframes (config E): F = 512 / 1024 sequences of ONE wireframe
-    print("%4s %5s %5s | %8s %8s   TF/s of the automatic choice" % ("t", "F", "S", "lds(1)", "auto(0)"))
-    for Fw, S in ((512, 516), (1024, 1028)):
+    print("%4s %5s %5s | %8s %8s %8s   TF/s: lds, wave, automatic choice" % ("t", "F", "S", "lds(1)", "wave(2)", "auto(0)"))
+    for Fw, S in ((512, 516), (1024, 1028), (300, 304)):
         for t in (1, 2, 4, 8, 16, 24, 37):
-            t1, t0 = run(t, S, 1, iters=10, F=Fw), run(t, S, 0, iters=10, F=Fw)
-            print("%4d %5d %5d | %8.1f %8.1f   %.1f" % (t, Fw, S, t1, t0, 4.0 * 512 * t * Fw * S / t0 / 1e6))
+            t1, t4, t0 = run(t, S, 1, iters=10, F=Fw), run(t, S, 2, iters=10, F=Fw), run(t, S, 0, iters=10, F=Fw)
+            fl = 4.0 * 512 * t * Fw * S / 1e6
+            print("%4d %5d %5d | %8.1f %8.1f %8.1f   %.1f %.1f %.1f" % (t, Fw, S, t1, t4, t0, fl / t1, fl / t4, fl / t0))
     ops.set_attention_algo(0)
     sys.exit(0)
 print("%4s %5s | %8s %8s %8s" % ("t", "S", "lds(1)", "wave(2)", "resid(3)"))
