@@ -44,3 +44,37 @@ def test_world_size_that_disagrees_with_gpus_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-spawn"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_compact_line_of_the_round_4_record_is_parsable_and_small():
+    """the driver could not parse round 4's 25 KB line.  bench.compact_line() of that very record must stay
+    under 4 KB and still carry the contract keys, `roofline.frac` and `cpu_baseline.value`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r04", "bench_r04_B.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < 4096
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert abs(d["value"] - full["value"]) / full["value"] < 1e-5
+    assert abs(d["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5 and d["roofline"]["bound"] == "mfma"
+    assert abs(d["roofline"]["traffic"] / full["roofline"]["traffic"] - 1) < 1e-5
+    assert abs(d["cpu_baseline"]["value"] - full["cpu_baseline"]["value"]) < 1e-2 and len(d["cpu_baseline"]["sample"]) <= 160
+    assert set(d["other_configs"]) == set(full["other_configs"])
+    assert all(set(v) <= {"value", "ms_per_step", "frac", "kernel_frac", "bf16x3"} for v in d["other_configs"].values())
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_compact_line_sheds_optional_blocks_rather_than_grow():
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r04", "bench_r04_B.json")) as f:
+        full = json.load(f)
+    full["other_configs"] = {"cfg%03d" % i: dict(full["other_configs"]["C128"]) for i in range(60)}
+    line = bench.compact_line(full)
+    d = json.loads(line)
+    assert len(line) < 4096 and "other_configs" not in d and "roofline" in d and "cpu_baseline" in d
