@@ -182,7 +182,12 @@ inline int compact_width(const ff_decode_params* p, const int* num_input_host, i
 void plan_chunks(const ff_decode_params* p, const int* num_input_host, int ns, std::vector<Chunk>* out, int* btot,
                  int* max_bc) {
   const int N = p->N;
-  const int cw_lim = (p->chunk_wireframes <= 0 || p->chunk_wireframes > N) ? N : p->chunk_wireframes;
+  int cw_lim = (p->chunk_wireframes <= 0 || p->chunk_wireframes > N) ? N : p->chunk_wireframes;
+  // The single-sequence model decodes ONE sequence per wireframe (reference model.py:193-210: N sequences per step), so a
+  // micro-batch of chunk_wireframes = 16 wireframes is 16 rows per position -- 64 wireframes then are 4 x 258 steps of
+  // <= 4 128-row launches.  There the micro-batch is cut by SEQUENCES: up to chunk_max_seqs of them (0: chunk_wireframes as
+  // before).  The cumulative EOS rule is untouched: every micro-batch adds to the same per-step counters.
+  if (p->variant == FF_SEQ2SEQ && p->chunk_max_seqs > 0) cw_lim = p->chunk_max_seqs < N ? p->chunk_max_seqs : N;
   int b0 = 0, mx = 0;
   int w = 0;
   while (w < N) {

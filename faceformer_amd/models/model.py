@@ -21,6 +21,9 @@ class SurfaceFormer(SurfaceFormerBase):
         self._build(num_model, num_head, num_feedforward, num_encoder_layers, num_decoder_layers,
                     dropout, activation, normalize_before, num_points_per_line, num_lines, point_dim,
                     label_seq_length, token, teacher_forcing_ratio)
+        # One sequence per wireframe: a micro-batch is cut by sequences, not by `chunk_wireframes` wireframes.  256 sequences
+        # x (label_seq_length - 1) positions = 66 k active rows at the last step of configs A / D (1.6 GB of scratch).
+        self.chunk_max_seqs = 256
 
     def get_embeddings(self, input, label):
         val_embed = self.val_enc(input)
@@ -37,7 +40,7 @@ class SurfaceFormer(SurfaceFormerBase):
         eng, memory, mask, kv_len = self._encode(inputs)
         out = eng.decode(memory, mask, kv_len, _L.FF_SEQ2SEQ, T=T, F=1,
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
-                         num_streams=self.num_streams, sync_every=1,
+                         chunk_max_seqs=self.chunk_max_seqs, num_streams=self.num_streams, sync_every=1,
                          flags=self.decode_flags, x3_min_rows=self.x3_min_rows, ln_fuse_max_rows=self.ln_fuse_max_rows, chain_max_rows=self.chain_max_rows, flow_min_rows=self.flow_min_rows, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
                          return_pointer=True, extra_mask=self._extra_mask(inputs))
         inputs["embedding"] = memory

@@ -50,7 +50,7 @@ def run_traced(model, case, batch):
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          extra_mask=extra, flags=model.decode_flags, return_pointer=True,
                          x3_min_rows=model.x3_min_rows,
-                         chunk_wireframes=model.chunk_wireframes,
+                         chunk_wireframes=model.chunk_wireframes, chunk_max_seqs=getattr(model, "chunk_max_seqs", 0),
                          chain_max_rows=getattr(model, "chain_max_rows", 0), flow_min_rows=getattr(model, "flow_min_rows", 0))
     out["memory"] = memory
     return out
@@ -417,6 +417,71 @@ def test_config_c_batch_of_256_edge_wireframes_full_size(hip_lib):
             frac = same.mean()
             assert frac > 0.995, "chunk=%d: only %.4f of the tokens equal the 16-per-chunk run" % (chunk, frac)
             assert np.abs(best[0] - base[1][0]).max() <= tol_scale     # step 0: identical prefixes
+
+
+@pytest.mark.parametrize("name,N", [("seq_small_gain4", 40), ("seq_full_A64_gain4", 64)])
+def test_seq2seq_batch_is_micro_batched_by_sequences_and_equals_one_wireframe_decodes(hip_lib, name, N):
+    """SurfaceFormer.forward_eval of a batch (reference model.py:193-210: N sequences per step) is cut
+    into micro-batches of up to chunk_max_seqs SEQUENCES.  With the stop rule off (so that every wireframe runs all T-1
+    steps) a batch of N wireframes must give, wireframe by wireframe, what N one-wireframe decodes give wherever the
+    one-wireframe decode's own top-2 margin is decisive -- for micro-batches of 1, 16 and all N sequences -- and the model's
+    forward (cumulative EOS rule, reference model.py:191,207-210) must equal the no-stop tokens cut at its stop step."""
+    from faceformer_amd.hip import lib as L
+    from faceformer_amd.synth import make_wireframes
+    case, z = load_golden(name)
+    sd, _ = case_weights_and_batch(case)
+    m = case["model"]
+    model = build_model(case, sd, "cuda")
+    model.x3_min_rows = 0
+    T = m["seq_len"]
+    rng = np.random.default_rng(7)
+    n_edges = [int(v) for v in rng.integers(max(4, m["L"] // 3), m["L"] + 1, size=N)]
+    n_edges[0] = case["n_edges"][0]
+    seeds = [case["seeds"][0]] + list(range(100, 100 + N - 1))
+    batch = batch_to(make_wireframes(n_edges, m["L"], T, "seq2seq", seeds=seeds), "cuda")
+    eng, memory, mask, kv_len = model._encode(batch)
+
+    def decode(mem, msk, kvl, seqs, trace=True):
+        return eng.decode(mem, msk, kvl, L.FF_SEQ2SEQ, T=T, F=1, trace=trace, sync_every=1, flags=model.decode_flags,
+                          chunk_wireframes=model.chunk_wireframes, chunk_max_seqs=seqs, no_stop=True,
+                          tok_sos=model.token.SOS, tok_eos=model.token.EOS)
+    singles = [decode(memory[i:i + 1], mask[i:i + 1], kv_len[i:i + 1], 1) for i in range(N)]
+    one_pred = np.stack([o["predict"].cpu().numpy()[0] for o in singles])                       # [N, T]
+    one_best = np.stack([o["best"].cpu().numpy()[:, 0] for o in singles], axis=1)               # [T-1, N]
+    one_second = np.stack([o["second"].cpu().numpy()[:, 0] for o in singles], axis=1)
+    # wireframe 0 is the golden's wireframe: the one-wireframe decode reproduces the reference's tokens up to its stop step
+    gsteps = int(z["steps"])
+    gold0 = z["predict"].reshape(-1, T)[0]
+    if name == "seq_full_A64_gain4":
+        assert np.array_equal(one_pred[0, :gsteps + 1], gold0[:gsteps + 1])
+    scale = np.abs(one_best).max(axis=1)
+    tol = LOGIT_TOL * np.maximum(1.0, scale / LOGIT_SCALE)                                       # [T-1]
+    for seqs in (1, 16, N):
+        out = decode(memory, mask, kv_len, seqs)
+        pred = out["predict"].cpu().numpy()
+        best = out["best"].cpu().numpy()
+        alive = np.ones(N, dtype=bool)
+        n_cmp = 0
+        for s_ in range(T - 1):
+            d = np.abs(best[s_] - one_best[s_])[alive]
+            assert d.size == 0 or d.max() <= tol[s_], "chunk_max_seqs=%d step %d: best logit off by %g" % (seqs, s_, d.max())
+            must = alive & ((one_best[s_] - one_second[s_]) > 2 * tol[s_])
+            same = pred[:, s_ + 1] == one_pred[:, s_ + 1]
+            assert same[must].all(), "chunk_max_seqs=%d step %d: token mismatch at a decisive margin" % (seqs, s_)
+            n_cmp += int(must.sum())
+            alive &= same
+        assert n_cmp >= 0.9 * N * (T - 1) and alive.mean() > 0.9
+        if seqs == 1:
+            assert np.array_equal(pred, one_pred)     # micro-batches of one sequence ARE the one-wireframe launches
+    # the model's forward: the same tokens, cut by the cumulative EOS rule of the reference
+    model.chunk_max_seqs = N
+    with torch.no_grad():
+        fwd = model(dict(batch))["predict"].cpu().numpy()
+    full = decode(memory, mask, kv_len, N, trace=False)["predict"].cpu().numpy()
+    cum = np.cumsum((full[:, 1:] == model.token.EOS).sum(axis=0))
+    hit = np.nonzero(cum == N)[0]                # (equality, like the reference: a count that jumps past N never stops)
+    steps = int(hit[0]) + 1 if hit.size else T - 1
+    assert np.array_equal(fwd[:, :steps + 1], full[:, :steps + 1]) and (fwd[:, steps + 1:] == 0).all()
 
 
 def test_json_gather_over_rccl(hip_lib, tmp_path):
