@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 E_SIZES, E_PROBS, E_SEED = (64, 128, 256, 512, 1024), (.3, .3, .2, .1, .1), 2024
-CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops", "chain_launches",
+CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops", "unused",
              "gemm_bf16x3_kernel"]
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense; the split product spends 6 of them per fp32 product
 
@@ -403,12 +403,6 @@ def main():
                     help="which `other_configs` entries to measure (all: C128,E32,D,A,D64,A64; the default keeps the run short)")
     ap.add_argument("--other-profiled", default="C128",
                     help="which `other_configs` entries also get a profiled pass (their own kernel roofline); 'all' = every entry")
-    ap.add_argument("--chain", type=int, default=-1,
-                    help="chain launches (FF_CHAIN): 1 on, 0 off, -1 the package default")
-    ap.add_argument("--chain-max-rows", type=int, default=0, help="FF_CHAIN row limit of a whole-step chain (0: 1024)")
-    ap.add_argument("--graphs", type=int, default=-1, help="step graphs (FF_GRAPH): 1 on, 0 off, -1 the package default (off)")
-    ap.add_argument("--flow", type=int, default=-1, help="flow launches (FF_FLOW): 1 on, 0 off, -1 the package default")
-    ap.add_argument("--flow-min-rows", type=int, default=0, help="FF_FLOW: rows from which a step takes the flow launches (0: 1025)")
     ap.add_argument("--ln-fuse-max-rows", type=int, default=0, help="LayerNorm folded into the projections up to this many rows (0: 12288)")
     ap.add_argument("--plain-multi", action="store_true",
                     help="N > 1: time the plain per-rank model(batch) + all-gather (the round-2 form) instead of decode_sharded")
@@ -485,24 +479,10 @@ def main():
             model.decode_flags = model.decode_flags & ~L.FF_DEDUP_PAD_ANCHORS
         if args.no_fuse_ln:
             model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
-        apply_chain(model)
+        apply_knobs(model)
         return model, cfg, T
 
-    def apply_chain(mod):
-        if args.chain == 1:
-            mod.decode_flags = mod.decode_flags | L.FF_CHAIN
-        elif args.chain == 0:
-            mod.decode_flags = mod.decode_flags & ~L.FF_CHAIN
-        mod.chain_max_rows = args.chain_max_rows
-        if args.flow == 1:
-            mod.decode_flags = mod.decode_flags | L.FF_FLOW
-        elif args.flow == 0:
-            mod.decode_flags = mod.decode_flags & ~L.FF_FLOW
-        mod.flow_min_rows = args.flow_min_rows
-        if args.graphs == 1:
-            mod.decode_flags = mod.decode_flags | L.FF_GRAPH
-        elif args.graphs == 0:
-            mod.decode_flags = mod.decode_flags & ~L.FF_GRAPH
+    def apply_knobs(mod):
         mod.ln_fuse_max_rows = args.ln_fuse_max_rows
 
     def steps_executed(pred):   # pred [N, F, T] or [N, T]
@@ -794,7 +774,12 @@ def main():
 
         import threading
         cpu_thread = threading.Thread(target=cpu_job, name="cpu-baseline", daemon=True)
-        cpu_thread.start()
+
+    def start_cpu():
+        # beside the GPU-bound entries (C128 / E32) only: the launch-bound one-wireframe seq2seq entries lose 10-20 % when 32
+        # host threads compete with the launching thread (profiles/r05/bench_line_first.json: D 111.7 -> 133.2 ms)
+        if cpu_thread is not None and not cpu_thread.is_alive() and cpu_thread.ident is None:
+            cpu_thread.start()
 
     # ================================================================================================================
     # N = 1: the other BASELINE configurations in the same run (a few timed passes each)
@@ -834,25 +819,6 @@ def main():
                                              "note": "package default (x3_min_rows = %d), fp32-accurate; not the headline form" % X3_MIN_ROWS_DEFAULT}
             other[name] = ent
 
-        # C128: config 3's per-GPU share on this GPU (the model of the main line, a batch of 128 wireframes)
-        if "C128" in want:
-            bC = to_dev(make_wireframes([args.edges] * 128, L_lines, T, "parallel", seeds=list(range(128))))
-            par_entry("C128", model, bC, [args.edges] * 128, T,
-                      "BASELINE config 3's per-GPU share: 128 synthetic %d-edge wireframes in one call (configs/ours.yml, "
-                      "model.num_lines=%d), micro-batches of %d wireframes, default-xavier weights" % (args.edges, L_lines, args.chunk))
-            del bC
-        # E32: config 5's per-GPU share
-        if "E32" in want:
-            mE, cE, TE = parallel_model("ours-perspective.yml", 1024)
-            nE = config_e_edge_counts(8 * 32)[:32]
-            bE = to_dev(make_wireframes(nE, 1024, TE, "parallel", seeds=list(range(32))))
-            par_entry("E32", mE, bE, nE, TE,
-                      "BASELINE config 5's per-GPU share: 32 ragged wireframes, edge counts %s (configs/ours-perspective.yml, "
-                      "model.num_lines=1024, max_face_length %d), padding anchors de-duplicated, width-bucketed micro-batches"
-                      % ({str(k): nE.count(k) for k in E_SIZES}, TE))
-            other["E32"]["decoded_sequences"] = (getattr(mE, "last_decode_stats", None) or {}).get("decoded_seqs")
-            del mE, bE
-
         # D / A: the single-sequence model (SurfaceFormer), one wireframe, 258 steps with the gain-4 parity weights
         wbytes = decoder_weight_bytes()
         for name, cfg_file, n1, wseed, wfseed, mask_seed, what in (
@@ -871,7 +837,7 @@ def main():
             m1.load_state_dict(make_state_dict(state_dict_spec("seq2seq", L1, T1), "gain4", wseed))
             m1 = m1.eval().to(dev)
             m1.x3_min_rows = 0
-            apply_chain(m1)
+            apply_knobs(m1)
             K1 = max(3, K2)
             if name in want:
                 b1 = make_wireframes([n1], L1, T1, "seq2seq", seeds=[wfseed])
@@ -932,9 +898,30 @@ def main():
                 other[name + "64"] = e64
                 del b64
             del m1
+        start_cpu()
+        # C128: config 3's per-GPU share on this GPU (the model of the main line, a batch of 128 wireframes)
+        if "C128" in want:
+            bC = to_dev(make_wireframes([args.edges] * 128, L_lines, T, "parallel", seeds=list(range(128))))
+            par_entry("C128", model, bC, [args.edges] * 128, T,
+                      "BASELINE config 3's per-GPU share: 128 synthetic %d-edge wireframes in one call (configs/ours.yml, "
+                      "model.num_lines=%d), micro-batches of %d wireframes, default-xavier weights" % (args.edges, L_lines, args.chunk))
+            del bC
+        # E32: config 5's per-GPU share
+        if "E32" in want:
+            mE, cE, TE = parallel_model("ours-perspective.yml", 1024)
+            nE = config_e_edge_counts(8 * 32)[:32]
+            bE = to_dev(make_wireframes(nE, 1024, TE, "parallel", seeds=list(range(32))))
+            par_entry("E32", mE, bE, nE, TE,
+                      "BASELINE config 5's per-GPU share: 32 ragged wireframes, edge counts %s (configs/ours-perspective.yml, "
+                      "model.num_lines=1024, max_face_length %d), padding anchors de-duplicated, width-bucketed micro-batches"
+                      % ({str(k): nE.count(k) for k in E_SIZES}, TE))
+            other["E32"]["decoded_sequences"] = (getattr(mE, "last_decode_stats", None) or {}).get("decoded_seqs")
+            del mE, bE
+
         result["other_configs"] = other
 
     if cpu_thread is not None:
+        start_cpu()
         cpu_thread.join()
         wf_local = local[seeds.index(seed_cpu)]
         tried, sweep, rec, k, threads = cpu_raw["tried"], cpu_raw["sweep"], cpu_raw["rec"], cpu_raw["k"], cpu_raw["threads"]

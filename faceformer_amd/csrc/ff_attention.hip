@@ -20,7 +20,6 @@
 
 #include "ff_common.h"
 #include "ff_device.h"
-#include "ff_chain.h"
 
 // Timing experiment (tools/attn_phase_probe.py, -DFF_EXP_ATTN_STAMP): workgroup 0, wave 0 of the K/V-resident kernel stamps the
 // shader clock at entry, when K / V are in LDS, when its items are done, after the partial records are exchanged, at the end.
@@ -279,7 +278,7 @@ template <int NWAVES>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 4 ? 2 : 1)) void attention_wave_kernel(ff_attn_desc d, int q_tiles, int ks,
                                                                       long total_units, int tail_ok, int qtail) {
   __shared__ __attribute__((aligned(16))) float lds[ff_attention_wave_lds_floats(NWAVES)];
-  ff_attention_wave_block<NWAVES, false>(d, q_tiles, ks, total_units, tail_ok, qtail, (long)blockIdx.x, lds);
+  ff_attention_wave_block<NWAVES>(d, q_tiles, ks, total_units, tail_ok, qtail, (long)blockIdx.x, lds);
 }
 
 // ---- K/V-resident variant ------------------------------------------------------------------------------
@@ -727,7 +726,6 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
                "ff_attention: ld smaller than num_heads*64");
   FF_CHECK_ARG(d.q_inner > 0, "ff_attention: q_inner must be positive");
   hipStream_t st = (hipStream_t)stream;
-  if (ff_chain_recording()) return ff_chain_record_attention(d);   // operator of a chain launch (ff_chain.hip)
   const long gh = (long)d.num_groups * d.num_heads;
   int nw = d.nq > 64 ? 4 : (d.nq > 32 ? 2 : 1);
   const int q_tiles = ff_cdiv(d.nq, 32 * nw);

@@ -64,8 +64,8 @@ struct FFProfScope {
   }
 };
 
-// bumped by every setter that changes how an operator is launched (ff_set_gemm_tuning, ff_set_attention_algo): captured step
-// graphs (ff_engine.hip) are keyed on it
+// bumped by every setter that changes how an operator is launched (ff_set_gemm_tuning, ff_set_attention_algo): kept for
+// callers that cache launch decisions
 unsigned long long ff_tuning_epoch();
 void ff_tuning_changed();
 

@@ -1,99 +1,42 @@
-// Device-side building blocks shared by the stand-alone kernels (one launch per operator) and the chain kernel
-// (ff_chain.hip: many operators inside ONE persistent launch, separated by grid-wide phase boundaries).
-//
-// COH = true is the chain form: every value another workgroup of the SAME launch may have produced (activations, row
-// statistics, tokens) is read and written with agent-scope (sc1) accesses -- write-through stores that leave the
-// producing XCD's L2, loads that bypass the reading CU's vector L1 -- so that a grid-wide barrier needs no cache
-// maintenance of its own (MI355X: one L2 per XCD, one L1 per CU, neither refreshed by other CUs' stores).  Weights,
-// biases, tables, masks and everything else written BEFORE the launch keep plain cached loads.  COH = false compiles
-// to exactly the plain accesses the stand-alone kernels always had.
+// Device-side building blocks shared by the kernels of the library (one launch per operator): small typed access helpers,
+// the projection argument block, the small-M projection tile, the wave-per-unit attention block, the LayerNorm row and the
+// pointer head's row reduction.  (Until round 4 every helper also had an agent-coherent form for the persistent "chain"
+// launches of round 3; those were measured slower three ways -- DESIGN.md 8 -- and are gone.)
 #pragma once
 #include "ff_common.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Pointers of the chain form come out of operator descriptors in memory: the compiler cannot see that they are global
-// (it would emit flat_* accesses, which also tick the LDS counter and serialise the software pipelines), so every access
-// of the COH form goes through an explicit address_space(1) pointer.
 #define FF_GLOBAL __attribute__((address_space(1)))
 typedef unsigned long long ff_u64;
 
-template <bool COH>
-__device__ __forceinline__ f32x4 ff_ld16(const float* p) {
-  if (!COH) return *reinterpret_cast<const f32x4*>(p);
-  // two 8-byte agent-scope loads (the compiler tracks their vmcnt like any other load: no inline asm in pipelined code)
-  const FF_GLOBAL ff_u64* q = (const FF_GLOBAL ff_u64*)p;
-  const ff_u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const ff_u64 hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const f32x2 a = __builtin_bit_cast(f32x2, lo), b = __builtin_bit_cast(f32x2, hi);
-  return f32x4{a.x, a.y, b.x, b.y};
-}
-template <bool COH>
-__device__ __forceinline__ void ff_st16(float* p, f32x4 v) {
-  if (!COH) { *reinterpret_cast<f32x4*>(p) = v; return; }
-  FF_GLOBAL ff_u64* q = (FF_GLOBAL ff_u64*)p;
-  __hip_atomic_store(q, __builtin_bit_cast(ff_u64, f32x2{v.x, v.y}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 1, __builtin_bit_cast(ff_u64, f32x2{v.z, v.w}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ f32x2 ff_ld8(const float* p) {
-  if (!COH) return *reinterpret_cast<const f32x2*>(p);
-  return __builtin_bit_cast(f32x2, __hip_atomic_load((const FF_GLOBAL ff_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-template <bool COH>
-__device__ __forceinline__ void ff_st8(float* p, f32x2 v) {
-  if (!COH) { *reinterpret_cast<f32x2*>(p) = v; return; }
-  __hip_atomic_store((FF_GLOBAL ff_u64*)p, __builtin_bit_cast(ff_u64, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ float ff_ld4(const float* p) {
-  if (!COH) return *p;
-  return __hip_atomic_load((const FF_GLOBAL float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ void ff_st4(float* p, float v) {
-  if (!COH) { *p = v; return; }
-  __hip_atomic_store((FF_GLOBAL float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ int ff_ld4i(const int* p) {
-  if (!COH) return *p;
-  return __hip_atomic_load((const FF_GLOBAL int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ void ff_st4i(int* p, int v) {
-  if (!COH) { *p = v; return; }
-  __hip_atomic_store((FF_GLOBAL int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// data written BEFORE the launch (weights, biases, tables, masks, lengths, encoder memory): plain cached loads, global in
-// the chain form
+__device__ __forceinline__ f32x4 ff_ld16(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void ff_st16(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x2 ff_ld8(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ void ff_st8(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
+__device__ __forceinline__ float ff_ld4(const float* p) { return *p; }
+__device__ __forceinline__ void ff_st4(float* p, float v) { *p = v; }
+__device__ __forceinline__ int ff_ld4i(const int* p) { return *p; }
+__device__ __forceinline__ void ff_st4i(int* p, int v) { *p = v; }
 // The 16 accumulator rows of a lane (row0 + (e&3) + 8*(e>>2), one column) -> C.  Whole tiles -- the wave's 32 rows inside M --
 // take 16 unguarded stores in a row; only the last row tile of a launch takes the guarded form.
-template <bool COH>
 __device__ __forceinline__ void ff_store_tile(float* cp, int ldc, int row0, int col, int M, bool colok, const float (&v)[16]) {
   float* p = cp + (size_t)row0 * ldc + col;
   if (row0 - (row0 & 4) + 32 <= M) {   // wave-uniform (row0 differs by 4 between the lane halves): rows row0 .. row0 + 27 exist
     if (colok) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) ff_st4<COH>(p + (size_t)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
+      for (int e = 0; e < 16; ++e) ff_st4(p + (size_t)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
     }
   } else {
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      if (row0 + (e & 3) + 8 * (e >> 2) < M && colok) ff_st4<COH>(p + (size_t)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
+      if (row0 + (e & 3) + 8 * (e >> 2) < M && colok) ff_st4(p + (size_t)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
   }
 }
 
-template <bool COH>
-__device__ __forceinline__ f32x4 ff_ldw16(const float* p) {
-  if (!COH) return *reinterpret_cast<const f32x4*>(p);
-  return *(const FF_GLOBAL f32x4*)p;
-}
-template <bool COH, typename T>
-__device__ __forceinline__ T ff_ldw(const T* p) {
-  if (!COH) return *p;
-  return *(const FF_GLOBAL T*)p;
-}
+__device__ __forceinline__ f32x4 ff_ldw16(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <typename T>
+__device__ __forceinline__ T ff_ldw(const T* p) { return *p; }
 
 // ---- projection kernels: argument block ------------------------------------------------------------------------------
 struct GemmArgs {
@@ -134,7 +77,7 @@ __host__ __device__ constexpr int ff_gemm_small_lds_floats(int mode, int nw) {
 }
 
 // ---- small-M projection: one 32x32 output tile per workgroup, K split over the waves -----------------------------------
-template <int KQ, int MODE, int NW, bool COH>  // MODE: 0 plain, 1 LayerNorm-normalised A rows (+ row table), 2 emits row statistics of C
+template <int KQ, int MODE, int NW>  // MODE: 0 plain, 1 LayerNorm-normalised A rows (+ row table), 2 emits row statistics of C
 __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, long long bz, float* red) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int RPW = 16 / NW;  // accumulator registers (tile rows x 2 halves) a wave finishes
@@ -159,8 +102,8 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
   f32x4 a[2][GB], b[2][GB];
 #pragma unroll
   for (int j = 0; j < GB; ++j) {
-    a[0][j] = ff_ld16<COH>(ap + j * 8);
-    b[0][j] = ff_ldw16<COH>(wp + j * 8);
+    a[0][j] = ff_ld16(ap + j * 8);
+    b[0][j] = ff_ldw16(wp + j * 8);
   }
   float* lnrow = red + NW * 16 * 64 + (MODE == 2 ? 32 * 33 : 0);   // MODE 1: [32][2] (mean, rstd)
   f32x4 sv = {0.f, 0.f, 0.f, 0.f};
@@ -168,11 +111,11 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
   if (MODE == 1) {
     int r = m0 + srow;
     r = r < g.M ? r : g.M - 1;
-    if (2 * spart < g.ln_nseg) sv = ff_ld16<COH>(g.ln_in + ((size_t)r * g.ln_nseg + 2 * spart) * 2);
+    if (2 * spart < g.ln_nseg) sv = ff_ld16(g.ln_in + ((size_t)r * g.ln_nseg + 2 * spart) * 2);
   }
   const int ocol = n0 + l32;
   const bool colok = ocol < g.N;
-  const float bv = (g.bias && colok) ? ff_ldw<COH>(g.bias + ocol) : 0.f;
+  const float bv = (g.bias && colok) ? ff_ldw(g.bias + ocol) : 0.f;
   const bool tab = MODE == 1 && g.rowtab != nullptr && !g.res;
   float rv[RPW];
   int orow[RPW], prow[RPW];
@@ -183,9 +126,9 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
     orow[q] = m0 + prow[q];
     const bool ok = colok && orow[q] < g.M;
     rv[q] = 0.f;
-    if (g.res) { if (ok) rv[q] = ff_ld4<COH>(g.res + bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol); }
+    if (g.res) { if (ok) rv[q] = ff_ld4(g.res + bz * g.batch_stride_c + (size_t)orow[q] * g.ldr + ocol); }
     else if (tab && ok && ocol < g.rowtab_cols)
-      rv[q] = ff_ldw<COH>(g.rowtab + (size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol);
+      rv[q] = ff_ldw(g.rowtab + (size_t)(orow[q] / g.rowtab_div) * g.ld_rowtab + ocol);
   }
   __builtin_amdgcn_sched_barrier(0);
   float mu = 0.f, rs = 1.f;
@@ -213,8 +156,8 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
     if (g0 + GB < NG) {
 #pragma unroll
       for (int j = 0; j < GB; ++j) {
-        a[cur ^ 1][j] = ff_ld16<COH>(ap + (g0 + GB + j) * 8);
-        b[cur ^ 1][j] = ff_ldw16<COH>(wp + (g0 + GB + j) * 8);
+        a[cur ^ 1][j] = ff_ld16(ap + (g0 + GB + j) * 8);
+        b[cur ^ 1][j] = ff_ldw16(wp + (g0 + GB + j) * 8);
       }
     }
 #pragma unroll
@@ -251,7 +194,7 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
   }
 #pragma unroll
   for (int q = 0; q < RPW; ++q)
-    if (colok && orow[q] < g.M) ff_st4<COH>(Cout + (size_t)orow[q] * g.ldc + ocol, o[q]);
+    if (colok && orow[q] < g.M) ff_st4(Cout + (size_t)orow[q] * g.ldc + ocol, o[q]);
   if (MODE == 2) {  // row statistics of the finished 32x32 tile: 64 threads, (row, column half) each
     __syncthreads();
     if (tid < 64) {
@@ -266,7 +209,7 @@ __device__ __forceinline__ void ff_gemm_small_tile(const GemmArgs& g, int tile, 
       m2 = ff_halves_sum(m2);
       const int r = m0 + l32;
       if (half == 0 && r < g.M) {
-        ff_st8<COH>(g.ln_out + ((size_t)r * (g.N >> 5) + (n0 >> 5)) * 2, f32x2{mean, m2});
+        ff_st8(g.ln_out + ((size_t)r * (g.N >> 5) + (n0 >> 5)) * 2, f32x2{mean, m2});
       }
     }
   }
@@ -281,7 +224,7 @@ __host__ __device__ constexpr int ff_attention_wave_lds_floats(int nwaves) {
   return nwaves * (32 * FF_ATTN_K_LD) + nwaves * 32 + nwaves * (nwaves == 4 ? (3 * 8 * 64 + 40 * 8 + 8) : 0);
 }
 
-template <int NWAVES, bool COH>
+template <int NWAVES>
 __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, int q_tiles, int ks, long total_units, int tail_ok,
                                                         int qtail, long vblock, float* lds) {
   constexpr int K_LD = FF_ATTN_K_LD;
@@ -320,7 +263,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
     const float* qp = d.q + qrow * d.ldq + h * FF_HEAD_DIM + half * 32;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      f32x4 t = ff_ld16<COH>(qp + c * 4);
+      f32x4 t = ff_ld16(qp + c * 4);
       qreg[c * 4 + 0] = t.x * qscale;
       qreg[c * 4 + 1] = t.y * qscale;
       qreg[c * 4 + 2] = t.z * qscale;
@@ -350,11 +293,11 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
     for (int p = 0; p < 8; ++p) {
       const int key = kt * 32 + srow + 4 * p;
       const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
-      kst[p] = ff_ld16<COH>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
+      kst[p] = ff_ld16(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
     }
     if (mrow && lane < 32) {
       const int key = kt * 32 + lane;
-      mbyte = key < nk_s ? ff_ldw<COH>(mrow + key) : (unsigned char)1;
+      mbyte = key < nk_s ? ff_ldw(mrow + key) : (unsigned char)1;
     }
   };
   auto load_v = [&](int kt) {   // V fragments straight to registers (each load instruction reads two full 128-byte row segments)
@@ -363,8 +306,8 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
       const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
       const float* vp = vbase + (size_t)kc * d.k_stride * d.ldv + l32;
-      v0[r] = ff_ld4<COH>(vp);
-      v1[r] = ff_ld4<COH>(vp + 32);
+      v0[r] = ff_ld4(vp);
+      v1[r] = ff_ld4(vp + 32);
     }
   };
   auto wave_fence = [&]() {
@@ -383,20 +326,20 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
     for (int p = 0; p < 2; ++p) {
       const int key = 32 + srow + 4 * p;
       const int kc = key < nk_s ? key : (nk_s > 0 ? nk_s - 1 : 0);
-      tk[p] = ff_ld16<COH>(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
-      tv[p] = ff_ld16<COH>(vbase + (size_t)kc * d.k_stride * d.ldv + sc4 * 4);
+      tk[p] = ff_ld16(kbase + (size_t)kc * d.k_stride * d.ldk + sc4 * 4);
+      tv[p] = ff_ld16(vbase + (size_t)kc * d.k_stride * d.ldv + sc4 * 4);
       if (q_extra) {
         const int r = srow + 4 * p;
         const int qx = q_tiles * 32 + (r < qtail ? r : qtail - 1);
         const size_t xr = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
-        tq[p] = ff_ld16<COH>(d.q + xr * d.ldq + h * FF_HEAD_DIM + sc4 * 4);
+        tq[p] = ff_ld16(d.q + xr * d.ldq + h * FF_HEAD_DIM + sc4 * 4);
       }
     }
-    if (mrow && lane < 8) tmb = (32 + lane) < nk_s ? ff_ldw<COH>(mrow + 32 + lane) : (unsigned char)1;
+    if (mrow && lane < 8) tmb = (32 + lane) < nk_s ? ff_ldw(mrow + 32 + lane) : (unsigned char)1;
   }
   int nk = nk_s;
   if (d.kv_len) {
-    const int kl = ff_ldw<COH>(d.kv_len + g);
+    const int kl = ff_ldw(d.kv_len + g);
     nk = kl < nk ? kl : nk;
   }
   if (tails) {
@@ -569,7 +512,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
           acc.w += r[192] * sc[j];
         }
       acc.x *= inv_c; acc.y *= inv_c; acc.z *= inv_c; acc.w *= inv_c;
-      ff_st16<COH>(op + (e0 < 16 ? 2 * e0 : 32 + 2 * (e0 - 16)), acc);
+      ff_st16(op + (e0 < 16 ? 2 * e0 : 32 + 2 * (e0 - 16)), acc);
     }
     return;   // (the key-split form never carries short tails: nothing below applies)
   }
@@ -581,8 +524,8 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 a = {o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv, o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv};
       f32x4 b = {o1[g4 * 4 + 0] * inv, o1[g4 * 4 + 1] * inv, o1[g4 * 4 + 2] * inv, o1[g4 * 4 + 3] * inv};
-      ff_st16<COH>(op + 8 * g4, a);
-      ff_st16<COH>(op + 32 + 8 * g4, b);
+      ff_st16(op + 8 * g4, a);
+      ff_st16(op + 32 + 8 * g4, b);
     }
   }
 
@@ -656,7 +599,7 @@ __device__ __forceinline__ void ff_attention_wave_block(const ff_attn_desc& d, i
         const float s1 = ff_halves_sum(a1[i]);
         const int qx = q_tiles * 32 + i;
         const size_t xr = (size_t)g * d.q_group_stride + (size_t)(qx / d.q_inner) * d.q_outer_stride + (size_t)(qx % d.q_inner);
-        ff_st4<COH>(d.o + xr * d.ldo + h * FF_HEAD_DIM + 32 * half + l32, half ? s1 : s0);
+        ff_st4(d.o + xr * d.ldo + h * FF_HEAD_DIM + 32 * half + l32, half ? s1 : s0);
       }
     }
   }
@@ -674,7 +617,7 @@ struct LnArgs {
   int rows, E;
 };
 
-template <int NV, bool COH>
+template <int NV>
 __device__ __forceinline__ void ff_layernorm_row(const LnArgs& a, int row, int lane) {
   const int nvec = a.E >> 2;
   const float* xr = a.x + (size_t)row * a.ldx;
@@ -684,7 +627,7 @@ __device__ __forceinline__ void ff_layernorm_row(const LnArgs& a, int row, int l
   for (int c = 0; c < NV; ++c) {
     int vi = lane + c * 64;
     if (vi < nvec) {
-      v[c] = ff_ld16<COH>(xr + vi * 4);
+      v[c] = ff_ld16(xr + vi * 4);
       s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
     } else {
       v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -709,13 +652,13 @@ __device__ __forceinline__ void ff_layernorm_row(const LnArgs& a, int row, int l
   for (int c = 0; c < NV; ++c) {
     int vi = lane + c * 64;
     if (vi < nvec) {
-      f32x4 g = ff_ldw16<COH>(a.gamma + vi * 4);
-      f32x4 b = ff_ldw16<COH>(a.beta + vi * 4);
+      f32x4 g = ff_ldw16(a.gamma + vi * 4);
+      f32x4 b = ff_ldw16(a.beta + vi * 4);
       f32x4 o = (v[c] - mean) * rstd * g + b;
-      if (a.y != nullptr) ff_st16<COH>(a.y + (size_t)row * a.ldy + vi * 4, o);
+      if (a.y != nullptr) ff_st16(a.y + (size_t)row * a.ldy + vi * 4, o);
       if (a.ypos != nullptr) {
-        f32x4 p = ff_ldw16<COH>(pr + vi * 4);
-        ff_st16<COH>(a.ypos + (size_t)row * a.ldypos + vi * 4, o + p);
+        f32x4 p = ff_ldw16(pr + vi * 4);
+        ff_st16(a.ypos + (size_t)row * a.ldypos + vi * 4, o + p);
       }
     }
   }
@@ -736,11 +679,10 @@ struct PointerArgs {
 // `logits` holds the raw dot products of every (sequence, key); mask the row in place and reduce (value, index) pairs --
 // per lane over its strided keys, then across the 64 lanes with a butterfly that keeps torch's tie rule (lowest index)
 // and the runner-up value.
-template <bool COH>
 __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int b, int lane) {
   const int w = b / a.spg;
   int kv = a.S;
-  if (a.kv_len) { const int k = ff_ldw<COH>(a.kv_len + w); kv = k < kv ? k : kv; }
+  if (a.kv_len) { const int k = ff_ldw(a.kv_len + w); kv = k < kv ? k : kv; }
   const unsigned char* mrow = a.mask ? a.mask + (size_t)w * a.S : nullptr;
   const unsigned char* erow = a.extra ? a.extra + (size_t)b * a.ldextra : nullptr;
   float* lrow = a.logits + (size_t)b * a.ldlogits;
@@ -749,10 +691,10 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
   int i1 = 0x7fffffff;
   for (int s = lane; s < a.S; s += 64) {
     bool ok = s < kv;
-    if (ok && mrow) ok = ff_ldw<COH>(mrow + s) == 0;
-    if (ok && erow) ok = ff_ldw<COH>(erow + s) == 0;
-    const float v = ok ? ff_ld4<COH>(lrow + s) : FILL;
-    ff_st4<COH>(lrow + s, v);
+    if (ok && mrow) ok = ff_ldw(mrow + s) == 0;
+    if (ok && erow) ok = ff_ldw(erow + s) == 0;
+    const float v = ok ? ff_ld4(lrow + s) : FILL;
+    ff_st4(lrow + s, v);
     if (v > b1) { b2 = b1; b1 = v; i1 = s; }
     else if (v > b2) b2 = v;
   }
@@ -767,9 +709,9 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
   }
   if (i1 == 0x7fffffff) { i1 = 0; b1 = FILL; }
   if (lane == 0) {
-    ff_st4i<COH>(a.next_tok + b, i1);
-    if (a.best) ff_st4<COH>(a.best + b, b1);
-    if (a.second) ff_st4<COH>(a.second + b, b2);
+    ff_st4i(a.next_tok + b, i1);
+    if (a.best) ff_st4(a.best + b, b1);
+    if (a.second) ff_st4(a.second + b, b2);
     if (a.count_ge && i1 >= a.ge_bound) atomicAdd(a.count_ge, 1);
     if (a.count_eq && i1 == a.eq_value) atomicAdd(a.count_eq, 1);
   }
@@ -777,6 +719,6 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
     const float* src = a.memory + ((size_t)w * a.S + i1) * a.E;
     float* dst = a.next_rows + (size_t)b * a.ldnext;
     for (int vi = lane; vi < (a.E >> 2); vi += 64)
-      ff_st16<COH>(dst + vi * 4, ff_ldw16<COH>(src + vi * 4));
+      ff_st16(dst + vi * 4, ff_ldw16(src + vi * 4));
   }
 }

@@ -21,7 +21,6 @@
 #include <vector>
 
 #include "ff_common.h"
-#include "ff_chain.h"
 
 namespace {
 
@@ -136,8 +135,7 @@ inline bool x3_wins(const ff_decode_params* prm, int M, int N, int K) {
 int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, int lda, const float* A2, int n_split,
                const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M,
                int N, int K, int act, hipStream_t st) {
-  if (planes && x3_wins(prm, M, N, K) && (!A2 || (n_split % 128) == 0) &&
-      !ff_chain_recording())   // (a chain launch runs every projection on the small-M f32 kernel)
+  if (planes && x3_wins(prm, M, N, K) && (!A2 || (n_split % 128) == 0))
     return ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
   return gemm(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, st);
 }
@@ -274,12 +272,9 @@ bool can_fuse_layernorm(const ff_model* m, const ff_decode_params* prm) {
 // by a projection with a residual (out-proj, linear2), which leaves per-row segment statistics in `lnstat`; the
 // projection that consumes LN(x) (+ qpos) reads x and the statistics and applies gamma / beta / qpos W^T through
 // folded weights (ff_gemm_f32_ln).  19 -> 1 LayerNorm launches per decode step of a 6-layer decoder.
-// phase: 0 the whole pass; 1 only its HEAD -- every layer but the last, and the self-attention q|k|v projections of the last
-// layer (the launches that still have all t * Bc rows when the last layer is pruned to its newest position); 2 only the TAIL
-// -- the rest of the last layer, decoder.norm and project (Bc rows each: what a chain launch takes over on the large steps).
 int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuffers& bufs, const Scratch& buf,
                  const Chunk& ck, const unsigned char* mask, const int* kv_len, int t, bool full_rows,
-                 float* proj_all, hipStream_t st, int phase = 0) {
+                 float* proj_all, hipStream_t st) {
   const int E = m->E, FFd = m->FF, H = m->H, S = prm->L + m->num_token, F = ck.Fc, T = prm->T;
   const int Bc = ck.Bc, R = t * Bc, nd = m->num_dec_layers;
   const size_t newoff = (size_t)(t - 1) * Bc;
@@ -302,15 +297,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows
                        : ((x3_folds || (!x3_bound && E == 512)) ? (1 << 30)
                           : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288));
-  // Flow launches (FF_FLOW): the dependent projections between two attention operators -- out-proj -> q-proj and
-  // out-proj -> linear1 -> linear2 -> the next layer's q|k|v -- run inside ONE persistent launch each, tile by tile behind
-  // row-panel dependency counters (ff_gemm.hip: gemm_flow_kernel).  They need the LayerNorm-folded forms, so a step that takes
-  // them folds at every size; steps below flow_min_rows rows keep the small-M kernels.
-  const int flow_min = prm->flow_min_rows > 0 ? prm->flow_min_rows : 1025;
-  const bool flow = (prm->flags & FF_FLOW) && can_fuse_layernorm(m, prm) && R >= flow_min && (E % 64) == 0 && (FFd % 64) == 0 &&
-                    !ff_chain_recording() && getenv("FF_NO_FLOW") == nullptr &&
-                    (getenv("FF_FLOW_MAX_ROWS") == nullptr || R <= atoi(getenv("FF_FLOW_MAX_ROWS")));   // (probe knob)
-  const bool fuse = can_fuse_layernorm(m, prm) && (R <= fuse_max || flow);
+  const bool fuse = can_fuse_layernorm(m, prm) && R <= fuse_max;
   const int nseg = E / 32;
   const float* qpos = m->qpos_table;
   const float* qpos_new = qpos + (size_t)(t - 1) * E;
@@ -328,8 +315,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     d.ln_stats_in = st_in; d.ln_nseg = K / 32; d.ln_eps = m->ln_eps;
     d.row_table = table; d.ld_row_table = ldt; d.row_div = Bc; d.row_cols = tcols;
     d.ln_stats_out = st_out;
-    if (planes && x3_wins(prm, M, N, K) && (!st_in || K == 512) && (!table || (tcols & 3) == 0) && !ff_chain_recording() &&
-        !ff_flow_recording())
+    if (planes && x3_wins(prm, M, N, K) && (!st_in || K == 512) && (!table || (tcols & 3) == 0))
       return ff_gemm_x3_ln(&d, planes, plane_rows, row0, st_in ? colsum : nullptr, st);
     return ff_gemm_f32_ln(&d, st);
   };
@@ -344,39 +330,22 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     return gemm_ln(buf.x, E, w2.ln1_w, E, w2.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat, w2.ln1_pos, 2 * E,
                    2 * E, nullptr, w2.ln1_planes, 3 * E, 0, w2.ln1_csum);
   };
-  // runs `ops` (a few dependent projections) as ONE flow launch when possible, operator by operator otherwise
-  auto flow_or_launch = [&](bool want_flow, auto&& ops) -> int {
-    if (want_flow) {
-      int launched = 0;
-      FF_RETURN_IF(ff_flow_begin());
-      const int rc = ops();
-      if (rc != FF_OK) { ff_chain_abort(); return rc; }
-      FF_RETURN_IF(ff_flow_end(st, &launched));
-      if (launched) return FF_OK;
-    }
-    return ops();
-  };
-  bool first_done = false;   // the previous layer's flow launch already ran this layer's first projection
-  for (int l = (phase == 2 ? nd - 1 : 0); l < nd; ++l) {
+  for (int l = 0; l < nd; ++l) {
     const ff_layer_weights& w = m->dec[l];
     const bool last = prune_last && (l == nd - 1);
     const float* xin = (l == 0) ? ck.x0 : buf.x;
     const float* QKV;
     // ---- self attention: q = k = LN1(x) + qpos, v = LN1(x), no mask (transformer.py:242-246) ----
-    if (phase == 2) {   // the head already projected q|k|v of this (last) layer
-      QKV = (l == 0 && reuse0) ? ck.qkv0 : buf.qkv;
-    } else if (l == 0 && reuse0) {
+    if (l == 0 && reuse0) {
       FF_RETURN_IF(ff_layernorm(xin + newoff * E, E, w.norm1_w, w.norm1_b, m->ln_eps, buf.y, E, buf.yq, E,
                                 qpos_new, E, Bc, 1, Bc, E, st));
       FF_RETURN_IF(gemm(buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
                         ck.qkv0 + newoff * 3 * E, 3 * E, Bc, 3 * E, E, 0, st));
       QKV = ck.qkv0;
     } else if (fuse && l > 0) {
-      if (!first_done) FF_RETURN_IF(first_proj(l));
-      first_done = false;
+      FF_RETURN_IF(first_proj(l));
       if (last && t > 1) {
         // the pruned last layer attends from its newest position only: k | v for every row (above), q for the last Bc rows
-        ff_chain_next_is_independent();   // (chain launches: k|v and q share a phase)
         FF_RETURN_IF(gemm_ln(xin + newoff * E, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E,
                              0, buf.lnstat + newoff * nseg * 2, w.ln1_pos + (size_t)(t - 1) * 2 * E, 2 * E, E, nullptr));
       }
@@ -390,7 +359,6 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
         // pruned last layer: k (from LN(x)+qpos) | v (from LN(x)) for every row, q for the newest position only
         FF_RETURN_IF(gemm(buf.yq, E, buf.y, E, w.self_attn.in_proj_w + (size_t)E * E, E, w.self_attn.in_proj_b + E, nullptr,
                           0, buf.qkv + E, 3 * E, R, 2 * E, E, 0, st));
-        ff_chain_next_is_independent();
         FF_RETURN_IF(gemm(buf.yq + newoff * E, E, nullptr, 0, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
                           buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E, 0, st));
       } else {
@@ -399,7 +367,6 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       }
       QKV = buf.qkv;
     }
-    if (phase == 1 && l == nd - 1) return FF_OK;
     // rows that continue through the rest of this layer
     const size_t roff = last ? newoff : 0;
     const int Rl = last ? Bc : R;
@@ -419,15 +386,12 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       FF_RETURN_IF(ff_attention(&d, st));
     }
     float* qc = buf.qkv;  // [rows, E] view of the scratch
-    const bool flow_here = flow && Rl >= flow_min;
     if (fuse) {
-      FF_RETURN_IF(flow_or_launch(flow_here, [&]() -> int {
-        FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
-                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.self_out_planes, E, 0));
-        // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
-        return gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
-                       w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr, w.ln2_planes, E, 0, w.ln2_csum);
-      }));
+      FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
+                           buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.self_out_planes, E, 0));
+      // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
+      FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
+                           w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr, w.ln2_planes, E, 0, w.ln2_csum));
     } else {
       FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
                               w.self_attn.out_b, xin + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
@@ -459,19 +423,13 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       FF_RETURN_IF(ff_attention(&d, st));
     }
     if (fuse) {
-      // the flow launch also takes the next layer's first projection (same R rows) when there is one
-      const bool with_next = flow_here && !last && l + 1 < nd;
-      FF_RETURN_IF(flow_or_launch(flow_here, [&]() -> int {
-        FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.cross_attn.out_w, E, w.cross_attn.out_b, buf.x + roff * E, E,
-                             buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.cross_out_planes, E, 0));
-        // ---- feed forward (transformer.py:253-255) ----
-        FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln3_w, E, w.ln3_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl, FFd, E, 1,
-                             stat, nullptr, 0, 0, nullptr, w.ln3_planes, FFd, 0, w.ln3_csum));
-        FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
-                             Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat, w.lin2_planes, E, 0));
-        return with_next ? first_proj(l + 1) : FF_OK;
-      }));
-      first_done = with_next;
+      FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.cross_attn.out_w, E, w.cross_attn.out_b, buf.x + roff * E, E,
+                           buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.cross_out_planes, E, 0));
+      // ---- feed forward (transformer.py:253-255) ----
+      FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln3_w, E, w.ln3_b, nullptr, 0, buf.h + roff * FFd, FFd, Rl, FFd, E, 1,
+                           stat, nullptr, 0, 0, nullptr, w.ln3_planes, FFd, 0, w.ln3_csum));
+      FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
+                           Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat, w.lin2_planes, E, 0));
     } else {
       FF_RETURN_IF(gemm_or_x3(prm, w.cross_out_planes, buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E,
                               w.cross_attn.out_b, buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
@@ -544,51 +502,6 @@ int pool_get(int n, StreamPool** out) {
   }
   *out = &pool;
   return FF_OK;
-}
-
-// ---- step graphs (FF_GRAPH) ----------------------------------------------------------------------------------------------
-// A decode step of a small micro-batch is ~50 dependent launches of a few microseconds each, and on a stream every one
-// of them pays the full dependent-dispatch cost (tools/ubench/launch_floor.hip: 4.6-5.3 us per small kernel that writes
-// memory, 1.5-2.3 us for the same kernels as nodes of a hipGraph).  The launches of step t are a pure function of the
-// call's arguments (tokens travel through device memory), so the steps of a decode whose arguments were seen before
-// are captured once -- one graph per step, so that the host's stop rule keeps working between them -- and replayed.
-struct StepGraphs {
-  std::string key;                     // every byte the launches depend on (graph_key)
-  std::vector<hipGraphExec_t> exec;    // [step]; nullptr: not captured
-  int seen;                            // decodes that presented this key
-  unsigned long long last_use;
-};
-struct GraphCache {
-  std::vector<StepGraphs> entries;
-  unsigned long long tick;
-};
-GraphCache g_graph_cache[FF_MAX_DEVICES];   // guarded by g_pool_busy[dev] (one decode per device at a time)
-std::atomic<int> g_graph_last_captured{0}, g_graph_last_replayed{0};   // steps of the calling process's latest ff_decode
-constexpr size_t FF_GRAPH_ENTRIES = 8;
-
-void graphs_release(StepGraphs& e) {
-  for (hipGraphExec_t g : e.exec) if (g) (void)hipGraphExecDestroy(g);
-  e.exec.clear();
-}
-
-template <typename T>
-void key_add(std::string& k, const T& v) { k.append(reinterpret_cast<const char*>(&v), sizeof(T)); }
-
-// The entry of `key` (created on first sight; least recently used entry evicted).  Callers hold the device's busy mutex
-// and every earlier decode has drained its streams, so no graph of an evicted entry is still running.
-StepGraphs* graphs_lookup(int dev, const std::string& key, int max_steps) {
-  GraphCache& gc = g_graph_cache[dev];
-  ++gc.tick;
-  for (StepGraphs& e : gc.entries)
-    if (e.key == key) { e.last_use = gc.tick; ++e.seen; return &e; }
-  if (gc.entries.size() >= FF_GRAPH_ENTRIES) {
-    size_t lru = 0;
-    for (size_t i = 1; i < gc.entries.size(); ++i) if (gc.entries[i].last_use < gc.entries[lru].last_use) lru = i;
-    graphs_release(gc.entries[lru]);
-    gc.entries.erase(gc.entries.begin() + lru);
-  }
-  gc.entries.push_back(StepGraphs{key, std::vector<hipGraphExec_t>((size_t)max_steps, nullptr), 1, gc.tick});
-  return &gc.entries.back();
 }
 
 std::mutex* pool_busy_mutex() {
@@ -664,11 +577,6 @@ extern "C" int ff_encode(const ff_model* m, const float* input, const unsigned c
   return FF_OK;
 }
 
-extern "C" void ff_graph_stats(int* captured_steps, int* replayed_steps) {
-  if (captured_steps) *captured_steps = g_graph_last_captured.load();
-  if (replayed_steps) *replayed_steps = g_graph_last_replayed.load();
-}
-
 extern "C" size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p, const int* num_input_host) {
   if (!m || !p || p->N <= 0 || p->F <= 0 || p->T <= 0) return 0;
   int btot = 0, max_bc = 0;
@@ -690,12 +598,6 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_CHECK_ARG(memory && mask && kv_len && predict && workspace, "ff_decode: null pointer");
   FF_CHECK_ARG(p->variant != FF_PARALLEL || num_input, "ff_decode: num_input required for the parallel variant");
   FF_CHECK_ARG(p->variant != FF_SEQ2SEQ || p->F == 1, "ff_decode: seq2seq decodes one sequence per wireframe");
-#ifndef FF_EXPERIMENTAL
-  FF_CHECK_ARG(!(p->flags & (FF_CHAIN | FF_FLOW | FF_GRAPH)),
-               "ff_decode: FF_CHAIN / FF_FLOW / FF_GRAPH are compiled into the experimental build of the library only "
-               "(python -m faceformer_amd.hip.build --experimental -> libfaceformer_hip_exp.so; measured slower than "
-               "launch-per-operator, DESIGN.md 8)");
-#endif
   FF_CHECK_ARG(!p->stop_fn || (p->flags & FF_NO_STOP) || p->sync_every > 0, "ff_decode: stop_fn needs sync_every > 0");
   // The callback's cadence is a CONTRACT with callers that replay it elsewhere (an idle rank of a sharded decode joins the
   // same host collectives: faceformer_amd/dist.py check_points): the counters of the first n = enq - sync_every steps when
@@ -727,11 +629,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
   }
   const int ns = ns_req < (int)chunks.size() ? ns_req : (int)chunks.size();
-  // Step graphs: single-stream decodes only (a micro-batch per stream has steps long enough not to need them), never while
-  // the per-launch event profile is on (events inside a capture would time nothing), never with the persistent launches.
-  const bool use_graph = (p->flags & FF_GRAPH) && ns == 1 && !(p->flags & (FF_CHAIN | FF_FLOW)) && !ff_prof_enabled() &&
-                         getenv("FF_NO_GRAPH") == nullptr;
-  const bool forked = ns > 1 || use_graph;   // the decode runs on the pool's streams (a capture cannot start on the legacy default stream)
+  const bool forked = ns > 1;
   // With more than one stream ALL micro-batch work runs on the internal pool (the caller's stream is
   // often the legacy default stream, whose implicit synchronisation would serialise the others).
   hipStream_t sts[FF_MAX_STREAMS];
@@ -749,39 +647,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     return FF_OK;
   };
 
-  // Chain launches need every workgroup of the launch resident: one stream only (two chain launches interleaving on the
-  // CUs could wait for each other for ever), and operand widths the small-M projection forms take.
-  auto chain_dim_ok = [](int k) { return k == 128 || k == 256 || k == 512 || k == 1024; };
-  const bool use_chain = (p->flags & FF_CHAIN) && ns == 1 && chain_dim_ok(E) && chain_dim_ok(m->FF) && getenv("FF_NO_CHAIN") == nullptr;
-  if (ns != 1) prm_local.flags &= ~(FF_CHAIN | FF_FLOW);   // (p points at prm_local) persistent launches: one stream only
-  const bool use_flow = (p->flags & FF_FLOW) != 0;
-  const long chain_rows = p->chain_max_rows > 0 ? p->chain_max_rows : 1024;
-  int chain_launches = 0;
   int enq = 0;
-  StepGraphs* graphs = nullptr;
-  // steps per graph: the stop rule is looked at between graphs only (a graph launch costs the host ~55 us)
-  const int graph_steps = getenv("FF_GRAPH_STEPS") && atoi(getenv("FF_GRAPH_STEPS")) > 0 && !p->stop_fn   // (stop_fn: its cadence)
-                              ? atoi(getenv("FF_GRAPH_STEPS"))
-                              : (p->sync_every > 0 && !(p->flags & FF_NO_STOP) ? p->sync_every : T);
-  if (use_graph) {
-    int dev = 0;
-    FF_CHECK_HIP(hipGetDevice(&dev));
-    std::string key;
-    {   // the host callback is not part of what a captured step does: a caller that passes a fresh thunk per call must still hit
-      ff_decode_params kp = prm_local;
-      kp.stop_fn = nullptr; kp.stop_user = nullptr;
-      key_add(key, *m); key_add(key, kp);
-    }
-    const void* ptrs[] = {memory, mask, kv_len, num_input, extra_mask, trace_logits, trace_best, trace_second, workspace, (const void*)sts[0]};
-    key_add(key, ptrs); key_add(key, workspace_bytes); key_add(key, ff_tuning_epoch()); key_add(key, graph_steps);
-    for (const Chunk& c : chunks) {   // (field by field: the struct has padding bytes)
-      const int ci[] = {c.w0, c.nw, c.Fc, c.f0, c.b0, c.Bc, c.sid};
-      const void* cp[] = {c.x0, c.qkv0};
-      key_add(key, ci); key_add(key, cp);
-    }
-    graphs = graphs_lookup(dev, key, T - 1);
-  }
-  int graph_replays = 0, graph_captures = 0;
   // Everything that enqueues work on the side streams sits in this lambda: on ANY failure the streams are
   // drained before the error is returned (the caller frees the workspace the queued kernels use).
   auto run = [&]() -> int {
@@ -811,8 +677,6 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
 
     // ---- greedy loop -----------------------------------------------------------------------------------
     const int max_steps = T - 1;
-    if (use_chain || use_flow)   // descriptor ring + sync words of this decode (zeroed behind the work queued so far)
-      FF_RETURN_IF(ff_chain_prepare((size_t)max_steps * chunks.size() * (size_t)(12 * m->num_dec_layers + 16), main_st));
     const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
     // Stop rule on the host WITHOUT draining the queue: every sync_every steps the counters of the steps enqueued so
@@ -847,60 +711,16 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
               trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
               c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st);
         };
-        // Chain launches (FF_CHAIN): a step with at most chain_rows active rows is ONE persistent launch; a larger step
-        // launches its head operator by operator and hands the last layer's newest-position tail + the pointer head (Bc
-        // rows each) to one chain launch.  An operator the chain forms cannot take leaves the recording unlaunched and
-        // the same operators are enqueued one by one.
-        int phase_done = 0;   // 0 nothing enqueued yet, 1 head enqueued, 2 everything enqueued
-        if (use_chain) {
-          const bool whole = (long)t * c.Bc <= chain_rows;
-          const bool tail = !whole && (p->flags & FF_LAST_LAYER_LAST_ROW) && c.Bc <= chain_rows;
-          if (whole || tail) {
-            int launched = 0;
-            if (tail) { FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, 1)); phase_done = 1; }
-            FF_RETURN_IF(ff_chain_begin());
-            int rc = decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, tail ? 2 : 0);
-            if (rc == FF_OK) rc = pointer_head();
-            if (rc != FF_OK) { ff_chain_abort(); return rc; }
-            FF_RETURN_IF(ff_chain_end(st, &launched));
-            if (launched) { phase_done = 2; ++chain_launches; }
-          }
-        }
-        if (phase_done < 2) {
-          FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, phase_done == 1 ? 2 : 0));
-          FF_RETURN_IF(pointer_head());
-        }
+        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
+        FF_RETURN_IF(pointer_head());
       }
       return FF_OK;
     };
-    const int gsteps = graphs ? graph_steps : 1;
     for (int step = 0; step < max_steps && !stopped;) {
-      const int nstep = gsteps < max_steps - step ? gsteps : max_steps - step;
-      hipGraphExec_t ge = nullptr;
-      if (graphs) {
-        // second sight of these arguments: capture the steps; from then on: replay
-        hipGraphExec_t& slot = graphs->exec[(size_t)step];
-        if (!slot && graphs->seen >= 2) {
-          FF_CHECK_HIP(hipStreamBeginCapture(sts[0], hipStreamCaptureModeRelaxed));
-          int rc = FF_OK;
-          for (int i = 0; i < nstep && rc == FF_OK; ++i) rc = enqueue_step(step + i);
-          hipGraph_t g = nullptr;
-          const hipError_t e = hipStreamEndCapture(sts[0], &g);
-          if (rc != FF_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-          FF_CHECK_HIP(e);
-          const hipError_t ei = hipGraphInstantiate(&slot, g, nullptr, nullptr, 0);
-          (void)hipGraphDestroy(g);
-          if (ei != hipSuccess) slot = nullptr;
-          FF_CHECK_HIP(ei);
-          graph_captures += nstep;
-        }
-        ge = slot;
-      }
-      if (ge) { FF_CHECK_HIP(hipGraphLaunch(ge, sts[0])); graph_replays += nstep; }
-      else for (int i = 0; i < nstep; ++i) FF_RETURN_IF(enqueue_step(step + i));
-      step += nstep;
+      FF_RETURN_IF(enqueue_step(step));
+      ++step;
       enq = step;
-      if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && ((enq % p->sync_every) == 0 || nstep > 1) && enq < max_steps) {
+      if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
         const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
         if (lagged) {
           if (pending_enq > 0) {
@@ -927,15 +747,13 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
         }
       }
     }
-    g_graph_last_captured = graph_captures;
-    g_graph_last_replayed = graph_replays;
     if (pending_enq > 0) FF_CHECK_HIP(hipEventSynchronize(pool->chk_done));   // hpin is reused by the next call
     if (dbg_timing) {
       const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
       FF_RETURN_IF(sync_all());
       const double tot_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-      fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks (%d of %d sequences decoded; %d steps captured, %d replayed): "
-                      "%.2f ms; until GPU idle: %.2f ms\n", enq, chunks.size(), Btot, N * F, graph_captures, graph_replays, host_ms, tot_ms);
+      fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks (%d of %d sequences decoded): %.2f ms; until GPU idle: "
+                      "%.2f ms\n", enq, chunks.size(), Btot, N * F, host_ms, tot_ms);
     }
     if (forked) {  // join
       for (int s = 0; s < ns; ++s) {
@@ -974,7 +792,6 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
                                   sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
     FF_CHECK_HIP(hipStreamSynchronize(main_st));
     if (steps_done) *steps_done = steps;
-    if (chain_launches > 0 || use_flow) FF_RETURN_IF(ff_chain_check(main_st));   // a boundary / dependency that timed out voids the results
 
     // ---- optional: project(decoder(...)) of every prefix row at the last executed step
     //      (SurfaceFormer returns it as inputs['pointer'], reference model.py:217) --------------------

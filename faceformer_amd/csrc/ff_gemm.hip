@@ -33,7 +33,6 @@
 
 #include "ff_common.h"
 #include "ff_device.h"
-#include "ff_chain.h"
 
 // Timing experiment (tools/gemm_slice_probe.py, -DFF_EXP_STAMP): the four waves of workgroup 0 of the persistent kernel stamp
 // the shader clock in front of and behind the block barrier of their first 256 slices.
@@ -94,12 +93,11 @@ namespace {
 // in front of the MFMA chain.
 constexpr int LN_NQ = 2;                     // segments per lane: ln_nseg <= 8 * LN_NQ, i.e. K <= 512 for the fused consumer
 struct LnRaw { f32x2 seg[LN_NQ]; };          // (mean, M2) pairs exactly as loaded: no register shuffling behind the loads
-template <bool COH = false>
 __device__ __forceinline__ void ff_ln_issue(const float* __restrict__ st, int nseg, int c, LnRaw& r) {
 #pragma unroll
   for (int q = 0; q < LN_NQ; ++q) {
     const int sidx = c + 8 * q;
-    r.seg[q] = ff_ld8<COH>(st + 2 * (sidx < nseg ? sidx : 0));
+    r.seg[q] = ff_ld8(st + 2 * (sidx < nseg ? sidx : 0));
   }
 }
 __device__ __forceinline__ void ff_ln_finish(const LnRaw& r, int nseg, int c, float eps, float& mean, float& rstd) {
@@ -121,7 +119,6 @@ __device__ __forceinline__ void ff_ln_finish(const LnRaw& r, int nseg, int c, fl
 
 // rv[e] = rowtab[(row_e / div), col] for the 16 accumulator rows row_e = row0 + (e&3) + 8*(e>>2) of a lane: one
 // division; the 28-row span crosses a multiple of div at most once when div >= 28 (sequences per micro-batch).
-template <bool COH = false>
 __device__ __forceinline__ void ff_load_rowtab(const GemmArgs& g, int row0, int colc, float (&rv)[16]) {
   const int div = g.rowtab_div;
   const int qmax = (g.M - 1) / div;
@@ -129,7 +126,7 @@ __device__ __forceinline__ void ff_load_rowtab(const GemmArgs& g, int row0, int 
   if (div >= 28) {
     const int q0 = row0 / div, rem0 = row0 - q0 * div;
     if (rem0 + 27 < div) {   // the lane's 28-row span lies inside ONE table row (always, when div is a multiple of 64): one load
-      const float v = ff_ldw<COH>(tp + (size_t)(q0 < qmax ? q0 : qmax) * g.ld_rowtab);
+      const float v = ff_ldw(tp + (size_t)(q0 < qmax ? q0 : qmax) * g.ld_rowtab);
 #pragma unroll
       for (int e = 0; e < 16; ++e) rv[e] = v;
     } else {
@@ -137,7 +134,7 @@ __device__ __forceinline__ void ff_load_rowtab(const GemmArgs& g, int row0, int 
       for (int e = 0; e < 16; ++e) {
         int q = q0 + ((rem0 + (e & 3) + 8 * (e >> 2)) >= div ? 1 : 0);
         q = q < qmax ? q : qmax;
-        rv[e] = ff_ldw<COH>(tp + (size_t)q * g.ld_rowtab);
+        rv[e] = ff_ldw(tp + (size_t)q * g.ld_rowtab);
       }
     }
   } else {
@@ -145,7 +142,7 @@ __device__ __forceinline__ void ff_load_rowtab(const GemmArgs& g, int row0, int 
     for (int e = 0; e < 16; ++e) {
       int q = (row0 + (e & 3) + 8 * (e >> 2)) / div;
       q = q < qmax ? q : qmax;
-      rv[e] = ff_ldw<COH>(tp + (size_t)q * g.ld_rowtab);
+      rv[e] = ff_ldw(tp + (size_t)q * g.ld_rowtab);
     }
   }
 }
@@ -154,7 +151,6 @@ __device__ __forceinline__ void ff_load_rowtab(const GemmArgs& g, int row0, int 
 // rows (e&3) + 8*(e>>2) + 4*half).  The values go through a wave-private LDS patch [32][33] so that lane
 // (row = l32, half) can sum 16 consecutive columns of ITS row; the two halves meet with one shuffle.  Two passes
 // (mean, then centred squares) like the standalone LayerNorm kernel.  Writes (mean, M2) of rows < M.
-template <bool COH = false>
 __device__ __forceinline__ void ff_emit_ln_stats(const float (&v)[16], float* patch, int l32, int half, int row0, int M,
                                                  float* __restrict__ ln_out, int nseg_out, int seg) {
 #pragma unroll
@@ -173,7 +169,7 @@ __device__ __forceinline__ void ff_emit_ln_stats(const float (&v)[16], float* pa
   m2 = ff_halves_sum(m2);
   const int row = row0 + l32;
   if (half == 0 && row < M) {
-    ff_st8<COH>(ln_out + ((size_t)row * nseg_out + seg) * 2, f32x2{mean, m2});
+    ff_st8(ln_out + ((size_t)row * nseg_out + seg) * 2, f32x2{mean, m2});
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();   // the patch is reused by this wave's next tile
@@ -573,49 +569,8 @@ __global__ __launch_bounds__(256, (BK == 16 ? 2 : 1)) void gemm_pipe_kernel(Gemm
 // flight while the current tile finishes: no pipeline fill/drain per tile, only per block (+4-6 %).  Bias
 // and residual of a tile are fetched when its first slice is computed and consumed after its last one.
 // Requires K % 64 == 0 and K >= 128.
-// Dependencies of a FLOW launch (gemm_flow_kernel below): tile (m, n) of an operator may read its A rows (and residual / row
-// statistics) only when every column tile of row panel m of the PREVIOUS operator of the launch has been stored -- counted
-// per 64-row panel in `wait_ctr` -- and counts itself into `signal_ctr` when its own stores have left the CU.
-struct FlowDeps {
-  unsigned* wait_ctr;      // [panels] arrivals of the producer's column tiles (null: no dependency inside the launch)
-  unsigned wait_target;    // = the producer's tiles_n
-  unsigned* done_ctr;      // [panels] consumers that have passed the wait: the last one clears both counters (self-cleaning)
-  unsigned done_target;    // = this operator's tiles_n
-  unsigned* signal_ctr;    // [panels] of this operator (null: nobody inside the launch consumes it)
-  unsigned* err;           // sticky error word of the launch's sync area
-};
-
-constexpr unsigned FLOW_SPIN_LIMIT = 1u << 20;
-// Block-uniform: one lane polls the producer's panel counter (relaxed agent loads + s_sleep, bounded); the consumer that
-// completes the panel's consumer count clears both counters for the next launch that uses the slot.
-__device__ __forceinline__ void flow_wait(const FlowDeps& dep, int panel) {
-  if (threadIdx.x == 0) {
-    const unsigned* c = dep.wait_ctr + panel;
-    bool ok = false;
-    for (unsigned n = 0; n < FLOW_SPIN_LIMIT; ++n) {
-      if (__hip_atomic_load((const FF_GLOBAL unsigned*)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= dep.wait_target) { ok = true; break; }
-      if ((n & 255u) == 255u && __hip_atomic_load((const FF_GLOBAL unsigned*)dep.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (!ok) __hip_atomic_store((FF_GLOBAL unsigned*)dep.err, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned seen = __hip_atomic_fetch_add((FF_GLOBAL unsigned*)(dep.done_ctr + panel), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (seen + 1u == dep.done_target) {
-      __hip_atomic_store((FF_GLOBAL unsigned*)(dep.wait_ctr + panel), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store((FF_GLOBAL unsigned*)(dep.done_ctr + panel), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-}
-// Block-uniform: every wave's write-through stores of the finished tile have left the CU, then one lane counts the tile in.
-__device__ __forceinline__ void flow_signal(const FlowDeps& dep, int panel) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_fetch_add((FF_GLOBAL unsigned*)(dep.signal_ctr + panel), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int MODE, bool COH>  // MODE: 0 plain, 1 LayerNorm-normalised A rows + row-indexed additive table, 2 emits row statistics of C
-__device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_tiles, int vbid, int G, float* lds, const FlowDeps& dep) {
+template <int MODE>  // MODE: 0 plain, 1 LayerNorm-normalised A rows + row-indexed additive table, 2 emits row statistics of C
+__device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_tiles, int vbid, int G, float* lds) {
   constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = BK + 4, KF = BK / 8;
   constexpr int BUF_FLOATS = (BM + BN) * LDS_LD;
   const int tid = threadIdx.x;
@@ -658,7 +613,6 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
     const int id = first + (k < my_tiles ? k : my_tiles - 1) * stride;
     const int bz = id / tiles_mn, rem2 = id - bz * tiles_mn;
     const int m0 = (rem2 / g.tiles_n) * BM, n0 = (rem2 % g.tiles_n) * BN;
-    if (COH && dep.wait_ctr && k < my_tiles) flow_wait(dep, m0 / BM);   // block-uniform: the producer's row panel is complete
     const float* Asrc = ((g.A2 != nullptr && n0 >= g.n_split) ? g.A2 : g.A) + (long long)bz * g.batch_stride_a;
     const float* W = g.W + (long long)bz * g.batch_stride_w;
 #pragma unroll
@@ -666,7 +620,7 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
       int row = m0 + r + 32 * p;
       row = row < g.M ? row : g.M - 1;
       a_ptr[p] = Asrc + (size_t)row * g.lda + c4 * 4;
-      if (MODE == 1) ff_ln_issue<COH>(g.ln_in + (size_t)row * g.ln_nseg * 2, g.ln_nseg, c4, ln_raw[p]);
+      if (MODE == 1) ff_ln_issue(g.ln_in + (size_t)row * g.ln_nseg * 2, g.ln_nseg, c4, ln_raw[p]);
       int n = n0 + r + 32 * p;
       n = n < g.N ? n : g.N - 1;
       w_ptr[p] = W + (size_t)n * g.ldw + c4 * 4;
@@ -680,8 +634,8 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
     const int k0 = ld_j * BK;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      xa[p] = ff_ld16<COH>(a_ptr[p] + k0);
-      xw[p] = ff_ldw16<COH>(w_ptr[p] + k0);
+      xa[p] = ff_ld16(a_ptr[p] + k0);
+      xw[p] = ff_ldw16(w_ptr[p] + k0);
     }
   };
   auto advance = [&](bool defer) {  // block-uniform; past the last tile the cursor stays on the last slice
@@ -735,16 +689,16 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
     e_colok = e_col < g.N;
     e_coff = (long long)bz * g.batch_stride_c;
     const int colc = e_colok ? e_col : g.N - 1;
-    bv = g.bias ? ff_ldw<COH>(g.bias + colc) : 0.f;
+    bv = g.bias ? ff_ldw(g.bias + colc) : 0.f;
     if (g.res) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         int row = e_row0 + (e & 3) + 8 * (e >> 2);
         row = row < g.M ? row : g.M - 1;
-        rv[e] = ff_ld4<COH>(g.res + e_coff + (size_t)row * g.ldr + colc);
+        rv[e] = ff_ld4(g.res + e_coff + (size_t)row * g.ldr + colc);
       }
     } else if (MODE == 1 && g.rowtab && colc < g.rowtab_cols) {  // additive table indexed by row / div (positions)
-      ff_load_rowtab<COH>(g, e_row0, colc, rv);
+      ff_load_rowtab(g, e_row0, colc, rv);
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e) rv[e] = 0.f;
@@ -766,9 +720,9 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
       fin[e] = v;
       acc[e] = 0.f;
     }
-    ff_store_tile<COH>(cp, g.ldc, e_row0, e_col, g.M, e_colok, fin);
+    ff_store_tile(cp, g.ldc, e_row0, e_col, g.M, e_colok, fin);
     if (MODE == 2)
-      ff_emit_ln_stats<COH>(fin, lds + 3 * BUF_FLOATS + wave * (32 * 33), l32, half, e_row0 - 4 * half, g.M, g.ln_out,
+      ff_emit_ln_stats(fin, lds + 3 * BUF_FLOATS + wave * (32 * 33), l32, half, e_row0 - 4 * half, g.M, g.ln_out,
                        g.N >> 5, (e_col - l32) >> 5);
   };
 
@@ -808,7 +762,6 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
       }
     }
     end_tile();
-    if (COH && dep.signal_ctr) flow_signal(dep, (e_row0 - wm0 - 4 * half) / BM);
     if (cp_k + 1 < my_tiles) begin_tile(cp_k + 1);
   }
 }
@@ -816,65 +769,8 @@ __device__ __forceinline__ void gemm_persist_body(const GemmArgs& g, int total_t
 template <int MODE>  // 0 plain, 1 LayerNorm-normalised A rows + row-indexed additive table, 2 emits row statistics of C
 __global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs g, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const FlowDeps none{nullptr, 0u, nullptr, 0u, nullptr, nullptr};
-  gemm_persist_body<MODE, false>(g, total_tiles, (int)blockIdx.x, (int)gridDim.x, lds, none);
+  gemm_persist_body<MODE>(g, total_tiles, (int)blockIdx.x, (int)gridDim.x, lds);
 }
-
-// ---- flow launch: consecutive DEPENDENT projections inside one persistent launch ------------------------------------------
-// out-proj -> (LayerNorm) -> q-proj, or out-proj -> linear1 -> linear2 -> next layer's q|k|v: tile (m, n) of one projection needs
-// rows m of the previous one's output (all its column tiles), nothing else.  As separate launches every boundary costs a
-// dispatch, a cold prologue, a drain of the partially filled last round and -- for the launch shapes that cut tiles -- a
-// cross-block hand-over: ~10-12 us per boundary at the decode path's sizes.  Here the launch keeps the
-// persistent grid (2 workgroups per CU) and runs the operators back to back; a workgroup that has finished (or never had) its
-// tiles of operator i moves on to its tiles of operator i + 1 and waits only for the row panel it reads (FlowDeps): the tail
-// of one operator overlaps the head of the next, and a tile count that does not fill the last round costs nothing.
-// Deadlock freedom: an operator's tiles wait only on tiles of the previous operator, which wait on nothing later; every
-// workgroup of the grid is resident (grid <= 2 x CUs, LDS / registers sized for two per CU); every poll is bounded.
-struct FlowSync {
-  unsigned* ctr;     // [FF_FLOW_MAX_OPS][panel_stride] arrivals per operator and row panel (self-cleaning)
-  unsigned* done;    // [FF_FLOW_MAX_OPS][panel_stride]
-  unsigned* err;
-  int panel_stride;
-  int nodep;         // FF_FLOW_NODEP=1 (timing experiments only: WRONG results): operators run without waiting / signalling
-};
-
-#ifdef FF_EXPERIMENTAL
-template <int MODE>
-__device__ __forceinline__ void flow_op(const ff_chain_op* opp_v, unsigned* wait_ctr, unsigned wait_target,
-                                        unsigned* done_ctr, unsigned* signal_ctr, unsigned* err) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const ff_u64 pv = (ff_u64)opp_v;
-  // (readfirstlane returns a SIGNED int: without the casts a low half with bit 31 set sign-extends over the high half)
-  const unsigned p_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pv);
-  const unsigned p_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
-  const FF_GLOBAL ff_chain_op* opp = (const FF_GLOBAL ff_chain_op*)(((ff_u64)p_hi << 32) | (ff_u64)p_lo);
-  GemmArgs g;
-  {
-    unsigned* o = reinterpret_cast<unsigned*>(&g);
-    const FF_GLOBAL unsigned* q = (const FF_GLOBAL unsigned*)&opp->u.g;
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(GemmArgs) / 4); ++i) o[i] = q[i];
-  }
-  const FlowDeps dep{wait_ctr, wait_target, done_ctr, (unsigned)g.tiles_n, signal_ctr, err};
-  gemm_persist_body<MODE, true>(g, g.tiles_m * g.tiles_n, (int)blockIdx.x, (int)gridDim.x, lds, dep);
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_flow_kernel(const ff_chain_op* __restrict__ ops, int nops, FlowSync sync) {
-  unsigned prev_tiles_n = 0;
-  for (int i = 0; i < nops; ++i) {
-    const ff_chain_op* op = ops + i;
-    const int mode = op->u.g.ln_in ? 1 : (op->u.g.ln_out ? 2 : 0);
-    unsigned* wait_ctr = (i > 0 && !sync.nodep) ? sync.ctr + (size_t)(i - 1) * sync.panel_stride : nullptr;
-    unsigned* done_ctr = (i > 0 && !sync.nodep) ? sync.done + (size_t)(i - 1) * sync.panel_stride : nullptr;
-    unsigned* signal_ctr = (i + 1 < nops && !sync.nodep) ? sync.ctr + (size_t)i * sync.panel_stride : nullptr;
-    if (mode == 1) flow_op<1>(op, wait_ctr, prev_tiles_n, done_ctr, signal_ctr, sync.err);
-    else if (mode == 2) flow_op<2>(op, wait_ctr, prev_tiles_n, done_ctr, signal_ctr, sync.err);
-    else flow_op<0>(op, wait_ctr, prev_tiles_n, done_ctr, signal_ctr, sync.err);
-    prev_tiles_n = (unsigned)op->u.g.tiles_n;
-    __syncthreads();   // the LDS ring is refilled by the next operator's prologue
-  }
-}
-#endif  // FF_EXPERIMENTAL
 
 // ---- stream-K form of the persistent kernel -----------------------------------------------------------------
 // The persistent kernel hands out WHOLE tiles, so a launch whose tile count is not a multiple of the
@@ -1112,7 +1008,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       fin[e] = v;
       acc[e] = 0.f;
     }
-    ff_store_tile<false>(cp, g.ldc, e_row0, e_col, g.M, e_colok, fin);
+    ff_store_tile(cp, g.ldc, e_row0, e_col, g.M, e_colok, fin);
     if (MODE == 2)
       ff_emit_ln_stats(fin, lds + 3 * BUF_FLOATS + wave * (32 * 33), l32, half, e_row0 - 4 * half, g.M, g.ln_out,
                        g.N >> 5, (e_col - l32) >> 5);
@@ -1284,7 +1180,7 @@ int sk_acquire(hipStream_t st, StreamK* out) {
 template <int KQ, int MODE, int NW>  // MODE as gemm_persist_kernel
 __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float red[ff_gemm_small_lds_floats(MODE, NW)];
-  ff_gemm_small_tile<KQ, MODE, NW, false>(g, (int)blockIdx.x, (long long)blockIdx.y, red);
+  ff_gemm_small_tile<KQ, MODE, NW>(g, (int)blockIdx.x, (long long)blockIdx.y, red);
 }
 
 // ---- panel form of the small-M kernel: ONE coalesced memory round trip per 512-wide K chunk -------------------------------
@@ -1593,7 +1489,6 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
   if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
   if (tile == 5 && !split128) tile = 4;
   const int M = g.M, N = g.N, K = g.K;
-  if (ff_chain_recording()) return ff_chain_record_gemm(g, batch);   // operator of a chain launch (ff_chain.hip)
   FFProfScope prof(FF_CAT_GEMM, 2.0 * M * N * K * batch, st);
   ff_prof_add_bytes(FF_CAT_GEMM, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (g.res ? 2 : 1)));
   // tile 11 / automatic from g_dma_min_rows rows on: the LDS-DMA kernel (ff_gemm_x3.hip: gemm_dma_f32_kernel)
@@ -1602,7 +1497,7 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
     FF_CHECK_ARG(dma_ok, "ff_gemm_f32: tile 11 needs K %% 32 == 0, K >= 64, N %% 4 == 0, leading dimensions %% 4, 16-byte aligned operands, batch 1");
     return ff_gemm_dma_f32(g, st);
   }
-  if (tile == 7 && dma_ok && (long)M >= g_dma_min_rows && !ff_chain_recording()) return ff_gemm_dma_f32(g, st);
+  if (tile == 7 && dma_ok && (long)M >= g_dma_min_rows) return ff_gemm_dma_f32(g, st);
   switch (tile) {
     case 1: return launch_generic<64, 64, 32, 32>(g, batch, st);
     case 2: return launch_pipe<64, 64, 32, 32>(g, batch, st);
@@ -1696,22 +1591,3 @@ extern "C" int ff_gemm_f32(const float* A, int lda, const float* A2, int n_split
                              1, 0, 0, 0, stream);
 }
 
-#ifdef FF_EXPERIMENTAL
-// Flow launch of `nops` recorded 64x64-tile projections (descriptors already on the device); called by ff_chain.hip.
-int ff_gemm_flow_launch(const ff_chain_op* dev_ops, int nops, unsigned* ctr, unsigned* done, unsigned* err, int panel_stride,
-                        hipStream_t st) {
-  static AttrFlags attr_set = {};
-  constexpr int bytes = 3 * 128 * 36 * (int)sizeof(float) + LN_PATCH_BYTES;
-  FF_RETURN_IF(set_lds_limit(&gemm_flow_kernel, bytes, &attr_set));
-  static const int nodep = getenv("FF_FLOW_NODEP") ? atoi(getenv("FF_FLOW_NODEP")) : 0;
-  FlowSync sync{ctr, done, err, panel_stride, nodep};
-  // every workgroup of the launch must be resident (dependency waits): two per CU, as many as the device has CUs for
-  int dev = 0, cus = 0;
-  FF_CHECK_HIP(hipGetDevice(&dev));
-  FF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int grid = cus >= 256 ? 512 : (cus > 0 ? 2 * cus : 2);
-  hipLaunchKernelGGL(gemm_flow_kernel, dim3(grid), dim3(256), bytes, st, dev_ops, nops, sync);
-  FF_CHECK_LAUNCH();
-  return FF_OK;
-}
-#endif  // FF_EXPERIMENTAL

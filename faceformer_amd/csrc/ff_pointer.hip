@@ -11,7 +11,6 @@
 
 #include "ff_common.h"
 #include "ff_device.h"
-#include "ff_chain.h"
 
 namespace {
 
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(256) void pointer_reduce_kernel(PointerArgs a) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= a.B) return;
-  ff_pointer_reduce_row<false>(a, b, lane);
+  ff_pointer_reduce_row(a, b, lane);
 }
 
 }  // namespace
@@ -155,7 +154,6 @@ extern "C" int ff_pointer_argmax(const float* p, int ldp, const float* memory, i
                                      seqs_per_group, S, E, 0, 0, B / seqs_per_group,
                                      (long long)seqs_per_group * ldp, (long long)S * E,
                                      (long long)seqs_per_group * ldlogits, stream));
-    if (ff_chain_recording()) return ff_chain_record_pointer(a);
     FFProfScope prof(FF_CAT_POINTER, (double)B * S * 8.0, st);
     hipLaunchKernelGGL(pointer_reduce_kernel, grid, block, 0, st, a);
     FF_CHECK_LAUNCH();

@@ -7,7 +7,6 @@
 
 #include "ff_common.h"
 #include "ff_device.h"
-#include "ff_chain.h"
 
 // ---- library-level helpers ---------------------------------------------------------------------
 static thread_local char g_ff_error[512] = "";
@@ -19,7 +18,7 @@ void ff_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int ff_version(void) { return 100; }
+extern "C" int ff_version(void) { return FF_ABI_VERSION; }
 extern "C" const char* ff_last_error(void) { return g_ff_error; }
 extern "C" int ff_device_count(void) {
   int n = 0;
@@ -66,14 +65,6 @@ void ff_prof_add_bytes(int cat, double bytes) {
 }
 void ff_prof_close(hipStream_t st) {
   if (!g_prof.recs.empty() && g_prof.recs.back().b) (void)hipEventRecord(g_prof.recs.back().b, st);
-}
-
-extern "C" int ff_has_experimental(void) {
-#ifdef FF_EXPERIMENTAL
-  return 1;
-#else
-  return 0;
-#endif
 }
 
 extern "C" int ff_profile_begin(void) {
@@ -141,7 +132,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= a.rows) return;
-  ff_layernorm_row<NV, false>(a, row, lane);
+  ff_layernorm_row<NV>(a, row, lane);
 }
 
 extern "C" int ff_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
@@ -161,7 +152,6 @@ extern "C" int ff_layernorm(const float* x, int ldx, const float* gamma, const f
   }
   hipStream_t st = (hipStream_t)stream;
   const LnArgs la{x, ldx, gamma, beta, eps, y, ldy, ypos, ldypos, pos, ldpos, pos_div, pos_mod, rows, E};
-  if (ff_chain_recording()) return ff_chain_record_layernorm(la);
   FFProfScope prof(FF_CAT_LN, (double)rows * E * 4.0 * (1 + (y != nullptr) + (ypos != nullptr)), st);
   dim3 block(256), grid(ff_cdiv(rows, 4));
   const int nv = ff_cdiv(E / 4, 64);

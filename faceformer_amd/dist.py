@@ -167,7 +167,7 @@ def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callbac
                      chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                      chunk_max_seqs=getattr(model, "chunk_max_seqs", 0),
                      num_streams=model.num_streams, sync_every=sync_every if stop_callback else 0, flags=model.decode_flags,
-                     x3_min_rows=model.x3_min_rows, ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0), chain_max_rows=getattr(model, "chain_max_rows", 0), flow_min_rows=getattr(model, "flow_min_rows", 0), extra_mask=extra_rows,
+                     x3_min_rows=model.x3_min_rows, ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0), extra_mask=extra_rows,
                      tok_sos=model.token.SOS if not parallel else 1,
                      tok_eos=model.token.EOS if not parallel else 3, no_stop=stop_callback is None,
                      stop_callback=stop_callback)

@@ -2,9 +2,6 @@
 plain C-ABI shared object (see include/faceformer_hip.h) linked only against the HIP runtime.
 
     python -m faceformer_amd.hip.build [--force] [--verbose]
-    python -m faceformer_amd.hip.build --experimental    -> libfaceformer_hip_exp.so: the same library with -DFF_EXPERIMENTAL, i.e.
-        with the persistent-launch experiments of round 3 (chain launches, flow launches, step graphs) compiled in; load it
-        with FF_HIP_LIB=<path> (tests/test_parity_golden.py runs their parity tests when the loaded library has them)
 """
 import hashlib
 import os
@@ -20,7 +17,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libfaceformer_hip.so")
 BUILD_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
-SOURCES = ["ff_rowops.hip", "ff_gemm.hip", "ff_gemm_x3.hip", "ff_attention.hip", "ff_pointer.hip", "ff_chain.hip", "ff_engine.hip"]
+SOURCES = ["ff_rowops.hip", "ff_gemm.hip", "ff_gemm_x3.hip", "ff_attention.hip", "ff_pointer.hip", "ff_engine.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function"]
 
@@ -41,18 +38,14 @@ def _digest(paths, flags=None):
     return h.hexdigest()
 
 
-def build(force=False, verbose=False, experimental=False):
+def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the shared library; returns its path."""
-    global FLAGS
-    build_dir, lib_path, flags = BUILD_DIR, LIB_PATH, FLAGS
-    if experimental:
-        build_dir, lib_path, flags = BUILD_DIR + "_exp", LIB_PATH.replace(".so", "_exp.so"), FLAGS + ["-DFF_EXPERIMENTAL"]
-    return _build(build_dir, lib_path, flags, force, verbose)
+    return _build(BUILD_DIR, LIB_PATH, FLAGS, force, verbose)
 
 
 def _build(BUILD_DIR, LIB_PATH, FLAGS, force, verbose):
     os.makedirs(BUILD_DIR, exist_ok=True)
-    headers = [os.path.join(INCLUDE, "faceformer_hip.h"), os.path.join(CSRC, "ff_common.h"), os.path.join(CSRC, "ff_device.h"), os.path.join(CSRC, "ff_chain.h")]
+    headers = [os.path.join(INCLUDE, "faceformer_hip.h"), os.path.join(CSRC, "ff_common.h"), os.path.join(CSRC, "ff_device.h")]
     hipcc = _hipcc()
     objs = []
     relink = force or not os.path.exists(LIB_PATH)
@@ -80,6 +73,5 @@ def _build(BUILD_DIR, LIB_PATH, FLAGS, force, verbose):
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv,
-                 experimental="--experimental" in sys.argv)
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
     print(path)

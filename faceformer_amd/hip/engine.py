@@ -201,30 +201,13 @@ class PathEngine:
                                          _p(memory), _p(ws), ws.numel(), _stream()), "ff_encode")
         return memory, kv_len
 
-    def _pinned(self, name, t, keep=8):
-        """Copy `t` into the buffer this engine keeps for (name, shape, dtype) -- same address every call."""
-        if t is None:
-            return None
-        if not hasattr(self, "_pinned_bufs"):
-            self._pinned_bufs = {}
-        key = (name, tuple(t.shape), t.dtype)
-        buf = self._pinned_bufs.pop(key, None)
-        if buf is None:
-            buf = torch.empty_like(t, memory_format=torch.contiguous_format)
-            mine = [k for k in self._pinned_bufs if k[0] == name]        # least recently used first
-            for old in mine[: max(0, len(mine) - (keep - 1))]:           # at most `keep` shapes per operand
-                del self._pinned_bufs[old]
-        self._pinned_bufs[key] = buf   # (re-inserted: the dict is in least-recently-used order)
-        buf.copy_(t)
-        return buf
-
     def _same_device(self, t, name):
         if t is not None and t.device != self.device:
             raise _L.HipExtensionError("%s is on %s but the engine's weights are on %s" % (name, t.device, self.device))
 
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
                chunk_wireframes=0, chunk_seqs=0, num_streams=1, sync_every=4, flags=DEFAULT_FLAGS,
-               tok_sos=1, tok_eos=3, x3_min_rows=0, chunk_max_seqs=0, ln_fuse_max_rows=0, chain_max_rows=0, flow_min_rows=0,
+               tok_sos=1, tok_eos=3, x3_min_rows=0, chunk_max_seqs=0, ln_fuse_max_rows=0,
                trace=False, return_pointer=False, no_stop=False, stop_callback=None):
         """Greedy decode. Returns dict(predict [N*F, T] int64, steps, decoded_seqs, [pointer], [trace
         tensors indexed like predict's rows])."""
@@ -238,8 +221,6 @@ class PathEngine:
         prm.chunk_seqs, prm.num_streams = chunk_seqs, num_streams
         prm.chunk_max_seqs = int(chunk_max_seqs)
         prm.ln_fuse_max_rows = int(ln_fuse_max_rows)
-        prm.chain_max_rows = int(chain_max_rows)
-        prm.flow_min_rows = int(flow_min_rows)
         prm.flags = flags | (_L.FF_RETURN_POINTER if return_pointer else 0) | (_L.FF_NO_STOP if no_stop else 0)
         if return_pointer or extra_mask is not None:   # (every padding-anchor row has its own extra-mask row)
             prm.flags &= ~_L.FF_DEDUP_PAD_ANCHORS
@@ -259,20 +240,12 @@ class PathEngine:
             _dev(extra_mask, "extra_mask", torch.uint8)
             self._same_device(extra_mask, "extra_mask")
             extra_mask = extra_mask.contiguous()
-        graphs = bool(prm.flags & _L.FF_GRAPH) and num_streams <= 1
-        if graphs:
-            # step graphs replay launches whose arguments are ADDRESSES: the per-call operands move into buffers this engine
-            # keeps (one per operand and shape), so that a second decode of the same shape presents the same arguments
-            memory, mask_u8, kv_len = self._pinned("memory", memory), self._pinned("mask", mask_u8), self._pinned("kv_len", kv_len)
-            ni, extra_mask = self._pinned("num_input", ni), self._pinned("extra_mask", extra_mask)
         pointer = torch.zeros((max(T - 1, 1), B, E), device=dev, dtype=torch.float32) if return_pointer else None
         tl = tb = ts = rows = None
         if trace:
             tl = torch.full((max(T - 1, 1), B, S), float("nan"), device=dev, dtype=torch.float32)
             tb = torch.full((max(T - 1, 1), B), float("nan"), device=dev, dtype=torch.float32)
             ts = torch.full((max(T - 1, 1), B), float("nan"), device=dev, dtype=torch.float32)
-            if graphs:   # (the traces are written by the captured launches: kept addresses as well; copied out below)
-                tl, tb, ts = self._pinned("trace_logits", tl), self._pinned("trace_best", tb), self._pinned("trace_second", ts)
         rows = torch.empty(B, device=dev, dtype=torch.int32)
         nbytes = self._lib.ff_decode_workspace_bytes(C.byref(self.model), C.byref(prm), ni_host)
         ws = self._workspace(nbytes)
@@ -299,12 +272,6 @@ class PathEngine:
             raise cb_error[0]
         out = {"predict": predict, "steps": steps.value, "step_counts": list(counts)[: steps.value],
                "seq_of_row": rows}
-        if graphs:
-            cap, rep = C.c_int(0), C.c_int(0)
-            self._lib.ff_graph_stats(C.byref(cap), C.byref(rep))
-            out["graph_steps"] = (cap.value, rep.value)   # decode steps captured by / replayed in this call
-            if trace:
-                tl, tb, ts = tl.clone(), tb.clone(), ts.clone()
         if return_pointer:
             out["pointer"] = pointer[: steps.value]
         if trace:

@@ -14,9 +14,8 @@ FF_HEAD_DIM = 64
 FF_PARALLEL, FF_SEQ2SEQ = 0, 1
 FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP, FF_DEDUP_PAD_ANCHORS = 1, 2, 4, 8, 16
 FF_FUSE_LAYERNORM = 32
-FF_CHAIN = 64
-FF_FLOW = 128
-FF_GRAPH = 256
+FF_STOP_EACH_EOS = 512
+FF_ABI_VERSION = 101   # include/faceformer_hip.h: the struct layouts below are this version's
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -98,7 +97,6 @@ class DecodeParams(C.Structure):
         ("sync_every", C.c_int), ("flags", C.c_int),
         ("tok_sos", C.c_int), ("tok_eos", C.c_int),
         ("x3_min_rows", C.c_int), ("chunk_max_seqs", C.c_int), ("ln_fuse_max_rows", C.c_int),
-        ("chain_max_rows", C.c_int), ("flow_min_rows", C.c_int),
         ("stop_fn", C.c_void_p), ("stop_user", C.c_void_p),
     ]
 
@@ -112,12 +110,10 @@ SIGNATURES = {
     "ff_version": (C.c_int, []),
     "ff_last_error": (C.c_char_p, []),
     "ff_device_count": (C.c_int, []),
-    "ff_has_experimental": (C.c_int, []),
     "ff_profile_begin": (C.c_int, []),
     "ff_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "ff_profile_bytes": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "ff_profile_bracket_us": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_void_p]),
-    "ff_graph_stats": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
                                fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,
@@ -187,6 +183,9 @@ def load():
             raise HipExtensionError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    if lib.ff_version() != FF_ABI_VERSION:   # a stale .so would read the ctypes structs above with another layout
+        raise HipExtensionError("%s reports ABI version %d, this package binds version %d: rebuild it "
+                                "(python -m faceformer_amd.hip.build --force)" % (LIB_PATH, lib.ff_version(), FF_ABI_VERSION))
     _lib = lib
     return lib
 

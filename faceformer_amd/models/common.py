@@ -54,8 +54,6 @@ class SurfaceFormerBase(nn.Module):
         self.chunk_max_seqs = 8192     # ... and at most this many sequences per micro-batch of several wireframes
         self.sort_by_edges = True      # ragged batches: decode the wireframes sorted by edge count (tight micro-batches)
         self.ln_fuse_max_rows = 0      # LayerNorm folded into the projections on steps with at most this many rows (0: 12288)
-        self.flow_min_rows = 0         # FF_FLOW: steps with at least this many rows take the flow launches (0: 1025)
-        self.chain_max_rows = 0        # FF_CHAIN: steps with at most this many active rows run as ONE persistent launch (0: 1024)
         self.sync_every = 1            # the host looks at the stop rule every k steps, one period behind the enqueued steps
                                        # (the queue never drains: free at every step, tools/run_sync_probe.sh); a decode
                                        # that stops at step s executes s + k ... s + 2k - 1 steps

@@ -41,7 +41,7 @@ class SurfaceFormer(SurfaceFormerBase):
         out = eng.decode(memory, mask, kv_len, _L.FF_SEQ2SEQ, T=T, F=1,
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
                          chunk_max_seqs=self.chunk_max_seqs, num_streams=self.num_streams, sync_every=1,
-                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, ln_fuse_max_rows=self.ln_fuse_max_rows, chain_max_rows=self.chain_max_rows, flow_min_rows=self.flow_min_rows, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
+                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, ln_fuse_max_rows=self.ln_fuse_max_rows, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
                          return_pointer=True, extra_mask=self._extra_mask(inputs))
         inputs["embedding"] = memory
         inputs["pointer"] = out["pointer"].transpose(0, 1)

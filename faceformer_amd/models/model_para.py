@@ -62,7 +62,7 @@ class SurfaceFormer_Parallel(SurfaceFormerBase):
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
                          chunk_max_seqs=self.chunk_max_seqs,
                          num_streams=self.num_streams, sync_every=self.sync_every,
-                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, ln_fuse_max_rows=self.ln_fuse_max_rows, chain_max_rows=self.chain_max_rows, flow_min_rows=self.flow_min_rows, extra_mask=extra)
+                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, ln_fuse_max_rows=self.ln_fuse_max_rows, extra_mask=extra)
         pred = out["predict"].view(N, F, T)
         if order is not None:
             inv = torch.empty(N, dtype=torch.long, device=pred.device)

@@ -38,21 +38,19 @@ enum ff_status {
 #define FF_HEAD_DIM 64   /* attention head width supported by the kernels (reference: 512 / 8) */
 #define FF_MAX_LAYERS 16
 
-/* Library version (major*10000 + minor*100 + patch). */
+/* Library version (major*10000 + minor*100 + patch).  101: the struct layouts of this header (round 5: ff_decode_params lost
+ * chain_max_rows / flow_min_rows, FF_STOP_EACH_EOS added; round 4: ff_layer_weights grew by the ln*_planes / ln*_csum
+ * pointers).  A caller built against another header must refuse to run: hip/lib.py asserts equality with FF_ABI_VERSION. */
+#define FF_ABI_VERSION 101
 int ff_version(void);
 /* Thread-local text of the last error returned by this library ("" if none). */
 const char* ff_last_error(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int ff_device_count(void);
-/* 1 when the library was built with -DFF_EXPERIMENTAL (python -m faceformer_amd.hip.build --experimental): the persistent-launch
- * experiments of round 3 -- chain launches, flow launches, step graphs (ff_decode flags FF_CHAIN / FF_FLOW / FF_GRAPH) -- are
- * compiled in; 0 for the default library, whose ff_decode refuses those flags. */
-int ff_has_experimental(void);
-
 /* Measurement hooks (bench.py roofline leg; not on the product path).  Between begin and end every
  * op launch of this library is bracketed by a hipEvent pair on its stream; end() synchronises the
- * device and returns, per category (0 f32 gemm, 1 attention, 2 layernorm, 3 pointer, 4 other row ops, 5 chain launches,
- * 6 the 3 x bf16 split gemm), the summed kernel time [ms], algorithmic work (flops for 0/1/3/6, bytes for 2/4) and launches. */
+ * device and returns, per category (0 f32 gemm, 1 attention, 2 layernorm, 3 pointer, 4 other row ops, 5 unused (the chain
+ * launches of round 3, removed), 6 the 3 x bf16 split gemm), the summed kernel time [ms], algorithmic work (flops for 0/1/3/6, bytes for 2/4) and launches. */
 int ff_profile_begin(void);
 int ff_profile_end(double* ms_by_cat, double* work_by_cat, long long* launches_by_cat, int ncat);
 /* Algorithmic bytes (operands read once + results written once) summed per category since the last
@@ -361,30 +359,18 @@ enum ff_decode_flags {
                                 produces a LayerNorm input leaves per-row segment statistics, the GEMM that consumes
                                 it normalises its A rows while staging them (ff_gemm_f32_ln).  Needs the folded
                                 weights (ln1_w ... proj_fold_b) and E, FF multiples of 64, 128 <= E <= 512; otherwise ignored */
-  /* The three flags below exist in the EXPERIMENTAL build only (ff_has_experimental): built, parity-tested on every golden and
-     measured slower than launch-per-operator; the default library's ff_decode returns FF_ERR_ARG for them. */
-  FF_CHAIN = 64,             /* chain launches (ff_chain.hip): a decode step with at most chain_max_rows active rows, and the
-                                last layer's newest-position tail + pointer head of every larger step, run as ONE persistent
-                                launch whose operators are separated by grid-wide phase boundaries instead of kernel boundaries
-                                (same device code, agent-coherent accesses).  Single-stream decodes only (num_streams <= 1);
-                                needs E, FF in {128, 256, 512, 1024}; otherwise ignored */
-  FF_FLOW = 128,             /* flow launches (ff_gemm.hip, gemm_flow_kernel): on decode steps with at least flow_min_rows active rows
-                                the dependent projections between two attention operators (out-proj -> q-proj; out-proj -> linear1
-                                -> linear2 -> the next layer's q|k|v) run inside ONE persistent launch each, tile by tile behind
-                                row-panel dependency counters; implies the LayerNorm-folded forms at every size (needs what
-                                FF_FUSE_LAYERNORM needs) */
-  FF_GRAPH = 256,            /* step graphs: the launches of a decode step are a pure function of ff_decode's arguments (tokens travel
-                                through device memory), so on the SECOND call with byte-identical arguments (model, parameters, every
-                                pointer, the micro-batch plan) each step is captured into a hipGraph -- one graph per step: the host's
-                                stop rule keeps working between them -- and every later call replays the steps (a small dependent
-                                launch costs 4.6-5.3 us on a stream, 1.5-2.3 us as a graph node).  Up to 8 argument sets are kept per
-                                device.  Single-stream decodes only (num_streams <= 1); the decode then runs on an internal stream
-                                forked from / joined into `stream`.  Results are those of the plain launches bit for bit */
-  FF_DEDUP_PAD_ANCHORS = 16  /* parallel variant: the F - num_input[w] padding-anchor sequences of a wireframe
+  FF_DEDUP_PAD_ANCHORS = 16, /* parallel variant: the F - num_input[w] padding-anchor sequences of a wireframe
                                 (start token num_token-1, reference model_para.py:204-205) are identical by
                                 construction; decode ONE of them and copy its tokens into all those rows of
                                 `predict`.  Needs num_input_host; ignored when an extra mask is given */
+  FF_STOP_EACH_EOS = 512     /* seq2seq variant: the per-step counter counts a sequence's FIRST EOS only, so the cumulative
+                                rule "count == N" fires at the first step by which EVERY wireframe has produced an EOS -- the
+                                rule a caller needs when the records of a batch must equal those of one-wireframe decodes
+                                (the reference's rule, model.py:207-210, counts repeated EOS of one sample as well and can stop
+                                a batch before another sample has produced its own).  Not a reference behaviour: off by default */
 };
+/* (64 / 128 / 256 were FF_CHAIN / FF_FLOW / FF_GRAPH, the persistent-launch experiments of round 3: built, parity-tested on
+   every golden, measured slower than launch-per-operator three ways -- DESIGN.md 8 -- and removed in round 5.) */
 
 /* External stop rule (multi-GPU: SURVEY.md 8e).  Called on the HOST, from inside ff_decode, every sync_every steps with this
  * call's per-step counters of steps [0, num_steps) -- #{tokens >= num_token} (parallel) or #{tokens == EOS} (seq2seq) over the
@@ -411,13 +397,11 @@ typedef struct ff_decode_params {
                            run on the bf16 matrix cores (3 x bf16 split, fp32 accuracy) when the micro-batch
                            has at least this many prefix rows (t * sequences); 0: never */
   int chunk_max_seqs;   /* > 0: a micro-batch of several wireframes holds at most this many sequences
-                           (a single wireframe is never cut by it); 0: no limit */
+                           (a single wireframe is never cut by it); 0: no limit.  seq2seq (one sequence per wireframe):
+                           > 0 REPLACES chunk_wireframes as the micro-batch size */
   int ln_fuse_max_rows; /* FF_FUSE_LAYERNORM applies to decode steps with at most this many active rows
                            (t * sequences of the micro-batch); 0: the default (12288; x3_min_rows - 1 when the 3 x bf16
                            projections are in use: the steps that take them launch their LayerNorms) */
-  int chain_max_rows;   /* FF_CHAIN: a step of a micro-batch with at most this many active rows is one chain launch, and the
-                           tail of a larger step when the micro-batch has at most this many sequences; 0: the default (1024) */
-  int flow_min_rows;    /* FF_FLOW: steps (and layer tails) with at least this many rows take the flow launches; 0: 1025 */
   ff_stop_fn stop_fn;   /* optional: replaces the LOCAL stop rule (needs sync_every > 0; ignored with FF_NO_STOP).
                            `predict` then keeps every step that was executed (as with FF_NO_STOP): the caller zero-pads
                            after the step its global rule names */
@@ -451,10 +435,6 @@ int ff_decode(const ff_model* m, const ff_decode_params* p,
               int64_t* predict, int* steps_done, int* step_counts, float* pointer_out,
               float* trace_logits, float* trace_best, float* trace_second, int* seq_of_row,
               void* workspace, size_t workspace_bytes, ff_stream_t stream);
-
-/* FF_GRAPH bookkeeping of this process's latest ff_decode: decode steps captured into graphs by that call, and decode steps
- * it ran by replaying a graph (0 / 0: plain launches -- first sight of the arguments, or graphs not applicable). */
-void ff_graph_stats(int* captured_steps, int* replayed_steps);
 
 #ifdef __cplusplus
 }

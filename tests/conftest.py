@@ -42,16 +42,6 @@ def hip_lib():
     return lib.load()
 
 
-@pytest.fixture
-def experimental_lib(hip_lib):
-    """The persistent-launch experiments (FF_CHAIN / FF_FLOW / FF_GRAPH) exist only in libfaceformer_hip_exp.so
-    (python -m faceformer_amd.hip.build --experimental; run these tests with FF_HIP_LIB pointing at it)."""
-    if not hip_lib.ff_has_experimental():
-        pytest.skip("the loaded library is the default build: chain / flow launches and step graphs are compiled out "
-                    "(FF_HIP_LIB=faceformer_amd/hip/libfaceformer_hip_exp.so runs them)")
-    return hip_lib
-
-
 def token_ns():
     return types.SimpleNamespace(PAD=0, SOS=1, SEP=2, EOS=3, DIR0=4, DIR1=5, len=4, face_type_offset=1)
 

@@ -44,14 +44,12 @@ def run_traced(model, case, batch):
                          x3_min_rows=model.x3_min_rows,
                          chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                          chunk_max_seqs=model.chunk_max_seqs, num_streams=model.num_streams,
-                         ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0),
-                         chain_max_rows=getattr(model, "chain_max_rows", 0), flow_min_rows=getattr(model, "flow_min_rows", 0))
+                         ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0))
     else:
         out = eng.decode(memory, mask, kv_len, L.FF_SEQ2SEQ, T=T, F=1, trace=True, sync_every=1,
                          extra_mask=extra, flags=model.decode_flags, return_pointer=True,
                          x3_min_rows=model.x3_min_rows,
-                         chunk_wireframes=model.chunk_wireframes, chunk_max_seqs=getattr(model, "chunk_max_seqs", 0),
-                         chain_max_rows=getattr(model, "chain_max_rows", 0), flow_min_rows=getattr(model, "flow_min_rows", 0))
+                         chunk_wireframes=model.chunk_wireframes, chunk_max_seqs=getattr(model, "chunk_max_seqs", 0))
     out["memory"] = memory
     return out
 
@@ -176,80 +174,6 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
     _record_margin(name, "bf16x3 from %d rows, standalone LN" % min_rows, stats)
 
 
-@pytest.mark.parametrize("chain_rows", [0, 64, 1 << 20])
-@pytest.mark.parametrize("name", golden_names())
-def test_golden_parity_with_chain_launches(experimental_lib, name, chain_rows):
-    """FF_CHAIN: decode steps with at most `chain_rows` active rows (0 = the default 1024; 1 << 20 = every step of every
-    golden) run as ONE persistent launch whose operators -- the same device code with agent-coherent accesses -- are
-    separated by grid-wide phase boundaries; larger steps hand their last-layer tail + pointer head to a chain launch.
-    Same bars as the launch-per-operator path."""
-    from faceformer_amd.hip import lib as L
-    case, z = load_golden(name)
-    if chain_rows == (1 << 20) and case.get("slow") and case["kind"] == "parallel" and max(case["n_edges"]) > 300:
-        pytest.skip("whole-step chains of 10^4-row steps: covered by the tail form")
-    sd, batch = case_weights_and_batch(case)
-    model = build_model(case, sd, "cuda")
-    model.decode_flags = model.decode_flags | L.FF_CHAIN
-    model.chain_max_rows = chain_rows
-    out = run_traced(model, case, batch_to(batch, "cuda"))
-    stats = compare_with_golden(case, z, out)
-    print(name, chain_rows, stats)
-    _record_margin(name, "chain launches <= %d rows" % (chain_rows or 1024), stats)
-
-
-@pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak", "par_full_n40_gain4",
-                                  "seq_small_gain4", "seq_small_eos", "par_small_extramask", "par_full_B256_default"])
-def test_golden_parity_with_step_graphs(experimental_lib, name):
-    """FF_GRAPH: the first decode of an argument set launches plainly, the second captures its steps into hipGraphs (and
-    runs them), later ones replay.  Every pass must meet the golden's bars, and the three passes must agree bit for bit
-    (the same kernels with the same arguments) -- including the stop step of the early-stopping goldens, which the host
-    rule decides between graphs."""
-    from faceformer_amd.hip import lib as L
-    case, z = load_golden(name)
-    sd, batch = case_weights_and_batch(case)
-    model = build_model(case, sd, "cuda")
-    model.decode_flags = model.decode_flags | L.FF_GRAPH
-    b = batch_to(batch, "cuda")
-    outs = [run_traced(model, case, b) for _ in range(3)]
-    steps = int(z["steps"])
-    want = [(0, 0), None, None]
-    for i, out in enumerate(outs):
-        stats = compare_with_golden(case, z, out)
-        cap, rep = out["graph_steps"]
-        print(name, "pass", i, "captured", cap, "replayed", rep, stats)
-        if i == 0:
-            assert (cap, rep) == (0, 0)
-        elif i == 1:
-            assert cap >= steps and rep == cap
-        else:
-            assert cap == 0 and rep >= steps
-    _record_margin(name, "step graphs (replay)", stats)
-    for out in outs[1:]:
-        assert torch.equal(out["predict"], outs[0]["predict"]) and out["steps"] == outs[0]["steps"]
-        for k in ("logits", "best", "second"):
-            a, r = out[k][: steps], outs[0][k][: steps]
-            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(r, nan=-7.0)), k
-
-
-@pytest.mark.parametrize("flow_rows", [0, 1])
-@pytest.mark.parametrize("name", golden_names())
-def test_golden_parity_with_flow_launches(experimental_lib, name, flow_rows):
-    """FF_FLOW: the dependent projections between two attention operators run inside one persistent launch each, tile by tile
-    behind row-panel dependency counters (steps with at least `flow_rows` active rows; 0 = the default 1025, 1 = every step of
-    every golden incl. the two-row ones).  Same bars as the launch-per-operator path."""
-    from faceformer_amd.hip import lib as L
-    case, z = load_golden(name)
-    sd, batch = case_weights_and_batch(case)
-    model = build_model(case, sd, "cuda")
-    model.decode_flags = model.decode_flags | L.FF_FLOW
-    model.flow_min_rows = flow_rows
-    model.x3_min_rows = 0
-    out = run_traced(model, case, batch_to(batch, "cuda"))
-    stats = compare_with_golden(case, z, out)
-    print(name, flow_rows, stats)
-    _record_margin(name, "flow launches >= %d rows" % (flow_rows or 1025), stats)
-
-
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak",
                                   "par_full_n40_gain4", "seq_small_gain4", "seq_small_eos",
                                   "par_small_extramask", "par_small_ragged300"])
@@ -263,38 +187,17 @@ def test_golden_parity_with_flow_launches(experimental_lib, name, flow_rows):
                                                         # 32 = FF_FUSE_LAYERNORM (the default): LayerNorm folded into
                                                         # the projections; the rows above run the unfused kernels
                                                         (32, 0, 1, 0, 1), (35, 1, 0, 0, 2), (51, 0, 2, 5, 3),
-                                                        (33, 2, 1, 0, 1), (34, 0, 0, 0, 1),
-                                                        # 64 = FF_CHAIN: chain launches (ignored with > 1 stream)
-                                                        (64 + 51, 0, 1, 0, 1), (64 + 19, 1, 0, 0, 1), (64 + 3, 0, 2, 5, 1),
-                                                        (64 + 35, 2, 1, 0, 2), (64 + 0, 0, 1, 0, 1), (64 + 32, 3, 4, 0, 1)])
+                                                        (33, 2, 1, 0, 1), (34, 0, 0, 0, 1)])
 def test_engine_options_do_not_change_results(hip_lib, name, flags, chunk, sync, cseq, nstr):
     """Pruning flags, micro-batching (by wireframe or by sequence group), concurrent streams and the
     host sync period are pure scheduling choices."""
     case, z = load_golden(name)
     sd, batch = case_weights_and_batch(case)
-    if (flags & 64) and not hip_lib.ff_has_experimental():
-        pytest.skip("FF_CHAIN: the experimental build only")
     model = build_model(case, sd, "cuda")
     model.decode_flags, model.chunk_wireframes, model.sync_every = flags, chunk, sync
     model.chunk_seqs, model.num_streams = cseq, nstr
     out = run_traced(model, case, batch_to(batch, "cuda"))
     compare_with_golden(case, z, out)
-
-
-def test_default_library_refuses_the_experimental_launch_forms(hip_lib):
-    """FF_CHAIN / FF_FLOW / FF_GRAPH are compiled into libfaceformer_hip_exp.so only: the default library says so."""
-    if hip_lib.ff_has_experimental():
-        pytest.skip("experimental build loaded")
-    from faceformer_amd.hip import lib as L
-    case, z = load_golden("par_small_gain4")
-    sd, batch = case_weights_and_batch(case)
-    model = build_model(case, sd, "cuda")
-    for flag in (L.FF_CHAIN, L.FF_FLOW, L.FF_GRAPH):
-        model.decode_flags = model.decode_flags | flag
-        with pytest.raises(L.HipExtensionError, match="experimental build"):
-            with torch.no_grad():
-                model(batch_to(batch, "cuda"))
-        model.decode_flags = model.decode_flags & ~flag
 
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_full_n40_default", "seq_small_default"])

@@ -14,7 +14,7 @@ from faceformer_amd.models import SurfaceFormer  # noqa: E402
 from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec  # noqa: E402
 
 CASES = (("seq2seq.yml", 64), ("seq2seq+coedge.yml", 216))
-BATCHES = (1, 8, 64)
+BATCHES = tuple(int(v) for v in os.environ.get("FF_SEQ_BATCHES", "1,8,64").split(","))
 if os.environ.get("FF_SEQ_ONLY_A"):   # kernel-trace runs: config A, one wireframe per call
     CASES, BATCHES = CASES[:1], (1,)
 for cfgfile, n in CASES:
@@ -23,9 +23,8 @@ for cfgfile, n in CASES:
     model = SurfaceFormer(**cfg.model)
     model.load_state_dict(make_state_dict(state_dict_spec("seq2seq", L, T), "gain4", 0))
     model = model.eval().cuda()
-    if os.environ.get("FF_TOOL_GRAPHS"):   # step graphs (FF_GRAPH, opt-in)
-        from faceformer_amd.hip import lib as _L
-        model.decode_flags |= _L.FF_GRAPH
+    if os.environ.get("FF_SEQ_CHUNK"):   # sequences per micro-batch (default: the model's 256)
+        model.chunk_max_seqs = int(os.environ["FF_SEQ_CHUNK"])
     for nb in BATCHES:
         b = make_wireframes(n, L, T, "seq2seq", seeds=list(range(3, 3 + nb)))
         b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
