@@ -233,7 +233,7 @@ def compact_line(result):
     out = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                          "vs_baseline", "dtype", "data"))
     cfg = dict(result.get("config") or {})
-    cfg["workload"] = _cut(cfg.get("workload"), 400)
+    cfg["workload"] = _cut(cfg.get("workload"), 640)
     out["config"] = cfg
     if "path_roofline" in result:
         out["path_roofline"] = result["path_roofline"]
@@ -278,6 +278,8 @@ def compact_line(result):
     for k in ("weak_one_wireframe_per_gpu", "face_json_gather"):
         if k in result:
             out[k] = _pick(result[k], ("value", "ms_per_step", "steps"))
+    if "scaling_series" in result:
+        out["scaling_series"] = {k: _cut(v, 120) for k, v in result["scaling_series"].items() if k != "note"}
     out["detail"] = "bench_detail.json beside bench.py (also gpurun_out/bench_detail.json and the stderr line tagged bench_detail)"
     out = _sig(out)
     line = json.dumps(out, separators=(",", ":"))

@@ -754,10 +754,11 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
       if (dev >= 0 && dev < 16) attr_done[dev].store(true, std::memory_order_release);
     }
     const int P = (int)gh;
-    int c = P <= 256 ? 256 / P : 1;
+    const int cus = ff_num_cus();
+    int c = P <= cus ? cus / P : 1;
     if (c > qt32) c = qt32;
     if (c < 1) c = 1;
-    const int nblocks = P <= 256 ? P * c : 256;
+    const int nblocks = P <= cus ? P * c : cus;
     static const int w_old = getenv("FF_RK_SPLIT_OLD") ? atoi(getenv("FF_RK_SPLIT_OLD")) : 1;      // (probe knobs: tools/run_r04_attn.sh)
     static const int w_young = getenv("FF_RK_SPLIT_YOUNG") ? atoi(getenv("FF_RK_SPLIT_YOUNG")) : 1;
     static const int phase_knob = getenv("FF_RK_PHASE") ? atoi(getenv("FF_RK_PHASE")) : 0;

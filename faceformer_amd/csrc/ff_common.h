@@ -69,6 +69,22 @@ struct FFProfScope {
 unsigned long long ff_tuning_epoch();
 void ff_tuning_changed();
 
+// compute units of the current device (cached per device; 256 on an MI355X in SPX mode)
+int ff_num_cus();
+
+// ff_pointer_argmax with the decode engine's stop-rule hand-over (ff_pointer.hip)
+struct ff_pointer_sync {
+  int* seen;        // [B] or null: count_eq counts a sequence's first eq_value only (FF_STOP_EACH_EOS)
+  int* arrive;      // device int, zero before the launch: arrivals of the launch's sequences
+  int* host_slot;   // device-visible address of a host-mapped pinned int: receives the launch's counter
+  int host_which;   // 0: count_ge, 1: count_eq
+};
+int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, int E, const unsigned char* mask,
+                           const int* kv_len, const unsigned char* extra_mask, int ldextra, int B, int seqs_per_group,
+                           int* next_tok, float* best, float* second, float* logits, int ldlogits, float* next_rows,
+                           int ldnext, int* count_ge, int ge_bound, int* count_eq, int eq_value,
+                           const ff_pointer_sync* sync, ff_stream_t stream);
+
 // partial-tile workspace of the 3 x bf16 kernel for (current device, stream): allocate now (ff_gemm_x3.hip)
 extern "C" int ff_x3_prepare_stream(hipStream_t st);
 // ... and the same area as scratch memory for another kernel of that stream (at most 24 MB)

@@ -674,7 +674,32 @@ struct PointerArgs {
   int* next_tok; float* best; float* second; float* logits; int ldlogits;
   float* next_rows; int ldnext;
   int* count_ge; int ge_bound; int* count_eq; int eq_value;
+  // Decode engine only (null otherwise): stop-rule counter of THIS launch published to the host without a copy launch.
+  int* seen;        // [B] seq2seq, FF_STOP_EACH_EOS: count_eq counts a sequence's FIRST eq_value only
+  int* arrive;      // arrivals of this launch's B sequences (zeroed before the decode)
+  int* host_slot;   // host-mapped pinned int: the last sequence to arrive stores the launch's counter there (system scope)
+  int host_which;   // 0: count_ge, 1: count_eq
 };
+
+// Stop-rule counters of one finished sequence (lane 0 of its wavefront), and -- when the engine asks for it -- the launch's
+// total into host-mapped memory by the LAST sequence of the launch to get here: every sequence's atomic add is ordered
+// before its arrival (release), the last arrival reads the counter after it (acquire).  The host looks at the slot only
+// behind an event recorded after the launch, so it never sees a partial count.
+__device__ __forceinline__ void ff_pointer_count(const PointerArgs& a, int b, int idx) {
+  if (a.count_ge && idx >= a.ge_bound) atomicAdd(a.count_ge, 1);
+  if (a.count_eq && idx == a.eq_value) {
+    bool first = true;
+    if (a.seen) { first = a.seen[b] == 0; a.seen[b] = 1; }   // (only this sequence's wavefronts touch seen[b], one step at a time)
+    if (first) atomicAdd(a.count_eq, 1);
+  }
+  if (a.arrive) {
+    const int prev = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == a.B - 1) {
+      const int v = __hip_atomic_load(a.host_which ? a.count_eq : a.count_ge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.host_slot, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 
 // `logits` holds the raw dot products of every (sequence, key); mask the row in place and reduce (value, index) pairs --
 // per lane over its strided keys, then across the 64 lanes with a butterfly that keeps torch's tie rule (lowest index)
@@ -712,8 +737,7 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
     ff_st4i(a.next_tok + b, i1);
     if (a.best) ff_st4(a.best + b, b1);
     if (a.second) ff_st4(a.second + b, b2);
-    if (a.count_ge && i1 >= a.ge_bound) atomicAdd(a.count_ge, 1);
-    if (a.count_eq && i1 == a.eq_value) atomicAdd(a.count_eq, 1);
+    ff_pointer_count(a, b, i1);
   }
   if (a.next_rows) {
     const float* src = a.memory + ((size_t)w * a.S + i1) * a.E;

@@ -59,20 +59,20 @@ __global__ void init_tokens_kernel(int* tok, int Bc, int Fc, int f0, const int* 
 }
 
 // steps_done from the per-step counters (the reference's stop rules, model_para.py:232 / model.py:207-210)
-__global__ void steps_kernel(const int* __restrict__ cnt_ge, const int* __restrict__ cnt_eq, int variant, int N,
-                             int steps_enqueued, int no_stop, int* __restrict__ steps_done_out) {
+// The counters are kept per (step, micro-batch) -- every pointer launch owns one, which it also publishes to the host
+// (ff_pointer_count) -- and summed here into cnt_tot[step].
+__global__ void steps_kernel(const int* __restrict__ cnt_ge, const int* __restrict__ cnt_eq, int nch, int variant, int N,
+                             int steps_enqueued, int no_stop, int* __restrict__ cnt_tot, int* __restrict__ steps_done_out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int steps = steps_enqueued;
-  if (no_stop) {
-  } else if (variant == FF_PARALLEL) {
-    for (int s = 0; s < steps_enqueued; ++s)
-      if (cnt_ge[s] == 0) { steps = s + 1; break; }
-  } else {
-    int cum = 0;
-    for (int s = 0; s < steps_enqueued; ++s) {
-      cum += cnt_eq[s];
-      if (cum == N) { steps = s + 1; break; }
-    }
+  const int* cnt = variant == FF_PARALLEL ? cnt_ge : cnt_eq;
+  int steps = steps_enqueued, cum = 0;
+  bool found = false;
+  for (int s = 0; s < steps_enqueued; ++s) {
+    int v = 0;
+    for (int c = 0; c < nch; ++c) v += cnt[(size_t)s * nch + c];
+    cnt_tot[s] = v;
+    cum += v;
+    if (!found && !no_stop && (variant == FF_PARALLEL ? v == 0 : cum == N)) { steps = s + 1; found = true; }
   }
   *steps_done_out = steps;
 }
@@ -124,8 +124,9 @@ int gemm(const float* A, int lda, const float* A2, int n_split, const float* W, 
 // N = 1536: 92 vs 65 TF/s at 1024 rows; N = 1024: 122 vs 94 at 2048 (69 vs 80 at 1024); the N = 512 projections, K = 512 or
 // 1024: 96 vs 72 / 119 vs 89 at 3072 (67 vs 79 / 84 vs 93 at 2048)): x3_min_rows is the threshold of the widest product, the
 // others need 7/4 and 11/4 times as many rows.
-inline bool x3_wins(const ff_decode_params* prm, int M, int N, int K) {
+inline bool x3_wins(const ff_decode_params* prm, int M, int N, int K, int lda) {
   if (prm->x3_min_rows <= 0 || (K % 32) != 0 || K < 64 || (N & 3) != 0) return false;
+  if ((size_t)M * (size_t)lda >= ((size_t)1 << 30)) return false;   // the split kernel's 32-bit byte offsets (x3_check_common): f32 family instead
   const long need = (long)prm->x3_min_rows * (N >= 1536 ? 4 : (N >= 1024 ? 7 : 11)) / 4;
   return M >= need;
 }
@@ -135,7 +136,7 @@ inline bool x3_wins(const ff_decode_params* prm, int M, int N, int K) {
 int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, int lda, const float* A2, int n_split,
                const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M,
                int N, int K, int act, hipStream_t st) {
-  if (planes && x3_wins(prm, M, N, K) && (!A2 || (n_split % 128) == 0))
+  if (planes && x3_wins(prm, M, N, K, lda) && (!A2 || (n_split % 128) == 0))
     return ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
   return gemm(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, st);
 }
@@ -151,7 +152,11 @@ struct DecodeBuffers {
   float *x0_all, *qkv0_all;
   int* tok_all;   // [T, Btot] global, position-major
   Scratch scr[FF_MAX_STREAMS];
-  int *cnt_ge, *cnt_eq, *steps_dev;
+  int *cnt_ge, *cnt_eq;   // [T, nch] per (step, micro-batch)
+  int *arrive;            // [T, nch] arrivals of the pointer launches (counter hand-over to the host)
+  int *seen;              // [Btot] FF_STOP_EACH_EOS: the sequence has produced an EOS
+  int *cnt_tot;           // [T] per-step totals (steps_kernel)
+  int *steps_dev;
 };
 
 // A micro-batch is a contiguous range [b0, b0 + Bc) of the COMPACT sequence index: nw >= 1 consecutive
@@ -178,7 +183,7 @@ inline int compact_width(const ff_decode_params* p, const int* num_input_host, i
 // wireframe into sequence groups.  Callers that want tight chunks pass the wireframes sorted by edge count
 // (the Python model does).
 void plan_chunks(const ff_decode_params* p, const int* num_input_host, int ns, std::vector<Chunk>* out, int* btot,
-                 int* max_bc) {
+                 int* max_bc, int* nchunks = nullptr) {
   const int N = p->N;
   int cw_lim = (p->chunk_wireframes <= 0 || p->chunk_wireframes > N) ? N : p->chunk_wireframes;
   // The single-sequence model decodes ONE sequence per wireframe (reference model.py:193-210: N sequences per step), so a
@@ -186,7 +191,7 @@ void plan_chunks(const ff_decode_params* p, const int* num_input_host, int ns, s
   // <= 4 128-row launches.  There the micro-batch is cut by SEQUENCES: up to chunk_max_seqs of them (0: chunk_wireframes as
   // before).  The cumulative EOS rule is untouched: every micro-batch adds to the same per-step counters.
   if (p->variant == FF_SEQ2SEQ && p->chunk_max_seqs > 0) cw_lim = p->chunk_max_seqs < N ? p->chunk_max_seqs : N;
-  int b0 = 0, mx = 0;
+  int b0 = 0, mx = 0, nc = 0;
   int w = 0;
   while (w < N) {
     int Fm = compact_width(p, num_input_host, w), Fmin = Fm, nw = 1;
@@ -208,12 +213,14 @@ void plan_chunks(const ff_decode_params* p, const int* num_input_host, int ns, s
       c.x0 = nullptr; c.qkv0 = nullptr;
       b0 += c.Bc;
       mx = c.Bc > mx ? c.Bc : mx;
+      ++nc;
       if (out) out->push_back(c);
     }
     w += nw;
   }
   *btot = b0;
   *max_bc = mx;
+  if (nchunks) *nchunks = nc;
 }
 
 int plan_streams(const ff_decode_params* p) {
@@ -221,7 +228,7 @@ int plan_streams(const ff_decode_params* p) {
 }
 
 // Workspace layout for `btot` compact sequences in micro-batches of at most `max_bc`.
-size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, size_t Bch, Bump& bp,
+size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, size_t Bch, size_t nch, Bump& bp,
                      DecodeBuffers* out) {
   const int E = m->E, FFd = m->FF, S = p->L + m->num_token, T = p->T;
   const int ns = plan_streams(p);
@@ -245,8 +252,11 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, 
     c.logits = bp.take<float>(Bch * (size_t)S);
     c.lnstat = bp.take<float>(Rmax * (size_t)(E / 32 + 1) * 2);
   }
-  b.cnt_ge = bp.take<int>(T);
-  b.cnt_eq = bp.take<int>(T);
+  b.cnt_ge = bp.take<int>((size_t)T * nch);
+  b.cnt_eq = bp.take<int>((size_t)T * nch);
+  b.arrive = bp.take<int>((size_t)T * nch);
+  b.seen = bp.take<int>(Btot);
+  b.cnt_tot = bp.take<int>(T);
   b.steps_dev = bp.take<int>(4);
   if (out) *out = b;
   return bp.off;
@@ -315,7 +325,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     d.ln_stats_in = st_in; d.ln_nseg = K / 32; d.ln_eps = m->ln_eps;
     d.row_table = table; d.ld_row_table = ldt; d.row_div = Bc; d.row_cols = tcols;
     d.ln_stats_out = st_out;
-    if (planes && x3_wins(prm, M, N, K) && (!st_in || K == 512) && (!table || (tcols & 3) == 0))
+    if (planes && x3_wins(prm, M, N, K, lda) && (!st_in || K == 512) && (!table || (tcols & 3) == 0))
       return ff_gemm_x3_ln(&d, planes, plane_rows, row0, st_in ? colsum : nullptr, st);
     return ff_gemm_f32_ln(&d, st);
   };
@@ -463,12 +473,13 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
 }
 
 // Internal side streams + fork/join events: one pool per device, created on first use.
-constexpr int FF_PINNED_COUNTERS = 8192;
+constexpr int FF_PINNED_COUNTERS = 65536;   // host-mapped ints: one per (step, micro-batch) of a decode
 struct StreamPool {
   hipStream_t side[FF_MAX_STREAMS];
   hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];
-  hipEvent_t chk_ev[FF_MAX_STREAMS], chk_done;   // stop-rule check: per-stream progress marks, copy completion
-  int* hpin;                                       // pinned host copy of the per-step counters
+  hipEvent_t chk_ev[FF_MAX_STREAMS];      // stop-rule check: per-stream progress marks
+  int* hpin;                                // host-mapped pinned counters [step][micro-batch], written by the pointer launches
+  int* hpin_dev;                            // ... the device-visible address of the same memory
   int created;
   bool events;
 };
@@ -491,8 +502,11 @@ int pool_get(int n, StreamPool** out) {
       FF_CHECK_HIP(hipEventCreateWithFlags(&pool.join_ev[i], hipEventDisableTiming));
       FF_CHECK_HIP(hipEventCreateWithFlags(&pool.chk_ev[i], hipEventDisableTiming));
     }
-    FF_CHECK_HIP(hipEventCreateWithFlags(&pool.chk_done, hipEventDisableTiming));
-    FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.hpin), sizeof(int) * FF_PINNED_COUNTERS, hipHostMallocDefault));
+    // coherent (fine-grained) host memory mapped into the device's address space: the pointer launches store their stop-rule
+    // counters straight into it (system-scope stores; no copy launch between two decode steps)
+    FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.hpin), sizeof(int) * FF_PINNED_COUNTERS,
+                               hipHostMallocMapped | hipHostMallocCoherent));
+    FF_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&pool.hpin_dev), pool.hpin, 0));
     pool.events = true;
   }
   while (pool.created < n) {
@@ -579,10 +593,10 @@ extern "C" int ff_encode(const ff_model* m, const float* input, const unsigned c
 
 extern "C" size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_params* p, const int* num_input_host) {
   if (!m || !p || p->N <= 0 || p->F <= 0 || p->T <= 0) return 0;
-  int btot = 0, max_bc = 0;
-  plan_chunks(p, num_input_host, 1, nullptr, &btot, &max_bc);
+  int btot = 0, max_bc = 0, nch = 0;
+  plan_chunks(p, num_input_host, 1, nullptr, &btot, &max_bc, &nch);
   Bump bp(nullptr, 0);
-  return layout_decode(m, p, (size_t)btot, (size_t)max_bc, bp, nullptr) + 256;
+  return layout_decode(m, p, (size_t)btot, (size_t)max_bc, (size_t)nch, bp, nullptr) + 256;
 }
 
 extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const float* memory,
@@ -602,8 +616,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   // The callback's cadence is a CONTRACT with callers that replay it elsewhere (an idle rank of a sharded decode joins the
   // same host collectives: faceformer_amd/dist.py check_points): the counters of the first n = enq - sync_every steps when
   // enq = 2 sync_every, 3 sync_every, ... steps are enqueued.  Only the lag-free path below has that cadence.
-  FF_CHECK_ARG(!p->stop_fn || (p->flags & FF_NO_STOP) || p->T <= 8192,
-               "ff_decode: stop_fn needs T <= 8192 (the lag-free counter copies; longer decodes check without a lag)");
+  FF_CHECK_ARG(!(p->flags & FF_STOP_EACH_EOS) || p->variant == FF_SEQ2SEQ, "ff_decode: FF_STOP_EACH_EOS is a seq2seq rule");
   const int E = m->E, S = p->L + m->num_token, T = p->T, F = p->F, N = p->N;
   FF_CHECK_ARG(S <= m->pos_len, "ff_decode: S=%d exceeds the position table (%d rows)", S, m->pos_len);
   FF_CHECK_ARG(T - 1 <= m->qpos_len, "ff_decode: T-1=%d exceeds the query position table (%d rows)", T - 1, m->qpos_len);
@@ -622,7 +635,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   plan_chunks(p, num_input_host, ns_req, &chunks, &Btot, &max_bc);
   Bump bp(workspace, workspace_bytes);
   DecodeBuffers buf;
-  layout_decode(m, p, (size_t)Btot, (size_t)max_bc, bp, &buf);
+  const int nch = (int)chunks.size();
+  layout_decode(m, p, (size_t)Btot, (size_t)max_bc, (size_t)nch, bp, &buf);
   if (!bp.ok) { ff_set_error("ff_decode: workspace too small (%zu needed, %zu given)", bp.off, workspace_bytes); return FF_ERR_WORKSPACE; }
   for (Chunk& c : chunks) {
     c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
@@ -648,6 +662,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   };
 
   int enq = 0;
+  const bool each_eos = (p->flags & FF_STOP_EACH_EOS) != 0;
   // Everything that enqueues work on the side streams sits in this lambda: on ANY failure the streams are
   // drained before the error is returned (the caller frees the workspace the queued kernels use).
   auto run = [&]() -> int {
@@ -659,8 +674,10 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       FF_RETURN_IF(gemm(buf.mem_pos, E, memory, E, c.in_proj_w + (size_t)E * E, E, c.in_proj_b + E, nullptr, 0,
                         buf.kvc[l], 2 * E, RS, 2 * E, E, 0, main_st));
     }
-    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * T, main_st));
-    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * T, main_st));
+    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * (size_t)T * nch, main_st));
+    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * (size_t)T * nch, main_st));
+    FF_CHECK_HIP(hipMemsetAsync(buf.arrive, 0, sizeof(int) * (size_t)T * nch, main_st));
+    if (each_eos) FF_CHECK_HIP(hipMemsetAsync(buf.seen, 0, sizeof(int) * (size_t)Btot, main_st));
     if (forked) {  // fork
       FF_CHECK_HIP(hipEventRecord(pool->fork_ev, main_st));
       for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], pool->fork_ev, 0));
@@ -679,14 +696,23 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     const int max_steps = T - 1;
     const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
-    // Stop rule on the host WITHOUT draining the queue: every sync_every steps the counters of the steps enqueued so
-    // far are copied to pinned memory behind the work (event-ordered on every stream); the copy issued at step c is
-    // looked at when step c + sync_every has been enqueued -- by then the host is a whole period ahead of it, so the
-    // wait normally returns at once and the GPU always has a period of steps queued.  A stop is noticed at most
+    // Stop rule on the host WITHOUT draining the queue and WITHOUT a copy launch: every pointer launch owns the counter of
+    // its (step, micro-batch) and its last sequence stores the total into host-mapped pinned memory (ff_pointer_count).
+    // Every sync_every steps an event is recorded behind the steps enqueued so far (on every stream); it is waited for
+    // when another sync_every steps have been enqueued -- by then the host is a whole period ahead of it, so the wait
+    // normally returns at once and the GPU always has a period of steps queued.  A stop is noticed at most
     // 2 * sync_every - 1 steps late; those surplus steps are dropped by the finalize kernels (exact results).
     bool stopped = false;
-    int pending_enq = 0;   // > 0: a counter copy covering steps [0, pending_enq) is in flight
-    const bool lagged = T <= FF_PINNED_COUNTERS;
+    int pending_enq = 0;   // > 0: events covering steps [0, pending_enq) are in flight
+    const bool lagged = (size_t)T * (size_t)nch <= (size_t)FF_PINNED_COUNTERS;
+    std::vector<int> tot;
+    auto host_totals = [&](const int* per_chunk, int n) -> const int* {   // [n][nch] -> per-step totals
+      tot.assign((size_t)n, 0);
+      const volatile int* v = per_chunk;
+      for (int s_ = 0; s_ < n; ++s_)
+        for (int c = 0; c < nch; ++c) tot[(size_t)s_] += v[(size_t)s_ * nch + c];
+      return tot.data();
+    };
     auto eval_counts = [&](const int* cnt, int n) {
       if (p->stop_fn) return p->stop_fn(p->stop_user, cnt, n) != 0;   // the caller's (batch-global) rule
       if (p->variant == FF_PARALLEL) {
@@ -703,13 +729,17 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
         hipStream_t st = sts[c.sid];
         const Scratch& sc = buf.scr[c.sid];
         const size_t trow = (size_t)step * ((size_t)N * F) + c.b0;  // traces: step stride N*F (caller sizes them so)
+        const size_t slot = (size_t)step * nch + (size_t)(&c - chunks.data());
+        ff_pointer_sync psync{each_eos ? buf.seen + c.b0 : nullptr, lagged ? buf.arrive + slot : nullptr,
+                              lagged ? pool->hpin_dev + slot : nullptr, p->variant == FF_PARALLEL ? 0 : 1};
         auto pointer_head = [&]() -> int {
-          return ff_pointer_argmax(
+          return ff_pointer_argmax_sync(
               sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
               extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,
               buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
               trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
-              c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + step, m->num_token, buf.cnt_eq + step, p->tok_eos, st);
+              c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + slot, m->num_token, buf.cnt_eq + slot, p->tok_eos,
+              (each_eos || lagged) ? &psync : nullptr, st);
         };
         FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
         FF_RETURN_IF(pointer_head());
@@ -721,33 +751,28 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       ++step;
       enq = step;
       if (p->sync_every > 0 && !(p->flags & FF_NO_STOP) && (enq % p->sync_every) == 0 && enq < max_steps) {
-        const int* src = (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq;
         if (lagged) {
           if (pending_enq > 0) {
-            FF_CHECK_HIP(hipEventSynchronize(pool->chk_done));
-            stopped = eval_counts(pool->hpin, pending_enq);
+            for (int s_ = 0; s_ < ns; ++s_) FF_CHECK_HIP(hipEventSynchronize(pool->chk_ev[s_]));
+            stopped = eval_counts(host_totals(pool->hpin, pending_enq), pending_enq);
             pending_enq = 0;
           }
           if (!stopped) {
-            if (forked)
-              for (int s = 0; s < ns; ++s) {
-                FF_CHECK_HIP(hipEventRecord(pool->chk_ev[s], sts[s]));
-                FF_CHECK_HIP(hipStreamWaitEvent(main_st, pool->chk_ev[s], 0));
-              }
-            FF_CHECK_HIP(hipMemcpyAsync(pool->hpin, src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
-            FF_CHECK_HIP(hipEventRecord(pool->chk_done, main_st));
+            for (int s_ = 0; s_ < ns; ++s_) FF_CHECK_HIP(hipEventRecord(pool->chk_ev[s_], sts[s_]));
             pending_enq = enq;
           }
-        } else {
-          std::vector<int> hcnt(enq);
+        } else {   // more (step, micro-batch) counters than host slots: drain and copy
+          std::vector<int> hcnt((size_t)enq * nch);
           FF_RETURN_IF(sync_all());
-          FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), src, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+          FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
+                                      sizeof(int) * hcnt.size(), hipMemcpyDeviceToHost, main_st));
           FF_CHECK_HIP(hipStreamSynchronize(main_st));
-          stopped = eval_counts(hcnt.data(), enq);
+          stopped = eval_counts(host_totals(hcnt.data(), enq), enq);
         }
       }
     }
-    if (pending_enq > 0) FF_CHECK_HIP(hipEventSynchronize(pool->chk_done));   // hpin is reused by the next call
+    if (pending_enq > 0)   // the slots are reused by the next call
+      for (int s_ = 0; s_ < ns; ++s_) FF_CHECK_HIP(hipEventSynchronize(pool->chk_ev[s_]));
     if (dbg_timing) {
       const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
       FF_RETURN_IF(sync_all());
@@ -775,8 +800,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   // Everything after the greedy loop (stop step, packing, the optional return-pointer pass) enqueues work that reads the
   // caller's workspace as well: same rule as above -- on any failure the streams are drained before the error goes back.
   auto finish = [&]() -> int {
-    hipLaunchKernelGGL(steps_kernel, dim3(1), dim3(64), 0, main_st, buf.cnt_ge, buf.cnt_eq, p->variant, N, enq,
-                       ((p->flags & FF_NO_STOP) || p->stop_fn) ? 1 : 0, buf.steps_dev);
+    hipLaunchKernelGGL(steps_kernel, dim3(1), dim3(64), 0, main_st, buf.cnt_ge, buf.cnt_eq, nch, p->variant, N, enq,
+                       ((p->flags & FF_NO_STOP) || p->stop_fn) ? 1 : 0, buf.cnt_tot, buf.steps_dev);
     FF_CHECK_LAUNCH();
     for (const Chunk& c : chunks) {
       const long total = (long)c.nw * F * T;
@@ -788,8 +813,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     int steps = 0;
     FF_CHECK_HIP(hipMemcpyAsync(&steps, buf.steps_dev, sizeof(int), hipMemcpyDeviceToHost, main_st));
     if (step_counts && enq > 0)
-      FF_CHECK_HIP(hipMemcpyAsync(step_counts, (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
-                                  sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
+      FF_CHECK_HIP(hipMemcpyAsync(step_counts, buf.cnt_tot, sizeof(int) * enq, hipMemcpyDeviceToHost, main_st));
     FF_CHECK_HIP(hipStreamSynchronize(main_st));
     if (steps_done) *steps_done = steps;
 
@@ -800,11 +824,14 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       FF_CHECK_ARG(Btot == N * F, "ff_decode: FF_RETURN_POINTER is not available with de-duplicated sequences");
       for (const Chunk& c : chunks) {
         const Scratch& sc = buf.scr[0];
-        float* proj_all = sc.h;  // [steps*Bc, E] fits in the FF-wide scratch
+        // one micro-batch: its [steps * Bc, E] rows ARE pointer_out [steps, Btot, E]; several: through the FF-wide scratch
+        // and one strided copy per micro-batch (was one copy launch per position: 258 of them for configs A / D)
+        float* proj_all = nch == 1 ? pointer_out : sc.h;
         FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, steps, true, proj_all, main_st));
-        for (int j = 0; j < steps; ++j)
-          FF_CHECK_HIP(hipMemcpyAsync(pointer_out + ((size_t)j * Btot + c.b0) * E, proj_all + (size_t)j * c.Bc * E,
-                                      sizeof(float) * c.Bc * E, hipMemcpyDeviceToDevice, main_st));
+        if (nch > 1)
+          FF_CHECK_HIP(hipMemcpy2DAsync(pointer_out + (size_t)c.b0 * E, sizeof(float) * (size_t)Btot * E, proj_all,
+                                        sizeof(float) * (size_t)c.Bc * E, sizeof(float) * (size_t)c.Bc * E, (size_t)steps,
+                                        hipMemcpyDeviceToDevice, main_st));
       }
     }
     return FF_OK;

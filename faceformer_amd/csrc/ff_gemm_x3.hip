@@ -39,6 +39,8 @@
 #include <mutex>
 #include <vector>
 
+#include <atomic>
+
 #include "ff_common.h"
 #include "ff_device.h"
 
@@ -1210,7 +1212,7 @@ int g_x3_force_shape = 0;
 
 template <int BM, int MODE>
 int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
-  static bool attr_set[16] = {};   // hipFuncSetAttribute is per device
+  static std::atomic<bool> attr_set[16] = {};   // hipFuncSetAttribute is per device; host threads may race here (idempotent)
   constexpr int bytes = 3 * (BM * 64 + 3 * X3_BN * 32) + (MODE == 1 ? X3_STAT_BYTES : 0);
   int dev = 0;
   FF_CHECK_HIP(hipGetDevice(&dev));
@@ -1225,7 +1227,7 @@ int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
 }
 template <int BM, int MODE>
 int dma_f32_launch_mode(const X3Args& g, int grid, hipStream_t st) {
-  static bool attr_set[16] = {};
+  static std::atomic<bool> attr_set[16] = {};
   constexpr int bytes = 3 * (BM * 64 + X3_BN * 64) + (MODE == 1 ? X3_STAT_BYTES : 0);
   int dev = 0;
   FF_CHECK_HIP(hipGetDevice(&dev));
@@ -1251,7 +1253,7 @@ int dma_f32_launch_mode(const X3Args& g, int grid, hipStream_t st) {
 int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
   const int M = g.M, N = g.N, K = g.K;
   constexpr int BM = 64;
-  const int cus = 256;
+  const int cus = ff_num_cus();   // 256 on an MI355X in SPX mode; a partition (CPX / fewer CUs) gets its own launch shape
   // block slots per CU: registers / the statistics patch of the LayerNorm consumers decide
   const int spc = f32 ? 3 : ((mode == 1 || mode == 3) ? 2 : 3);
   const int slots = cus * spc;

@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256) void pointer_kernel(PointerArgs a) {
     a.next_tok[b] = best_idx;
     if (a.best) a.best[b] = best;
     if (a.second) a.second[b] = second;
-    if (a.count_ge && best_idx >= a.ge_bound) atomicAdd(a.count_ge, 1);
-    if (a.count_eq && best_idx == a.eq_value) atomicAdd(a.count_eq, 1);
+    ff_pointer_count(a, b, best_idx);
   }
   if (a.next_rows) {
     const float* src = mem + (size_t)best_idx * a.E;
@@ -135,6 +134,17 @@ extern "C" int ff_pointer_argmax(const float* p, int ldp, const float* memory, i
                                  float* logits, int ldlogits, float* next_rows, int ldnext,
                                  int* count_ge, int ge_bound, int* count_eq, int eq_value,
                                  ff_stream_t stream) {
+  return ff_pointer_argmax_sync(p, ldp, memory, S, E, mask, kv_len, extra_mask, ldextra, B, seqs_per_group, next_tok, best,
+                                second, logits, ldlogits, next_rows, ldnext, count_ge, ge_bound, count_eq, eq_value, nullptr,
+                                stream);
+}
+
+// The same operator with the decode engine's counter hand-over (ff_common.h: ff_pointer_sync); not part of the C ABI.
+int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, int E, const unsigned char* mask,
+                           const int* kv_len, const unsigned char* extra_mask, int ldextra, int B, int seqs_per_group,
+                           int* next_tok, float* best, float* second, float* logits, int ldlogits, float* next_rows,
+                           int ldnext, int* count_ge, int ge_bound, int* count_eq, int eq_value,
+                           const ff_pointer_sync* sync, ff_stream_t stream) {
   if (B == 0) return FF_OK;
   FF_CHECK_ARG(B > 0 && S > 0 && E > 0 && (E & 3) == 0 && E <= 2048 && seqs_per_group > 0,
                "ff_pointer_argmax: bad sizes B=%d S=%d E=%d", B, S, E);
@@ -145,7 +155,10 @@ extern "C" int ff_pointer_argmax(const float* p, int ldp, const float* memory, i
   FF_CHECK_ARG(!extra_mask || ldextra >= S, "ff_pointer_argmax: ldextra < S");
   PointerArgs a{p, ldp, memory, S, E, mask, kv_len, extra_mask, ldextra, B, seqs_per_group,
                 next_tok, best, second, logits, ldlogits, next_rows, ldnext,
-                count_ge, ge_bound, count_eq, eq_value};
+                count_ge, ge_bound, count_eq, eq_value,
+                sync ? sync->seen : nullptr, sync ? sync->arrive : nullptr, sync ? sync->host_slot : nullptr,
+                sync ? sync->host_which : 0};
+  FF_CHECK_ARG(!a.arrive || (a.host_slot && (a.host_which ? count_eq : count_ge)), "ff_pointer_argmax: counter hand-over without a counter");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ff_cdiv(B, 4)), block(256);
   if (logits != nullptr && (B % seqs_per_group) == 0) {

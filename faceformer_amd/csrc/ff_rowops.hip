@@ -18,6 +18,18 @@ void ff_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int ff_num_cus() {
+  static std::atomic<int> cached[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 extern "C" int ff_version(void) { return FF_ABI_VERSION; }
 extern "C" const char* ff_last_error(void) { return g_ff_error; }
 extern "C" int ff_device_count(void) {

@@ -19,6 +19,8 @@ plan from `num_input`, so no extra communication is needed to reassemble the bat
 A rank may also hold ONLY its own wireframes (`local_shard=True`): then F, the stop-rule counters and the
 wireframe counts are agreed by collectives and the result is the concatenation in rank order.
 """
+import os
+
 import torch
 
 from .hip import lib as _L
@@ -141,8 +143,11 @@ def _control_group(dist_mod, group):
     return _CONTROL_GROUPS[key]
 
 
-# a rank that fails inside a stop check must not leave its peers blocked for torch's default 30 minutes
-CONTROL_TIMEOUT_S = 120
+# A rank that fails inside a stop check must not leave its peers blocked for ever -- but the first check of an early (or
+# idle) rank also waits for its slowest peer to GET there (data loading, first-call library build, a very large shard), so the
+# limit is torch's own 30 minutes unless the caller shortens it: FF_CONTROL_TIMEOUT_S, or dist.CONTROL_TIMEOUT_S before the
+# first sharded decode.  A caller-supplied control_group keeps its own timeout.
+CONTROL_TIMEOUT_S = int(os.environ.get("FF_CONTROL_TIMEOUT_S", "1800"))
 
 
 def check_points(T, sync_every):
@@ -166,7 +171,8 @@ def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callbac
                      num_input=[num_input[i] for i in order] if parallel else None,
                      chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                      chunk_max_seqs=getattr(model, "chunk_max_seqs", 0),
-                     num_streams=model.num_streams, sync_every=sync_every if stop_callback else 0, flags=model.decode_flags,
+                     num_streams=model.num_streams, sync_every=sync_every if stop_callback else 0,
+                     flags=model.decode_flags | (_L.FF_STOP_EACH_EOS if (not parallel and getattr(model, "stop_each_eos", False)) else 0),
                      x3_min_rows=model.x3_min_rows, ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0), extra_mask=extra_rows,
                      tok_sos=model.token.SOS if not parallel else 1,
                      tok_eos=model.token.EOS if not parallel else 3, no_stop=stop_callback is None,
@@ -333,9 +339,18 @@ def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominan
     from . import faces as FZ
     from .models import SurfaceFormer_Parallel
     n_here = inputs["input"].size(0)
-    out = decode_sharded(model, inputs, dist_mod, group, local_shard=local_shard)
-    rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
     parallel = isinstance(model, SurfaceFormer_Parallel)
+    # seq2seq: the reference's batch rule counts a sample's repeated EOS too and can stop the batch before another sample's own
+    # EOS; the records must be those of one-wireframe decodes, so the batch runs until EVERY wireframe has produced one
+    each = None if parallel else getattr(model, "stop_each_eos", False)
+    if each is False:
+        model.stop_each_eos = True
+    try:
+        out = decode_sharded(model, inputs, dist_mod, group, local_shard=local_shard)
+    finally:
+        if each is False:
+            model.stop_each_eos = False
+    rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
     if local_shard:
         sizes = out["shard_sizes"]
         N, base = sum(sizes), sum(sizes[:rank])

@@ -24,6 +24,11 @@ class SurfaceFormer(SurfaceFormerBase):
         # One sequence per wireframe: a micro-batch is cut by sequences, not by `chunk_wireframes` wireframes.  256 sequences
         # x (label_seq_length - 1) positions = 66 k active rows at the last step of configs A / D (1.6 GB of scratch).
         self.chunk_max_seqs = 256
+        # False: the reference's batch rule -- stop when the CUMULATIVE count of EOS tokens equals the batch size
+        # (model.py:191,207-210; a sample that repeats its EOS can end a batch before another sample has produced its own).
+        # True: stop at the first step by which EVERY wireframe has produced an EOS (FF_STOP_EACH_EOS) -- what a caller needs
+        # when the records of a batch must equal those of one-wireframe decodes (main.py --batch-size, dist.decode_to_face_json).
+        self.stop_each_eos = False
 
     def get_embeddings(self, input, label):
         val_embed = self.val_enc(input)
@@ -41,7 +46,8 @@ class SurfaceFormer(SurfaceFormerBase):
         out = eng.decode(memory, mask, kv_len, _L.FF_SEQ2SEQ, T=T, F=1,
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
                          chunk_max_seqs=self.chunk_max_seqs, num_streams=self.num_streams, sync_every=1,
-                         flags=self.decode_flags, x3_min_rows=self.x3_min_rows, ln_fuse_max_rows=self.ln_fuse_max_rows, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
+                         flags=self.decode_flags | (_L.FF_STOP_EACH_EOS if self.stop_each_eos else 0),
+                         x3_min_rows=self.x3_min_rows, ln_fuse_max_rows=self.ln_fuse_max_rows, tok_sos=self.token.SOS, tok_eos=self.token.EOS,
                          return_pointer=True, extra_mask=self._extra_mask(inputs))
         inputs["embedding"] = memory
         inputs["pointer"] = out["pointer"].transpose(0, 1)

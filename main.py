@@ -12,7 +12,11 @@ under logs/<name>/<version>/json/, printing the running mean decode time and pre
 call, i.e. the micro-batched engine -- 128 wireframes per call run at 0.84 of the f32 matrix peak, one at 0.63
 (DESIGN.md 5).  The records do not depend on N: a wireframe's faces are parsed from its OWN anchor rows (not the
 batch-wide padding-anchor rows behind them) up to its OWN stop step (faces.apply_own_stop_rule: in a batch the
-reference's loop runs on until every wireframe is done), i.e. from exactly the tokens a one-sample decode leaves.
+loop runs on until every wireframe is done), i.e. from exactly the tokens a one-sample decode leaves.  For the
+single-sequence model that needs another batch rule than the reference's: its loop stops when the CUMULATIVE number
+of EOS tokens equals the batch size (model.py:207-210), which a sample that repeats its EOS reaches before another
+sample has produced its own; with N > 1 the decode therefore runs until EVERY wireframe has produced an EOS
+(SurfaceFormer.stop_each_eos, ff_decode flag FF_STOP_EACH_EOS).
 
 Under torch.distributed.run every rank decodes a contiguous share of the samples on its own GPU; the JSON
 records are all-gathered (faceformer_amd.dist.gather_json_records: RCCL on GPUs, gloo on CPU) and rank 0
@@ -76,6 +80,9 @@ def run_test(cfg, ckpt_path, out_dir=None, device="cuda", limit=None, batch_size
     ds = dataset_class(cfg.root_dir, cfg.datasets_test, cfg.model)
     out_dir = out_dir or os.path.join("logs", cfg.trainer.name, str(cfg.trainer.version), "json")
     parallel = cfg.model_class == "SurfaceFormer_Parallel"
+    batch_size = max(1, int(batch_size))
+    if not parallel and batch_size > 1 and hasattr(model, "stop_each_eos"):
+        model.stop_each_eos = True      # every wireframe decodes up to its own EOS (module docstring)
     rank = dist_mod.get_rank() if dist_mod is not None else 0
     world = dist_mod.get_world_size() if dist_mod is not None else 1
     n_all = len(ds) if limit is None else min(limit, len(ds))

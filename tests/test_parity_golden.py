@@ -387,6 +387,49 @@ def test_seq2seq_batch_is_micro_batched_by_sequences_and_equals_one_wireframe_de
     assert np.array_equal(fwd[:, :steps + 1], full[:, :steps + 1]) and (fwd[:, steps + 1:] == 0).all()
 
 
+def test_seq2seq_batch_with_a_repeated_eos_keeps_every_wireframes_own_tokens(hip_lib):
+    """the reference's batch rule stops when the CUMULATIVE EOS count equals the batch size
+    (model.py:207-210).  Small seq2seq model, weight seed 9: wireframe A (7 edges, seed 33) emits EOS at steps 5, 6 and 7,
+    wireframe B (12 edges, seed 30) its first EOS at step 9 (searched with the oracle).  In the batch [A, B] the reference's
+    loop -- and the engine's default rule -- stops after step 6, before B's EOS.  With `stop_each_eos` the decode runs until
+    both have one, and each wireframe's tokens up to its own stop equal its one-wireframe decode: what main.py
+    --batch-size and dist.decode_to_face_json parse their records from."""
+    from faceformer_amd import faces as FZ
+    from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec
+    from oracle import refpath
+    L_, T = 16, 20
+    case = dict(kind="seq2seq", model=dict(E=128, H=2, FF=256, enc=2, dec=2, L=L_, seq_len=T))
+    sd = make_state_dict(state_dict_spec("seq2seq", L_, T, 128, 256, 2, 2), "gain4", 9)
+    model = build_model(case, sd, "cuda")
+    tok = model.token
+    pair = make_wireframes([7, 12], L_, T, "seq2seq", seeds=[33, 30])
+    ref = refpath.seq2seq_forward_eval(sd, dict(pair), num_head=2)["predict"].numpy()
+    with torch.no_grad():
+        got = model(batch_to(pair, "cuda"))["predict"].cpu().numpy()
+    assert np.array_equal(got, ref)                                  # the reference's rule, bit for bit
+    assert (ref[0, 1:] == tok.EOS).sum() == 2 and (ref[1] == tok.EOS).sum() == 0 and (ref[:, 8:] == 0).all()
+    singles = []
+    for n, sd_ in ((7, 33), (12, 30)):
+        one = make_wireframes([n], L_, T, "seq2seq", seeds=[sd_])
+        with torch.no_grad():
+            singles.append(model(batch_to(one, "cuda"))["predict"].cpu().numpy()[0])
+        assert np.array_equal(singles[-1], refpath.seq2seq_forward_eval(sd, dict(one), num_head=2)["predict"].numpy()[0])
+    assert (singles[1] == tok.EOS).sum() == 1 and int(np.nonzero(singles[1] == tok.EOS)[0][0]) == 10
+    model.stop_each_eos = True
+    for chunk in (256, 1):
+        model.chunk_max_seqs = chunk
+        with torch.no_grad():
+            each = model(batch_to(pair, "cuda"))["predict"].cpu().numpy()
+        assert (each[:, 11:] == 0).all() and each[1, 10] == tok.EOS      # ran through step 9, B's first EOS
+        for i in range(2):
+            own = FZ.apply_own_stop_rule(each[i], tok, False)
+            assert np.array_equal(own, singles[i]), "wireframe %d: batch tokens differ from its one-wireframe decode" % i
+    # the default rule of a one-wireframe batch is untouched by the flag
+    with torch.no_grad():
+        one_each = model(batch_to(make_wireframes([12], L_, T, "seq2seq", seeds=[30]), "cuda"))["predict"].cpu().numpy()[0]
+    assert np.array_equal(one_each, singles[1])
+
+
 def test_json_gather_over_rccl(hip_lib, tmp_path):
     """The north-star's 'RCCL all-gather of predicted face-loop JSON': decode_to_face_json on the nccl backend
     (world size 1 on this box; the gloo tests cover world sizes 2 and 3) incl. the co-edge post-processing
