@@ -48,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
+NOMINAL_GHZ = 2.4             # the clock both matrix peaks are quoted at
 E_SIZES, E_PROBS, E_SEED = (64, 128, 256, 512, 1024), (.3, .3, .2, .1, .1), 2024
 CAT_NAMES = ["gemm_f32_kernels", "attention_kernels", "layernorm_kernel", "pointer_kernels", "row_ops", "unused",
              "gemm_bf16x3_kernel"]
@@ -192,7 +193,8 @@ def x3_roofline(prof, wall_ms, with_traffic=False):
         "kernel_time_ms_per_step": {CAT_NAMES[i]: net[i] for i in range(len(ms))},
         "kernel_launches_per_step": {CAT_NAMES[i]: cnt[i] for i in range(len(ms))},
         "note": "peak = 2500 TF/s dense bf16 / 6 partial products; the loop is POWER-limited on this chip: the same binary reaches "
-                "245-272 TF/s-equivalent on zero-filled operands and 170-200 on random ones (profiles/r04/x3v2_*.txt)",
+                "245-272 TF/s-equivalent on zero-filled operands and 170-200 on random ones (profiles/r04/x3v2_*.txt); "
+                "effective_clock_ghz = shader clock measured under this configuration's passes (profiles/r05/effective_clock.md)",
     }
 
 
@@ -221,7 +223,7 @@ def _cut(s, n):
 
 
 ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "launches_per_step",
-             "avg_launch_us", "share_of_kernel_time", "effective_clock_ghz")
+             "avg_launch_us", "share_of_kernel_time", "effective_clock_ghz", "frac_at_effective_clock")
 LINE_LIMIT = 4096
 
 
@@ -492,6 +494,21 @@ def main():
         nz = (p[:, 1:] != 0).any(dim=0)
         return int(nz.nonzero().max().item()) + 1 if bool(nz.any()) else 0
 
+    def effective_clock(step_fn, sec_per_pass):
+        """GHz the SIMDs ran at while `step_fn` passes were executing: a one-wave probe kernel on a second stream reads the
+        shader-clock counter against the constant 100 MHz counter (ff_clock_probe_*) during ~80 % of a ~0.6 s run of passes."""
+        side = torch.cuda.Stream()
+        n = max(2, int(0.6 / max(sec_per_pass, 1e-4)) + 1)
+        step_fn()
+        torch.cuda.synchronize()
+        L.check(lib.ff_clock_probe_launch(ctypes.c_double(0.8 * n * sec_per_pass * 1e6), side.cuda_stream), "ff_clock_probe_launch")
+        for _ in range(n):
+            step_fn()
+        torch.cuda.synchronize()
+        g, u = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        L.check(lib.ff_clock_probe_read(ctypes.byref(g), ctypes.byref(u), side.cuda_stream), "ff_clock_probe_read")
+        return float(g.value)
+
     bracket_us = 0.0
     if rank == 0 and not args.no_roofline:
         b = ctypes.c_double(0.0)
@@ -648,6 +665,9 @@ def main():
                     model(dict(batch))
             roof3 = x3_roofline(profile_once(lib, L, once3), 1e3 * dt3 / args.steps,
                                 with_traffic=(not cfgE and args.edges == 256 and W == 1))
+            ghz3 = effective_clock(once3, dt3 / args.steps)
+            roof3["effective_clock_ghz"] = ghz3
+            roof3["frac_at_effective_clock"] = roof3["frac"] * NOMINAL_GHZ / ghz3 if ghz3 > 0 else None
         model.x3_min_rows = 0
         step()      # (re-binds the engine without the bf16 planes for the profiling leg below)
         fence()
@@ -678,6 +698,9 @@ def main():
             traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
         result["roofline"], extra = gemm_roofline(prof, 1e3 * dt / args.steps, bracket_us, traffic, traffic_src)
         result.update(extra)
+        ghz = effective_clock(once, dt / args.steps)
+        result["roofline"]["effective_clock_ghz"] = ghz
+        result["roofline"]["frac_at_effective_clock"] = result["roofline"]["frac"] * NOMINAL_GHZ / ghz if ghz > 0 else None
 
     cpu_thread = None
     if rank == 0 and not multi and not args.no_cpu_baseline:

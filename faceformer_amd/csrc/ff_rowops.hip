@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "ff_common.h"
 #include "ff_device.h"
@@ -136,6 +137,53 @@ extern "C" int ff_profile_bracket_us(int launches, double* us_per_launch, ff_str
   return FF_OK;
 }
 
+// ---- effective shader clock --------------------------------------------------------------------------------------------
+// One lane reads the shader-clock counter (s_memtime: ticks at the clock the SIMDs run at, MI355X_MICROARCH.md) and the
+// constant 100 MHz counter (s_memrealtime) when it starts, sleeps until `spin_ticks` of the constant counter have passed,
+// and reads both again: shader cycles / wall time = the clock the chip ran at in between.  Launched on a stream of its own
+// BESIDE the kernels under test (a 64-thread block fits next to their workgroups), it samples the clock UNDER that load.
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long spin_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long w0 = wall_clock64();
+  const unsigned long long c0 = clock64();
+  unsigned long long w1 = w0;
+  while (w1 - w0 < spin_ticks) {
+    __builtin_amdgcn_s_sleep(64);
+    w1 = wall_clock64();
+  }
+  const unsigned long long c1 = clock64();
+  out[0] = c1 - c0;
+  out[1] = w1 - w0;
+}
+namespace {
+unsigned long long* g_clock_out = nullptr;   // host-mapped pinned [2]
+std::mutex g_clock_mu;
+}  // namespace
+extern "C" int ff_clock_probe_launch(double spin_us, ff_stream_t stream) {
+  FF_CHECK_ARG(spin_us > 0 && spin_us <= 5e6, "ff_clock_probe_launch: spin_us in (0, 5e6]");
+  std::lock_guard<std::mutex> lock(g_clock_mu);
+  if (!g_clock_out)
+    FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_clock_out), 2 * sizeof(unsigned long long),
+                               hipHostMallocMapped | hipHostMallocCoherent));
+  g_clock_out[0] = g_clock_out[1] = 0;
+  unsigned long long* dev_out = nullptr;
+  FF_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_out), g_clock_out, 0));
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_out,
+                     (unsigned long long)(spin_us * 100.0));   // 100 MHz constant counter
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+extern "C" int ff_clock_probe_read(double* ghz, double* measured_us, ff_stream_t stream) {
+  FF_CHECK_ARG(ghz != nullptr, "ff_clock_probe_read: null output");
+  FF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  std::lock_guard<std::mutex> lock(g_clock_mu);
+  FF_CHECK_ARG(g_clock_out && g_clock_out[1] > 0, "ff_clock_probe_read: no finished probe");
+  const double us = (double)g_clock_out[1] / 100.0;
+  *ghz = (double)g_clock_out[0] / us * 1e-3;
+  if (measured_us) *measured_us = us;
+  return FF_OK;
+}
+
 // ---- LayerNorm (+pos) --------------------------------------------------------------------------
 // NV = float4 chunks per lane (E <= 256*NV).  Two-pass statistics in registers (mean, then the
 // centred second moment) -- the same formula torch's CPU kernel evaluates, biased variance.
@@ -205,6 +253,34 @@ extern "C" int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, 
   FFProfScope prof(FF_CAT_ROWOP, (double)rows * E * 8.0, (hipStream_t)stream);
   hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, pos,
                      ldpos, pos_div, pos_mod, out, ldout, rows, E / 4);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
+// ---- x = gelu(x), exact erf form (torch F.gelu default; reference transformer.py:276-284 "gelu") ------------------------
+// Module surface only: no reference config uses it, so it is a row op behind the plain projection and not a fourth epilogue
+// form inside the hand-scheduled projection kernels.
+__global__ __launch_bounds__(256) void gelu_kernel(float* __restrict__ x, int ldx, int rows, int E4) {
+  const size_t total = (size_t)rows * E4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / E4), c = (int)(i % E4);
+    f32x4* p = reinterpret_cast<f32x4*>(x + (size_t)r * ldx) + c;
+    f32x4 v = *p;
+    v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752440f));
+    v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752440f));
+    v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752440f));
+    v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752440f));
+    *p = v;
+  }
+}
+extern "C" int ff_gelu(float* x, int ldx, int rows, int E, ff_stream_t stream) {
+  if (rows == 0) return FF_OK;
+  FF_CHECK_ARG(rows > 0 && E > 0 && (E & 3) == 0 && x && (ldx & 3) == 0 && ldx >= E && ff_aligned16(x), "ff_gelu: bad arguments");
+  const size_t total = (size_t)rows * (E / 4);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  FFProfScope prof(FF_CAT_ROWOP, (double)rows * E * 8.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(gelu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, E / 4);
   FF_CHECK_LAUNCH();
   return FF_OK;
 }

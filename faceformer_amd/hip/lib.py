@@ -114,10 +114,13 @@ SIGNATURES = {
     "ff_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "ff_profile_bytes": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "ff_profile_bracket_us": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    "ff_clock_probe_launch": (C.c_int, [C.c_double, C.c_void_p]),
+    "ff_clock_probe_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "ff_layernorm": (C.c_int, [fptr, C.c_int, fptr, fptr, C.c_float, fptr, C.c_int, fptr, C.c_int,
                                fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_add_pos": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_int, C.c_int,
                              C.c_int, fptr]),
+    "ff_gelu": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_gemm_f32": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_gemm_f32_batched": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, C.c_int, fptr, fptr, C.c_int, fptr,

@@ -88,6 +88,16 @@ def add_pos(x, pos, pos_div=1, pos_mod=1):
 
 
 @_on_tensor_device
+def gelu_(x):
+    """In-place exact (erf) GELU of a 2-D row tensor; returns x."""
+    x2, ldx = _rows(x, "x")
+    if x2.data_ptr() != x.data_ptr():
+        raise ValueError("gelu_ works in place: x needs a unit inner stride")
+    _L.check(_L.load().ff_gelu(_p(x2), ldx, x2.size(0), x2.size(1), _stream()), "ff_gelu")
+    return x
+
+
+@_on_tensor_device
 def linear(x, weight, bias=None, act=0, residual=None, x2=None, n_split=0, tile=0, out=None):
     """out = act(xsel @ weight.T + bias) + residual on the f32 matrix cores (F.linear layout)."""
     x, lda = _rows(x, "x")

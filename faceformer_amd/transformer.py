@@ -101,7 +101,9 @@ class MultiheadAttention(nn.Module):
     def _check(self):
         _eval_only(self)
         if self.head_dim != FF_HEAD_DIM:
-            raise HipExtensionError("HIP attention kernels support head_dim == 64 only (got %d)" % self.head_dim)
+            raise HipExtensionError(
+                "num_model / num_head = %d / %d gives attention heads of width %d: the HIP attention kernels are written for "
+                "head width %d (every reference config: 512 / 8)" % (self.embed_dim, self.num_heads, self.head_dim, FF_HEAD_DIM))
 
     def project_self(self, yq, y):
         """q|k from `yq`, v from `y` in one launch -> [rows, 3E]."""
@@ -153,11 +155,17 @@ class HipLinear(nn.Linear):
 
 
 def _activation_code(name):
+    """1: ReLU in the projection's epilogue; 2: exact GELU as a row op behind the plain projection (module surface only: the
+    reference configs use relu, config.py / model.py:16)."""
     if name == "relu":
         return 1
-    if name in ("gelu", "glu"):
-        raise NotImplementedError("activation %r: the fused GEMM epilogue implements relu (the "
-                                  "reference configs use relu, config.py / model.py:16)" % name)
+    if name == "gelu":
+        return 2
+    if name == "glu":
+        # F.glu halves the feature dimension, so the reference's own linear2 (num_feedforward inputs) cannot consume it:
+        # transformer.py:283 accepts the name, the forward fails in torch.  Say so up front.
+        raise NotImplementedError("activation 'glu' halves the feed-forward width: the reference's linear2 cannot consume it "
+                                  "either (transformer.py:283 accepts the name, its forward raises)")
     raise RuntimeError("activation should be relu/gelu, not %s." % name)
 
 
@@ -202,7 +210,10 @@ class TransformerEncoderLayer(nn.Module):
         return ops.add_pos(_rows(tensor), table, div, mod).view_as(tensor)
 
     def _ffn(self, y, residual):
-        h = ops.linear(y, self.linear1.weight, self.linear1.bias, act=_activation_code(self.activation_name))
+        act = _activation_code(self.activation_name)
+        h = ops.linear(y, self.linear1.weight, self.linear1.bias, act=1 if act == 1 else 0)
+        if act == 2:
+            ops.gelu_(h)
         return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=residual)
 
     def _prep(self, src, src_mask, src_key_padding_mask, pos):

@@ -59,6 +59,12 @@ int ff_profile_bytes(double* bytes_by_cat, int ncat);
 /* Mean event-pair interval [us] around an EMPTY kernel, `launches` of them queued back to back on `stream`: what the
  * event bracket adds per launch to the category times of ff_profile_end (bench.py reports times net of it). */
 int ff_profile_bracket_us(int launches, double* us_per_launch, ff_stream_t stream);
+/* Effective shader clock UNDER LOAD (measurement hook): launch() enqueues a one-wave kernel on `stream` -- a stream of its own,
+ * beside the kernels under test -- that reads the shader-clock counter (s_memtime) and the constant 100 MHz counter
+ * (s_memrealtime), sleeps `spin_us` and reads both again; read() waits for `stream` and returns shader cycles / wall time in
+ * GHz (and the measured interval).  The chip clocks to its power budget: this is the clock a roofline has to be priced at. */
+int ff_clock_probe_launch(double spin_us, ff_stream_t stream);
+int ff_clock_probe_read(double* ghz, double* measured_us, ff_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * G2  LayerNorm (+ positional add).  Replaces nn.LayerNorm followed by `with_pos_embed`
@@ -76,6 +82,10 @@ int ff_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
 /* out[r,:] = x[r,:] + pos[((r / pos_div) % pos_mod), :]   (`memory + pos`, transformer.py:249) */
 int ff_add_pos(const float* x, int ldx, const float* pos, int ldpos, int pos_div, int pos_mod,
                float* out, int ldout, int rows, int E, ff_stream_t stream);
+
+/* x[r, 0:E] = gelu(x[r, 0:E]) in place, exact erf form: 0.5 x (1 + erf(x / sqrt 2)) (torch F.gelu's default; the "gelu"
+ * activation of reference transformer.py:276-284 -- module surface only, no reference config uses it).  E % 4 == 0. */
+int ff_gelu(float* x, int ldx, int rows, int E, ff_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * G3  Dense projection on the f32 matrix cores (v_mfma_f32_32x32x2_f32).  Replaces F.linear /

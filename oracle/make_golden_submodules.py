@@ -40,6 +40,10 @@ CASES = {
                             mem_kpm=True, intermediate=False, seed=5),
     "enc_pre": dict(kind="encoder", pre=True, layers=2, S=13, B=3, kpm=True, seed=6),
     "enc_post": dict(kind="encoder", pre=False, layers=2, S=12, B=4, kpm=True, seed=7),
+    # activation="gelu" (transformer.py:276-284): a constructor keyword of the boundary that no reference config sets
+    "enc_pre_gelu": dict(kind="encoder", pre=True, layers=2, S=10, B=3, kpm=True, seed=14, act="gelu"),
+    "dec_post_gelu": dict(kind="decoder", pre=False, layers=1, t=4, B=3, S=9, causal=False, tgt_kpm=False,
+                          mem_kpm=True, intermediate=False, seed=15, act="gelu"),
     # DETR-style wrapper that neither model class instantiates (transformer.py:18-59)
     "transformer_post": dict(kind="transformer", pre=False, enc=1, dec=2, N=2, Hh=3, Ww=4, Q=5, intermediate=True,
                              seed=8),
@@ -108,10 +112,10 @@ def build(name, c, tr, emb, models, token):
     """The module under test, constructed through the PUBLIC constructors (works for the reference's modules and
     for faceformer_amd's: same signatures)."""
     if c["kind"] == "decoder":
-        layer = tr.TransformerDecoderLayer(E, H, FF, 0.1, "relu", c["pre"])
+        layer = tr.TransformerDecoderLayer(E, H, FF, 0.1, c.get("act", "relu"), c["pre"])
         return tr.TransformerDecoder(layer, c["layers"], torch.nn.LayerNorm(E), return_intermediate=c["intermediate"])
     if c["kind"] == "encoder":
-        layer = tr.TransformerEncoderLayer(E, H, FF, 0.1, "relu", c["pre"])
+        layer = tr.TransformerEncoderLayer(E, H, FF, 0.1, c.get("act", "relu"), c["pre"])
         return tr.TransformerEncoder(layer, c["layers"], torch.nn.LayerNorm(E) if c["pre"] else None)
     if c["kind"] == "transformer":
         return tr.Transformer(num_model=E, num_head=H, num_encoder_layers=c["enc"], num_decoder_layers=c["dec"],
@@ -158,10 +162,10 @@ def restate(name, c, sd, inp):
                                final_norm=True, return_intermediate=c["intermediate"], tgt_mask=inp.get("tgt_mask"),
                                tgt_key_padding_mask=inp.get("tgt_key_padding_mask"),
                                memory_key_padding_mask=inp.get("memory_key_padding_mask"), pos=inp["pos"],
-                               query_pos=inp["query_pos"])
+                               query_pos=inp["query_pos"], activation=c.get("act", "relu"))
     if c["kind"] == "encoder":
         return R.encoder_stack(sd, "", inp["src"], H, c["layers"], normalize_before=c["pre"], final_norm=c["pre"],
-                               src_key_padding_mask=inp["src_key_padding_mask"], pos=inp["pos"])
+                               src_key_padding_mask=inp["src_key_padding_mask"], pos=inp["pos"], activation=c.get("act", "relu"))
     if c["kind"] == "select_next":
         return R.select_next(inp["embedding"], inp["pointer"], inp["input_mask"])[0]
     return None

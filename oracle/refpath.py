@@ -69,13 +69,13 @@ def embed_edges(sd, coord, num_token):
     return torch.cat((token_embed, h), dim=1)
 
 
-def encoder_layer(sd, p, src, key_padding_mask, pos, num_head):
+def encoder_layer(sd, p, src, key_padding_mask, pos, num_head, act=F.relu):
     """reference transformer.py:164-176 (forward_pre)."""
     y = _ln(src, sd, p + ".norm1")
     q = k = y + pos
     src = src + _mha(q, k, y, sd, p + ".self_attn", num_head, key_padding_mask)
     y = _ln(src, sd, p + ".norm2")
-    y = F.linear(F.relu(F.linear(y, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+    y = F.linear(act(F.linear(y, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
     return src + y
 
@@ -103,19 +103,19 @@ def decoder_layer(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, n
     return tgt + y
 
 
-def encoder_layer_post(sd, p, src, key_padding_mask, pos, num_head):
+def encoder_layer_post(sd, p, src, key_padding_mask, pos, num_head, act=F.relu):
     """reference transformer.py:148-162 (forward_post; unused by the reference's configs, part of the module
     surface)."""
     q = k = src if pos is None else src + pos
     src = src + _mha(q, k, src, sd, p + ".self_attn", num_head, key_padding_mask)
     src = _ln(src, sd, p + ".norm1")
-    y = F.linear(F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+    y = F.linear(act(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
     return _ln(src + y, sd, p + ".norm2")
 
 
 def decoder_layer_post(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, num_head, tgt_mask=None,
-                       tgt_key_padding_mask=None):
+                       tgt_key_padding_mask=None, act=F.relu):
     """reference transformer.py:211-233 (forward_post)."""
     q = k = tgt if query_pos is None else tgt + query_pos
     tgt = tgt + _mha(q, k, tgt, sd, p + ".self_attn", num_head, tgt_key_padding_mask, tgt_mask)
@@ -123,13 +123,13 @@ def decoder_layer_post(sd, p, tgt, memory, memory_key_padding_mask, pos, query_p
     tgt = tgt + _mha(tgt if query_pos is None else tgt + query_pos, memory if pos is None else memory + pos, memory,
                      sd, p + ".multihead_attn", num_head, memory_key_padding_mask)
     tgt = _ln(tgt, sd, p + ".norm2")
-    y = F.linear(F.relu(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+    y = F.linear(act(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
     return _ln(tgt + y, sd, p + ".norm3")
 
 
 def decoder_layer_pre_kpm(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, num_head, tgt_mask=None,
-                          tgt_key_padding_mask=None):
+                          tgt_key_padding_mask=None, act=F.relu):
     """reference transformer.py:235-256 with EVERY keyword of the layer (the eval loop passes no tgt masks; the
     teacher-forced caller model_para.py:162-163 passes tgt_mask and tgt_key_padding_mask)."""
     y = _ln(tgt, sd, p + ".norm1")
@@ -139,21 +139,30 @@ def decoder_layer_pre_kpm(sd, p, tgt, memory, memory_key_padding_mask, pos, quer
     tgt = tgt + _mha(y if query_pos is None else y + query_pos, memory if pos is None else memory + pos, memory, sd,
                      p + ".multihead_attn", num_head, memory_key_padding_mask)
     y = _ln(tgt, sd, p + ".norm3")
-    y = F.linear(F.relu(F.linear(y, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+    y = F.linear(act(F.linear(y, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
     return tgt + y
 
 
+def _activation(name):
+    """reference transformer.py:276-284 (_get_activation_fn; "glu" halves the width and cannot feed linear2)."""
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    raise RuntimeError("activation should be relu/gelu, not %s." % name)
+
+
 def decoder_stack(sd, prefix, tgt, memory, num_head, num_layers, normalize_before=True, final_norm=True,
                   return_intermediate=False, tgt_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None,
-                  pos=None, query_pos=None):
+                  pos=None, query_pos=None, activation="relu"):
     """reference transformer.py:95-124 over a state_dict with keys `<prefix>layers.<i>.*`, `<prefix>norm.*`: both
     layer forms and the `return_intermediate` stack."""
     layer = decoder_layer_pre_kpm if normalize_before else decoder_layer_post
     out, inter = tgt, []
     for i in range(num_layers):
         out = layer(sd, "%slayers.%d" % (prefix, i), out, memory, memory_key_padding_mask, pos, query_pos, num_head,
-                    tgt_mask, tgt_key_padding_mask)
+                    tgt_mask, tgt_key_padding_mask, _activation(activation))
         if return_intermediate:
             inter.append(_ln(out, sd, prefix + "norm"))
     if final_norm:
@@ -164,15 +173,15 @@ def decoder_stack(sd, prefix, tgt, memory, num_head, num_layers, normalize_befor
 
 
 def encoder_stack(sd, prefix, src, num_head, num_layers, normalize_before=True, final_norm=True,
-                  src_key_padding_mask=None, pos=None):
+                  src_key_padding_mask=None, pos=None, activation="relu"):
     """reference transformer.py:70-83 with either layer form."""
     out = src
     for i in range(num_layers):
         p = "%slayers.%d" % (prefix, i)
         if normalize_before:
-            out = encoder_layer(sd, p, out, src_key_padding_mask, 0 if pos is None else pos, num_head)
+            out = encoder_layer(sd, p, out, src_key_padding_mask, 0 if pos is None else pos, num_head, _activation(activation))
         else:
-            out = encoder_layer_post(sd, p, out, src_key_padding_mask, pos, num_head)
+            out = encoder_layer_post(sd, p, out, src_key_padding_mask, pos, num_head, _activation(activation))
     return _ln(out, sd, prefix + "norm") if final_norm else out
 
 

@@ -35,6 +35,33 @@ def rel_err(got, want):
     return float((got.double().cpu() - want).abs().max() / (want.abs().max() + 1e-30))
 
 
+# ---- GELU (module surface: activation="gelu", reference transformer.py:276-284) ----------------------
+@pytest.mark.parametrize("rows,E,ld", [(1, 256, 256), (37, 1024, 1024), (1000, 256, 320), (3, 4, 8)])
+def test_gelu_rows_match_fp64_erf_form(hip_lib, ops, rows, E, ld):
+    """x <- 0.5 x (1 + erf(x / sqrt 2)) in place on the first E columns of rows with leading dimension ld (torch F.gelu's
+    default form) against fp64; columns beyond E stay untouched."""
+    buf = rnd(rows, ld, seed=3, scale=2.5).cuda()
+    before = buf.clone()
+    view = buf[:, :E]
+    out = ops.gelu_(view)
+    assert out.data_ptr() == view.data_ptr()
+    want = F.gelu(before[:, :E].double().cpu())
+    assert float((buf[:, :E].double().cpu() - want).abs().max()) < 4e-7 * max(1.0, float(want.abs().max()))
+    assert torch.equal(buf[:, E:], before[:, E:])
+
+
+def test_head_width_other_than_64_is_a_clear_error(hip_lib, ops):
+    """num_model / num_head != 64 (a constructor choice of the boundary, reference transformer.py:132): the module says what it
+    supports instead of failing inside a kernel."""
+    from faceformer_amd.hip.lib import HipExtensionError
+    from faceformer_amd.transformer import TransformerEncoderLayer
+    layer = TransformerEncoderLayer(128, 4, 256, 0.1, "relu", True).eval().cuda()     # heads of 32
+    with pytest.raises(HipExtensionError, match="head width 64"):
+        layer(torch.zeros(5, 2, 128, device="cuda"))
+    with pytest.raises(NotImplementedError, match="glu"):
+        TransformerEncoderLayer(128, 2, 256, 0.1, "glu", True).eval().cuda()(torch.zeros(5, 2, 128, device="cuda"))
+
+
 # ---- LayerNorm -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rows,E", [(1, 512), (37, 512), (1000, 512), (130, 128), (5, 64), (9, 1024), (3, 2048)])
 def test_layernorm_pos(ops, rows, E):

@@ -1,0 +1,155 @@
+"""Effective shader clock UNDER LOAD of the path's dominant kernels, with the board's own power / clock read-outs beside it:
+    python tools/effective_clock.py > profiles/r05/effective_clock.md          (run on the GPU box)
+
+For each kernel (3 x bf16 split projection at an asymptotic and a config-B-sized shape, the f32 LDS-DMA projection, the
+K/V-resident cross-attention kernel) and each operand fill (random / zeros: the chip clocks to its POWER budget, and zero
+operands toggle no matrix-core data lines), the launches run back to back for ~2 s on torch's stream while
+  * a one-wave probe kernel on a SECOND stream (ff_clock_probe_launch: s_memtime cycles / s_memrealtime wall time) measures
+    the clock the SIMDs actually ran at during the middle of that loop, and
+  * a host thread samples `rocm-smi --showpower --showclocks` (or amd-smi) every ~100 ms.
+Printed per row: TF/s (fp32-equivalent flops / wall), effective GHz of the probe, the rate re-priced at that clock
+(fraction of peak x 2.4 / GHz), board power [W] and the sclk the SMI tool reports (min / mean / max of the samples).
+"""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from faceformer_amd.hip import lib as L  # noqa: E402
+from faceformer_amd.hip import ops  # noqa: E402
+
+NOMINAL_GHZ = 2.4
+PEAK_F32 = 157.3
+PEAK_X3 = 2500.0 / 6.0
+
+
+class Smi(threading.Thread):
+    """Samples board power and sclk while `running`."""
+
+    def __init__(self):
+        super().__init__(daemon=True)
+        self.running = True
+        self.power, self.sclk = [], []
+        self.tool = None
+        for cand in ("/opt/rocm/bin/rocm-smi", "rocm-smi"):
+            try:
+                subprocess.run([cand, "--version"], capture_output=True, timeout=20)
+                self.tool = cand
+                break
+            except (OSError, subprocess.TimeoutExpired):
+                continue
+
+    def sample(self):
+        if not self.tool:
+            return
+        try:
+            cp = subprocess.run([self.tool, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10)
+            d = json.loads(cp.stdout)
+        except (OSError, subprocess.TimeoutExpired, ValueError):
+            return
+        card = d.get("card0") or (list(d.values())[0] if d else {})
+        for k, v in card.items():
+            kl = k.lower()
+            try:
+                if "power" in kl and "(w)" in kl:
+                    self.power.append(float(v))
+                elif kl.startswith("sclk clock speed") or kl.startswith("sclk"):
+                    self.sclk.append(float(str(v).strip("()").lower().replace("mhz", "")))
+            except ValueError:
+                pass
+
+    def run(self):
+        while self.running:
+            self.sample()
+            time.sleep(0.05)
+
+
+def mmm(v):
+    return "%.0f / %.0f / %.0f" % (min(v), sum(v) / len(v), max(v)) if v else "n/a"
+
+
+def run_case(name, fn, flops, peak, seconds=2.0):
+    lib = L.load()
+    side = torch.cuda.Stream()
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-6)
+    iters = max(8, int(seconds / one))
+    smi = Smi()
+    smi.start()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    launched = False
+    for i in range(iters):
+        fn()
+        if not launched and i >= iters // 4:      # the probe covers the middle half of the loop
+            L.check(lib.ff_clock_probe_launch(ctypes.c_double(0.5 * seconds * 1e6), side.cuda_stream), "ff_clock_probe_launch")
+            launched = True
+    ev1.record()
+    torch.cuda.synchronize()
+    smi.running = False
+    smi.join(timeout=15)
+    ghz, us = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    L.check(lib.ff_clock_probe_read(ctypes.byref(ghz), ctypes.byref(us), side.cuda_stream), "ff_clock_probe_read")
+    sec = ev0.elapsed_time(ev1) * 1e-3
+    tf = flops * iters / sec / 1e12
+    frac = tf / peak
+    print("| %s | %d | %.1f | %.3f | %.3f | %.3f | %s | %s |" % (
+        name, iters, tf, frac, ghz.value, frac * NOMINAL_GHZ / ghz.value if ghz.value > 0 else float("nan"), mmm(smi.power), mmm(smi.sclk)))
+    sys.stdout.flush()
+
+
+def main():
+    dev = "cuda"
+    lib = L.load()
+    # idle clock first (nothing else queued)
+    side = torch.cuda.Stream()
+    L.check(lib.ff_clock_probe_launch(ctypes.c_double(2e5), side.cuda_stream), "ff_clock_probe_launch")
+    g, u = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    L.check(lib.ff_clock_probe_read(ctypes.byref(g), ctypes.byref(u), side.cuda_stream), "ff_clock_probe_read")
+    print("# Effective shader clock under load (tools/effective_clock.py; probe = s_memtime cycles / s_memrealtime wall time of one")
+    print("# wave on a second stream during the middle half of a ~2 s launch loop; nominal %.1f GHz)" % NOMINAL_GHZ)
+    print()
+    print("idle probe (no other work queued): %.3f GHz over %.0f us" % (g.value, u.value))
+    print()
+    print("| kernel, shape, operands | launches | TF/s (fp32-eq) | frac of peak @2.4 GHz | effective GHz | frac of peak @effective clock | board power W (min / mean / max) | SMI sclk MHz (min / mean / max) |")
+    print("|---|---|---|---|---|---|---|---|")
+    for fill in ("random", "zeros"):
+        for M, K, N in ((16384, 512, 1536), (4608, 512, 1536), (9216, 1024, 512)):
+            a = torch.randn(M, K, device=dev)
+            w = torch.randn(N, K, device=dev) * 0.05
+            b = torch.randn(N, device=dev)
+            if fill == "zeros":
+                a.zero_(); w.zero_(); b.zero_()
+            out = torch.empty(M, N, device=dev)
+            planes = ops.split_weight(w)
+            run_case("gemm_x3_kernel %dx%d->%d %s" % (M, K, N, fill),
+                     lambda: ops.linear_x3(a, planes, b, out=out), 2.0 * M * N * K, PEAK_X3)
+            if (M, K, N) != (4608, 512, 1536):
+                run_case("gemm_dma_f32_kernel %dx%d->%d %s" % (M, K, N, fill),
+                         lambda: ops.linear(a, w, b, out=out, tile=7), 2.0 * M * N * K, PEAK_F32)
+            del a, w, b, out, planes
+        # K/V-resident cross-attention of config B at t = 36: 256 sequences x 36 positions on S = 260 keys, 8 heads of 64
+        F_, t, S, H, E = 256, 36, 260, 8, 512
+        q = torch.randn(t * F_, E, device=dev)
+        kv = torch.randn(S, 2 * E, device=dev)
+        if fill == "zeros":
+            q.zero_(); kv.zero_()
+        kvl = torch.tensor([S], device=dev, dtype=torch.int32)
+        run_case("attention_resident_kernel F=256 t=36 S=260 %s" % fill,
+                 lambda: ops.attention(q, kv[:, :E], kv[:, E:], num_groups=1, num_heads=H, nq=F_ * t, nk=S, q_group_stride=F_,
+                                       q_inner=F_, q_outer_stride=F_, k_group_stride=S, k_stride=1, kv_len=kvl, scale=0.125),
+                 4.0 * F_ * t * S * E, PEAK_F32)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,14 @@ def section(d, suffix, title):
         n, us = avg[k]
         busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (us * 2400.0 * 1024.0)
         wait = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else float("nan")
-        print("%-36s launches %5d avg %7.2f us  MFMA-busy %.3f  wait_inst/wave_cycles %.2f" % (k, n, us, busy, wait))
+        line = "%-36s launches %5d avg %7.2f us  MFMA-busy %.3f  wait_inst/wave_cycles %.2f" % (k, n, us, busy, wait)
+        # effective clock of the PROFILED pass: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the dispatch duration under that
+        # pass (pmc_per_kernel.py's DURATION_NS rows); MFMA-busy re-priced at that clock = busy cycles / (duration x GHz x SIMDs)
+        if c.get("GRBM_GUI_ACTIVE") and c.get("DURATION_NS"):
+            ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / c["DURATION_NS"]
+            busy_eff = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["DURATION_NS"] * ghz * 1024.0)
+            line += "  | profiled pass: %.2f us, GRBM clock %.2f GHz, MFMA-busy at that clock %.3f" % (c["DURATION_NS"] / 1e3, ghz, busy_eff)
+        print(line)
 
 
 if __name__ == "__main__":
