@@ -6,7 +6,7 @@ K/V-resident cross-attention kernel) and each operand fill (random / zeros: the 
 operands toggle no matrix-core data lines), the launches run back to back for ~2 s on torch's stream while
   * a one-wave probe kernel on a SECOND stream (ff_clock_probe_launch: s_memtime cycles / s_memrealtime wall time) measures
     the clock the SIMDs actually ran at during the middle of that loop, and
-  * a host thread samples `rocm-smi --showpower --showclocks` (or amd-smi) every ~100 ms.
+  * a child process samples `rocm-smi --showpower --showclocks --json` every ~100 ms.
 Printed per row: TF/s (fp32-equivalent flops / wall), effective GHz of the probe, the rate re-priced at that clock
 (fraction of peak x 2.4 / GHz), board power [W] and the sclk the SMI tool reports (min / mean / max of the samples).
 """
@@ -15,7 +15,6 @@ import json
 import os
 import subprocess
 import sys
-import threading
 import time
 
 import torch
@@ -29,12 +28,11 @@ PEAK_F32 = 157.3
 PEAK_X3 = 2500.0 / 6.0
 
 
-class Smi(threading.Thread):
-    """Samples board power and sclk while `running`."""
+class Smi:
+    """Samples board power and sclk in a CHILD PROCESS (a shell loop around rocm-smi writing JSON lines to a file): a sampler
+    thread of this interpreter would share the GIL with the launch loop and slow the launches it is meant to observe."""
 
     def __init__(self):
-        super().__init__(daemon=True)
-        self.running = True
         self.power, self.sclk = [], []
         self.tool = None
         for cand in ("/opt/rocm/bin/rocm-smi", "rocm-smi"):
@@ -44,30 +42,43 @@ class Smi(threading.Thread):
                 break
             except (OSError, subprocess.TimeoutExpired):
                 continue
+        self.path = "/tmp/ff_smi_%d.jsonl" % os.getpid()
+        self.proc = None
 
-    def sample(self):
+    def start(self):
         if not self.tool:
             return
-        try:
-            cp = subprocess.run([self.tool, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10)
-            d = json.loads(cp.stdout)
-        except (OSError, subprocess.TimeoutExpired, ValueError):
-            return
-        card = d.get("card0") or (list(d.values())[0] if d else {})
-        for k, v in card.items():
-            kl = k.lower()
-            try:
-                if "power" in kl and "(w)" in kl:
-                    self.power.append(float(v))
-                elif kl.startswith("sclk clock speed") or kl.startswith("sclk"):
-                    self.sclk.append(float(str(v).strip("()").lower().replace("mhz", "")))
-            except ValueError:
-                pass
+        open(self.path, "w").close()
+        self.proc = subprocess.Popen(["bash", "-c", "while true; do %s --showpower --showclocks --json >> %s 2>/dev/null; echo >> %s; "
+                                      "sleep 0.05; done" % (self.tool, self.path, self.path)])
 
-    def run(self):
-        while self.running:
-            self.sample()
-            time.sleep(0.05)
+    def stop(self):
+        if self.proc is None:
+            return
+        self.proc.terminate()
+        try:
+            self.proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            self.proc.kill()
+        for line in open(self.path):
+            line = line.strip()
+            if not line.startswith("{"):
+                continue
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            card = d.get("card0") or (list(d.values())[0] if d else {})
+            for k, v in card.items():
+                kl = k.lower()
+                try:
+                    if "power" in kl and "(w)" in kl:
+                        self.power.append(float(v))
+                    elif kl.startswith("sclk clock speed"):
+                        self.sclk.append(float(str(v).strip("()").lower().replace("mhz", "")))
+                except ValueError:
+                    pass
+        os.remove(self.path)
 
 
 def mmm(v):
@@ -96,8 +107,7 @@ def run_case(name, fn, flops, peak, seconds=2.0):
             launched = True
     ev1.record()
     torch.cuda.synchronize()
-    smi.running = False
-    smi.join(timeout=15)
+    smi.stop()
     ghz, us = ctypes.c_double(0.0), ctypes.c_double(0.0)
     L.check(lib.ff_clock_probe_read(ctypes.byref(ghz), ctypes.byref(us), side.cuda_stream), "ff_clock_probe_read")
     sec = ev0.elapsed_time(ev1) * 1e-3
@@ -132,11 +142,15 @@ def main():
                 a.zero_(); w.zero_(); b.zero_()
             out = torch.empty(M, N, device=dev)
             planes = ops.split_weight(w)
+            st = torch.cuda.current_stream().cuda_stream
+            pa, pw, pb, po, pp = a.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), planes.data_ptr()
+            # (prebuilt arguments, straight ctypes calls: a few microseconds of host time per launch, so that the 26-us launches
+            # of the config-B-sized shape stay GPU-bound)
             run_case("gemm_x3_kernel %dx%d->%d %s" % (M, K, N, fill),
-                     lambda: ops.linear_x3(a, planes, b, out=out), 2.0 * M * N * K, PEAK_X3)
+                     lambda: lib.ff_gemm_x3(pa, K, None, 0, pp, pb, None, 0, po, N, M, N, K, 0, st), 2.0 * M * N * K, PEAK_X3)
             if (M, K, N) != (4608, 512, 1536):
                 run_case("gemm_dma_f32_kernel %dx%d->%d %s" % (M, K, N, fill),
-                         lambda: ops.linear(a, w, b, out=out, tile=7), 2.0 * M * N * K, PEAK_F32)
+                         lambda: lib.ff_gemm_f32(pa, K, None, 0, pw, K, pb, None, 0, po, N, M, N, K, 0, 11, st), 2.0 * M * N * K, PEAK_F32)
             del a, w, b, out, planes
         # K/V-resident cross-attention of config B at t = 36: 256 sequences x 36 positions on S = 260 keys, 8 heads of 64
         F_, t, S, H, E = 256, 36, 260, 8, 512

@@ -16,7 +16,9 @@ from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_sp
 CASES = (("seq2seq.yml", 64), ("seq2seq+coedge.yml", 216))
 BATCHES = tuple(int(v) for v in os.environ.get("FF_SEQ_BATCHES", "1,8,64").split(","))
 if os.environ.get("FF_SEQ_ONLY_A"):   # kernel-trace runs: config A, one wireframe per call
-    CASES, BATCHES = CASES[:1], (1,)
+    CASES = CASES[:1]
+    if "FF_SEQ_BATCHES" not in os.environ:
+        BATCHES = (1,)
 for cfgfile, n in CASES:
     cfg = load_cfg(os.path.join(ROOT, "configs", cfgfile))
     L, T = cfg.model.num_lines, cfg.model.label_seq_length
