@@ -704,11 +704,11 @@ def main():
 
     cpu_thread = None
     if rank == 0 and not multi and not args.no_cpu_baseline:
-        # The oracle runs in a child process with a hard wall-clock cap.  Threads: SURVEY 8(d) says all physical cores, but
+        # The oracle runs in child processes with hard wall-clock caps.  Threads: SURVEY 8(d) says all physical cores, but
         # torch's CPU eager path gets SLOWER beyond ~32 threads for these operator sizes (measured on the MI355X host:
-        # 256 threads 1.4 edges/s, 64 threads 133, 32 threads 165-245).  So the run first times a 32-anchor sample at
-        # 32 threads and at all physical cores (`threads_sweep`), then runs the FULL wireframe at the faster setting;
-        # `cores` reports what the full run actually used.
+        # 256 threads 1.4 edges/s, 64 threads 133, 32 threads 165-245; 128 threads: no result within 3 x the 32-thread time
+        # in every run of round 5).  The FULL wireframe runs at min(physical cores, 32) threads (`cores`); a 16-anchor
+        # sample is timed at that setting and at all physical cores afterwards (`threads_sweep`).
         import subprocess
         n_cpu = n_local[0] if not cfgE else min(n_local)      # config E: the smallest wireframe of the shard
         seed_cpu = seeds[0] if not cfgE else seeds[n_local.index(n_cpu)]
@@ -757,32 +757,11 @@ def main():
         cpu_raw = {"sweep": {}, "tried": [], "rec": None, "k": None, "threads": threads, "rec_a": None}
 
         def cpu_job():
-            """Every CPU child of the run, one after the other (never two at once), on a host thread BESIDE the GPU measurements
-            of `other_configs` (the headline, the package-default line and their profiled passes are finished by then; the
-            children use <= `phys` of the host's cores, the GPU process one)."""
+            """The FULL wireframe (and config A's sizes) on a host thread BESIDE the GPU measurement of `other_configs.C128`
+            only: C128 is GPU-bound (5.6 s per pass, unchanged beside 32 busy host threads), the launch-bound entries are not
+            (profiles/r05: D 111.7 -> 133.2 ms beside 32 threads, E32 1318 -> 1788 ms beside the 128-thread sweep child), so
+            they run first and the thread sweep runs after everything else, alone."""
             th_full = cpu_raw["threads"]
-            if args.cpu_threads <= 0 and phys > th_full and not args.cpu_anchors:
-                ks = max(1, min(32, n_cpu))
-                t_first = None
-                for th in (th_full, phys):
-                    # the second setting gets 3 x the time the first one took: slower than that it cannot win
-                    cap = 60 if t_first is None else max(10, int(3 * t_first) + 5)
-                    t0_ = time.perf_counter()
-                    try:
-                        r_ = run_cpu_child(child_code(ks, th), cap, th)
-                        pr_ = torch.tensor(r_["predict"], dtype=torch.int64)
-                        st_ = int((pr_[:, 1:] != 0).any(dim=0).nonzero().max().item()) + 1
-                        cpu_raw["sweep"][str(th)] = ks * st_ / r_["t"]
-                        if t_first is None:
-                            t_first = time.perf_counter() - t0_
-                    except (subprocess.TimeoutExpired, ValueError, IndexError):
-                        cpu_raw["sweep"][str(th)] = "no result within %d s" % cap
-                        if t_first is None:
-                            t_first = time.perf_counter() - t0_
-                ok = [(v, int(k_)) for k_, v in cpu_raw["sweep"].items() if isinstance(v, float)]
-                if ok:
-                    th_full = max(ok)[1]
-            cpu_raw["threads"] = th_full
             for k in ([args.cpu_anchors] if args.cpu_anchors > 0 else [n_cpu, 32]):
                 k = max(1, min(k, n_cpu))
                 try:
@@ -797,12 +776,32 @@ def main():
                 except (subprocess.TimeoutExpired, ValueError, IndexError):
                     pass
 
+        def cpu_sweep():
+            """SURVEY 8(d) says all physical cores; torch's CPU eager path is slower beyond ~32 threads for these operator
+            sizes.  The first 16 anchor sequences at 32 threads and at all physical cores, alone on the host (after every GPU
+            measurement); the second setting gets 3 x the time of the first -- slower than that it cannot win."""
+            if not (args.cpu_threads <= 0 and phys > cpu_raw["threads"] and not args.cpu_anchors):
+                return
+            ks = max(1, min(16, n_cpu))
+            t_first = None
+            for th in (cpu_raw["threads"], phys):
+                cap = 60 if t_first is None else max(8, int(3 * t_first) + 4)
+                t0_ = time.perf_counter()
+                try:
+                    r_ = run_cpu_child(child_code(ks, th), cap, th)
+                    pr_ = torch.tensor(r_["predict"], dtype=torch.int64)
+                    st_ = int((pr_[:, 1:] != 0).any(dim=0).nonzero().max().item()) + 1
+                    cpu_raw["sweep"][str(th)] = ks * st_ / r_["t"]
+                except (subprocess.TimeoutExpired, ValueError, IndexError):
+                    cpu_raw["sweep"][str(th)] = "no result within %d s" % cap
+                if t_first is None:
+                    t_first = time.perf_counter() - t0_
+
         import threading
         cpu_thread = threading.Thread(target=cpu_job, name="cpu-baseline", daemon=True)
 
     def start_cpu():
-        # beside the GPU-bound entries (C128 / E32) only: the launch-bound one-wireframe seq2seq entries lose 10-20 % when 32
-        # host threads compete with the launching thread (profiles/r05/bench_line_first.json: D 111.7 -> 133.2 ms)
+        # beside the GPU-bound entry (C128) only -- see cpu_job
         if cpu_thread is not None and not cpu_thread.is_alive() and cpu_thread.ident is None:
             cpu_thread.start()
 
@@ -923,14 +922,6 @@ def main():
                 other[name + "64"] = e64
                 del b64
             del m1
-        start_cpu()
-        # C128: config 3's per-GPU share on this GPU (the model of the main line, a batch of 128 wireframes)
-        if "C128" in want:
-            bC = to_dev(make_wireframes([args.edges] * 128, L_lines, T, "parallel", seeds=list(range(128))))
-            par_entry("C128", model, bC, [args.edges] * 128, T,
-                      "BASELINE config 3's per-GPU share: 128 synthetic %d-edge wireframes in one call (configs/ours.yml, "
-                      "model.num_lines=%d), micro-batches of %d wireframes, default-xavier weights" % (args.edges, L_lines, args.chunk))
-            del bC
         # E32: config 5's per-GPU share
         if "E32" in want:
             mE, cE, TE = parallel_model("ours-perspective.yml", 1024)
@@ -943,11 +934,20 @@ def main():
             other["E32"]["decoded_sequences"] = (getattr(mE, "last_decode_stats", None) or {}).get("decoded_seqs")
             del mE, bE
 
+        start_cpu()
+        # C128: config 3's per-GPU share on this GPU (the model of the main line, a batch of 128 wireframes)
+        if "C128" in want:
+            bC = to_dev(make_wireframes([args.edges] * 128, L_lines, T, "parallel", seeds=list(range(128))))
+            par_entry("C128", model, bC, [args.edges] * 128, T,
+                      "BASELINE config 3's per-GPU share: 128 synthetic %d-edge wireframes in one call (configs/ours.yml, "
+                      "model.num_lines=%d), micro-batches of %d wireframes, default-xavier weights" % (args.edges, L_lines, args.chunk))
+            del bC
         result["other_configs"] = other
 
     if cpu_thread is not None:
         start_cpu()
         cpu_thread.join()
+        cpu_sweep()
         wf_local = local[seeds.index(seed_cpu)]
         tried, sweep, rec, k, threads = cpu_raw["tried"], cpu_raw["sweep"], cpu_raw["rec"], cpu_raw["k"], cpu_raw["threads"]
         if rec is not None:
@@ -977,7 +977,7 @@ def main():
                           "fp32; %d threads on %d physical cores / %d hardware threads): %.1f s%s"
                           % (what, n_cpu, ref_steps, torch.__version__, threads, phys, os.cpu_count() or 1, tc,
                              ("; earlier attempts: " + "; ".join(tried)) if tried else ""),
-                "threads_sweep": {"sample": "first 32 anchor sequences, edges/s by thread count", **sweep} if sweep else None,
+                "threads_sweep": {"sample": "first 16 anchor sequences, edges/s by thread count, alone on the host", **sweep} if sweep else None,
                 "parallel_info": pinfo, "tokens_identical_to_gpu": same, "sequences_identical_to_gpu": seq_same,
                 "divergent_sequences": len(div),
                 "first_divergence": div[0] if div else None,
