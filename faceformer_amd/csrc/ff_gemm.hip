@@ -794,6 +794,11 @@ struct StreamK {
   unsigned int* flags;         // [grid]: 1 = slot holds a partial tile
   int upt;                     // units per tile = K / 64
   int base, rem;               // block lb owns base + (lb < rem) units
+  // HYBRID launch (nA > 0; round 5): the first nA blocks take tilesA WHOLE tiles each (no exchange at all) and the units of the
+  // remaining tiles -- less than one tile per CU -- are dealt in equal ranges to the other gridDim.x - nA blocks, which run as
+  // the SECOND resident block of the CUs: a launch of 1.125 tiles per CU (t = 9: 288 tiles of the 512-column projections) costs
+  // the CU 8 + 1 units instead of 9 + the exchange of EVERY tile (unit ranges) or 16 (whole-tile rounds).
+  int nA, tilesA, uA;          // uA = nA * tilesA * upt: first unit of the dealt region
 };
 
 template <int MODE>  // as gemm_persist_kernel
@@ -810,11 +815,20 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
   const int tiles_mn = g.tiles_m * g.tiles_n;
 
   // logical block index: the blocks of one XCD (blockIdx % 8) own neighbouring unit ranges
-  const int G = gridDim.x;
-  const int lb = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int upt = sk.upt;
-  const int u0 = lb * sk.base + (lb < sk.rem ? lb : sk.rem);
-  const int u1 = u0 + sk.base + (lb < sk.rem ? 1 : 0);
+  int lb, u0, u1;      // lb: index among the blocks that share unit ranges (slot of the partial-tile workspace)
+  if ((int)blockIdx.x < sk.nA) {          // hybrid launch, whole-tile block (block-uniform branch)
+    const int GA = sk.nA;
+    const int la = ((GA & 7) == 0) ? (blockIdx.x & 7) * (GA >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    lb = 0;
+    u0 = la * sk.tilesA * upt;
+    u1 = u0 + sk.tilesA * upt;
+  } else {
+    const int bb = blockIdx.x - sk.nA, G = gridDim.x - sk.nA;
+    lb = ((G & 7) == 0) ? (bb & 7) * (G >> 3) + (bb >> 3) : bb;
+    u0 = sk.uA + lb * sk.base + (lb < sk.rem ? lb : sk.rem);
+    u1 = u0 + sk.base + (lb < sk.rem ? 1 : 0);
+  }
   if (u0 >= u1) return;
   FF_EXP_SKSTAMP(0);
   const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
@@ -977,7 +991,7 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
       return;
     }
     if (cp_kind == 2) {  // add the partials of the blocks that hold units [k0 * upt, u0) of this tile
-      const int ub = k0 * upt;
+      const int ub = k0 * upt - sk.uA;   // (position inside the dealt region; whole-tile blocks never get here)
       const int big = sk.rem * (sk.base + 1);
       const int c0 = ub < big ? ub / (sk.base + 1) : sk.rem + (ub - big) / sk.base;
       for (int c = c0; c < lb; ++c) {
@@ -1441,6 +1455,31 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   const long cus = SK_MAX_GRID / 2;
   const double whole_cost = (double)((tiles + cus - 1) / cus) * sk.upt;
   const double split_cost = (double)units / cus + g_sk_fix_units;
+  sk.nA = 0; sk.tilesA = 0; sk.uA = 0;
+  // Hybrid (see StreamK): hw whole tiles per CU + the units of the remaining tiles dealt to a second block per CU.
+  static const int hyb_on = getenv("FF_SK_HYBRID") ? atoi(getenv("FF_SK_HYBRID")) : 1;               // (A/B knob)
+  static const double hyb_fix = getenv("FF_SK_HYBRID_FIX") ? 0.1 * atoi(getenv("FF_SK_HYBRID_FIX")) : 1.0;
+  const long hw = tiles / cus, left = tiles % cus;
+  // ... when at most half a round of tiles is left over: measured (profiles/r05/gemm_hybrid_ab.txt, 256 t rows) +15-26 % on the
+  // 512-column projections at t = 9 / 10, +8-12 % at t = 12, -2...-4 % at t = 14 (0.75 rounds left: unit ranges stay).
+  if (mode == 0 && hyb_on && hw >= 1 && left > 0 && 2 * left <= cus) {
+    const long left_units = left * sk.upt;
+    long gb = left_units / g_sk_min_units;
+    if (gb > cus) gb = cus;
+    if (gb < 1) gb = 1;
+    const double hybrid_cost = (double)hw * sk.upt + (double)((left_units + gb - 1) / gb) + hyb_fix;
+    if (hybrid_cost < whole_cost && hybrid_cost < split_cost) {
+      sk.nA = (int)cus; sk.tilesA = (int)hw; sk.uA = (int)(cus * hw * sk.upt);
+      sk.base = (int)(left_units / gb);
+      sk.rem = (int)(left_units % gb);
+      FF_RETURN_IF(sk_acquire(st, &sk));
+      const int lmh = gemm_mode(g);
+      const int gridh = (int)(cus + gb);
+      if (lmh == 1) return launch_streamk_mode<1>(g, sk, gridh, st);
+      if (lmh == 2) return launch_streamk_mode<2>(g, sk, gridh, st);
+      return launch_streamk_mode<0>(g, sk, gridh, st);
+    }
+  }
   if (mode == 0 && whole_cost <= split_cost) return launch_persist(g, batch, st);
   long grid;
   if (units >= g_sk_two_per_cu) grid = SK_MAX_GRID;

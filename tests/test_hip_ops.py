@@ -170,6 +170,30 @@ def test_gemm_split_a_and_inplace_residual(ops, tile, M):
     assert rel_err(x, ref2) < 3e-6
 
 
+@pytest.mark.parametrize("M", [2304, 2560, 3072, 3840, 2100, 3333])
+@pytest.mark.parametrize("N,K", [(512, 512), (1024, 512), (1536, 512), (512, 1024), (260, 512)])
+def test_gemm_hybrid_streamk_launch(ops, M, N, K):
+    """Round 5: the hybrid launch of the 64x64 family (automatic choice, tile 0): whole tiles on the first 256 blocks, the units
+    of the remaining tiles (less than one per CU) dealt to a second block per CU, cut tiles summed in block order.  The decode's
+    own shapes at t = 9 ... 15 (256 t rows) and ragged ones; bias / ReLU / aliased residual; split A; twice the same launch
+    bit-identical; the plain whole-tile kernel (tile 3) as a second reference for the summation order's error class."""
+    a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = torch.relu(a.double() @ w.double().t() + bias.double()) + res.double()
+    x = res.cuda()
+    ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=x, out=x)
+    assert rel_err(x, ref) < 3e-6
+    y = res.cuda()
+    ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=y, out=y)
+    assert torch.equal(x, y)
+    z = ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=res.cuda(), tile=3)
+    assert rel_err(z, ref) < 3e-6
+    if N % 128 == 0:   # q | k from one operand, v from another (the decoder's q|k|v projection)
+        a2 = rnd(M, K, seed=9)
+        out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), x2=a2.cuda(), n_split=N // 2)
+        want = torch.cat([a.double() @ w.double()[: N // 2].t(), a2.double() @ w.double()[N // 2:].t()], dim=1) + bias.double()
+        assert rel_err(out, want) < 3e-6
+
+
 @pytest.mark.parametrize("min_units,two_per_cu", [(1, 1), (1, 1 << 30), (2, 2048), (3, 100), (7, 5000)])
 @pytest.mark.parametrize("M,N,K,batch", [(256, 512, 512, 1), (64, 64, 512, 1), (2304, 512, 512, 1),
                                          (1100, 1536, 512, 1), (4400, 512, 1024, 1), (200, 260, 512, 3),
