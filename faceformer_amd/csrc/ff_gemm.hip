@@ -1523,6 +1523,13 @@ namespace {
 // forms +6-12 % from ~9 k rows, equal around 4-6 k, slower below; config B 59.9 -> 59.4 ms, 128 wireframes per call 206 -> 214 k/s
 // (with the LayerNorms folded at every size, which the 128x64 kernel could not).
 const long g_dma_min_rows = getenv("FF_DMA_MIN_ROWS") ? atol(getenv("FF_DMA_MIN_ROWS")) : 4096;
+// ... and for the 512-column projections (out-proj, cross-q, linear2): 64 x 128 tiles give them only 4 tile columns, and since the
+// 64x64 family has the hybrid launch (round 5) it is 3-14 % faster on them up to ~7.5 k rows (profiles/r05/gemm_families_4k_9k.txt:
+// LayerNorm-folded forms, 4096 ... 6400 rows), equal at 7680, slower from 8448.
+const long g_dma_min_rows_n512 = getenv("FF_DMA_MIN_ROWS_N512") ? atol(getenv("FF_DMA_MIN_ROWS_N512")) : 7680;
+// ... and for the 1536-column q|k|v projection (12 tile columns): its LayerNorm-folded form wins from ~2.5 k rows on (same file:
+// 89.7 / 91.4 / 91.0 / 94.4 against 79.5 / 79.7 / 81.6 / 85.4 TF/s at 2816 / 3072 / 3584 / 3840 rows, equal at 2304 / 2560 / 3328).
+const long g_dma_min_rows_wide = getenv("FF_DMA_MIN_ROWS_WIDE") ? atol(getenv("FF_DMA_MIN_ROWS_WIDE")) : 2560;
 int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
   const bool split128 = !g.A2 || (g.n_split % 128) == 0;
   if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
@@ -1536,7 +1543,9 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
     FF_CHECK_ARG(dma_ok, "ff_gemm_f32: tile 11 needs K %% 32 == 0, K >= 64, N %% 4 == 0, leading dimensions %% 4, 16-byte aligned operands, batch 1");
     return ff_gemm_dma_f32(g, st);
   }
-  if (tile == 7 && dma_ok && (long)M >= g_dma_min_rows) return ff_gemm_dma_f32(g, st);
+  const long dma_from = N <= 512 ? (g_dma_min_rows_n512 > g_dma_min_rows ? g_dma_min_rows_n512 : g_dma_min_rows)
+                                 : (N >= 1536 && g_dma_min_rows_wide < g_dma_min_rows ? g_dma_min_rows_wide : g_dma_min_rows);
+  if (tile == 7 && dma_ok && (long)M >= dma_from) return ff_gemm_dma_f32(g, st);
   switch (tile) {
     case 1: return launch_generic<64, 64, 32, 32>(g, batch, st);
     case 2: return launch_pipe<64, 64, 32, 32>(g, batch, st);
