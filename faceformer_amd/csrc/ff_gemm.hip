@@ -1462,7 +1462,8 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   const long hw = tiles / cus, left = tiles % cus;
   // ... when at most half a round of tiles is left over: measured (profiles/r05/gemm_hybrid_ab.txt, 256 t rows) +15-26 % on the
   // 512-column projections at t = 9 / 10, +8-12 % at t = 12, -2...-4 % at t = 14 (0.75 rounds left: unit ranges stay).
-  if (mode == 0 && hyb_on && hw >= 1 && left > 0 && 2 * left <= cus) {
+  static const long hyb_max_left8 = getenv("FF_SK_HYBRID_MAXLEFT8") ? atol(getenv("FF_SK_HYBRID_MAXLEFT8")) : 4;   // (A/B knob: eighths of a round)
+  if (mode == 0 && hyb_on && hw >= 1 && left > 0 && 8 * left <= hyb_max_left8 * cus) {
     const long left_units = left * sk.upt;
     long gb = left_units / g_sk_min_units;
     if (gb > cus) gb = cus;
