@@ -345,6 +345,39 @@ extern "C" int ff_assemble_embedding(const float* tok_embed, int num_token, cons
   return FF_OK;
 }
 
+// ---- process_masks + kv_len in one launch -----------------------------------------------------------------------------
+// mask_out[n, 0:num_token] = 0, mask_out[n, num_token + l] = (in[n, l] != 0)   (reference model.py:61-69 / model_para.py:62-70:
+// special tokens are never masked), kv_len[n] = 1 + the last unmasked key of row n (0 if every key is masked).  One wave per
+// wireframe.  Replaces eight torch operators in front of ff_encode (zeros, type_as, cat, to(uint8), arange, ==, *, amax).
+__global__ __launch_bounds__(256) void prepare_mask_kernel(const unsigned char* __restrict__ in, int N, int L, int num_token,
+                                                           unsigned char* __restrict__ out, int* __restrict__ kv_len) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int S = L + num_token;
+  int last = 0;
+  for (int s = lane; s < S; s += 64) {
+    const unsigned char m = s < num_token ? (unsigned char)0 : (in[(size_t)n * L + (s - num_token)] != 0 ? (unsigned char)1 : (unsigned char)0);
+    out[(size_t)n * S + s] = m;
+    if (m == 0) last = s + 1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(last, off, FF_WAVE);
+    last = o > last ? o : last;
+  }
+  if (lane == 0) kv_len[n] = last;
+}
+extern "C" int ff_prepare_mask(const unsigned char* input_mask, int N, int L, int num_token, unsigned char* mask_out,
+                               int* kv_len, ff_stream_t stream) {
+  FF_CHECK_ARG(N > 0 && L >= 0 && num_token >= 0 && L + num_token > 0 && mask_out && kv_len && (L == 0 || input_mask),
+               "ff_prepare_mask: bad arguments");
+  hipLaunchKernelGGL(prepare_mask_kernel, dim3(ff_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, input_mask, N, L, num_token,
+                     mask_out, kv_len);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
 // ---- LayerNorm affine folded into the following Linear ------------------------------------------------------
 __global__ __launch_bounds__(256) void scale_columns_kernel(const float* __restrict__ W, int ldw,
                                                             const float* __restrict__ gamma, float* __restrict__ out,

@@ -7,6 +7,10 @@ import torch
 from . import lib as _L
 from .ops import _dev, _p, _stream, split_weight
 
+import operator
+
+_VERSION_OF = operator.attrgetter("_version")
+
 DEFAULT_FLAGS = (_L.FF_REUSE_LAYER0_QKV | _L.FF_LAST_LAYER_LAST_ROW | _L.FF_DEDUP_PAD_ANCHORS
                  | _L.FF_FUSE_LAYERNORM)
 
@@ -165,10 +169,15 @@ class PathEngine:
     def pointers_current(self):
         """True while every bound tensor still lives at the address captured in the struct -- and, when
         derived copies of the weights exist (the bf16 planes), while no bound tensor was updated in place
-        since they were made (load_state_dict / optimizer.step bump `_version`)."""
-        if not all(self.tensors[k].data_ptr() == v.data_ptr() for k, v in self._keep.items()):
-            return False
-        return all(self.tensors[k]._version == ver for k, ver in self._versions.items())
+        since they were made (load_state_dict / optimizer.step bump `_version`).  Runs in front of EVERY forward:
+        two C-level passes over the ~200 tensors (33 us; the dict / generator form took 60 us of a 58.6 ms call)."""
+        chk = getattr(self, "_fast_check", None)
+        if chk is None:
+            kt = [self.tensors[k] for k in self._keep]
+            vt = [self.tensors[k] for k in self._versions]
+            chk = self._fast_check = (kt, tuple(v.data_ptr() for v in self._keep.values()), vt, tuple(self._versions.values()))
+        kt, ptrs, vt, vers = chk
+        return tuple(map(torch.Tensor.data_ptr, kt)) == ptrs and tuple(map(_VERSION_OF, vt)) == vers
 
     @property
     def has_planes(self):
@@ -182,7 +191,29 @@ class PathEngine:
         return self._ws
 
     # ---------------------------------------------------------------------------------------------
-    def encode(self, inp, mask_u8):
+    def prepare_mask(self, input_mask):
+        """input_mask [N, L] bool / uint8 (True = padding) -> (mask_u8 [N, S] with the never-masked special-token columns in
+        front, kv_len [N] int32): process_masks + key lengths as ONE launch (ff_prepare_mask)."""
+        if input_mask.dtype not in (torch.bool, torch.uint8) or input_mask.dim() != 2:
+            raise ValueError("input_mask must be a 2-D bool / uint8 tensor")
+        self._same_device(input_mask, "input_mask")
+        m = input_mask.contiguous()
+        N, L = m.shape
+        S = L + self.num_token
+        mask_u8 = torch.empty((N, S), device=self.device, dtype=torch.uint8)
+        kv_len = torch.empty((N,), device=self.device, dtype=torch.int32)
+        with torch.cuda.device(self.device):
+            _L.check(self._lib.ff_prepare_mask(_p(m), N, L, self.num_token, _p(mask_u8), _p(kv_len), _stream()), "ff_prepare_mask")
+        return mask_u8, kv_len
+
+    def stage_num_input(self, num_input):
+        """(host int array, device int32 tensor) of the per-wireframe edge counts for decode(): made BEFORE the encoder is
+        enqueued -- the pageable host-to-device copy inside decode() waited for the encoder's kernels on the same stream and
+        left the GPU idle until the host had caught up (~40 us per call)."""
+        vals = [int(x) for x in num_input]
+        return (C.c_int * len(vals))(*vals), torch.tensor(vals, dtype=torch.int32).to(self.device), vals
+
+    def encode(self, inp, mask_u8, kv_len=None):
         """inp [N, L, in_dim] fp32, mask_u8 [N, S] uint8 (1 = padding) -> (memory [N,S,E], kv_len)."""
         _dev(inp, "input"), _dev(mask_u8, "mask", torch.uint8)
         N, L = inp.shape[0], inp.shape[1]
@@ -191,7 +222,8 @@ class PathEngine:
         if inp.shape[2] != self.model.in_dim:
             raise ValueError("input has %d values per edge, model expects %d" % (inp.shape[2], self.model.in_dim))
         mask_u8 = mask_u8.contiguous()
-        kv_len = _kv_len_from_mask(mask_u8)
+        if kv_len is None:
+            kv_len = _kv_len_from_mask(mask_u8)
         memory = torch.empty((N, S, self.E), device=self.device, dtype=torch.float32)
         self._same_device(inp, "input"), self._same_device(mask_u8, "mask")
         nbytes = self._lib.ff_encode_workspace_bytes(C.byref(self.model), N, L)
@@ -208,7 +240,7 @@ class PathEngine:
     def decode(self, memory, mask_u8, kv_len, variant, T, F=1, num_input=None, extra_mask=None,
                chunk_wireframes=0, chunk_seqs=0, num_streams=1, sync_every=4, flags=DEFAULT_FLAGS,
                tok_sos=1, tok_eos=3, x3_min_rows=0, chunk_max_seqs=0, ln_fuse_max_rows=0,
-               trace=False, return_pointer=False, no_stop=False, stop_callback=None):
+               trace=False, return_pointer=False, no_stop=False, stop_callback=None, staged_num_input=None):
         """Greedy decode. Returns dict(predict [N*F, T] int64, steps, decoded_seqs, [pointer], [trace
         tensors indexed like predict's rows])."""
         _dev(memory, "memory")
@@ -230,7 +262,11 @@ class PathEngine:
         dev = self.device
         predict = torch.empty((B, T), device=dev, dtype=torch.int64)
         ni = ni_host = None
-        if num_input is not None:
+        if staged_num_input is not None:
+            ni_host, ni, vals = staged_num_input
+            if len(vals) != N or (num_input is not None and [int(x) for x in num_input] != vals):
+                raise ValueError("staged num_input does not belong to this batch")
+        elif num_input is not None:
             vals = [int(x) for x in num_input]
             if len(vals) != N:
                 raise ValueError("num_input has %d entries for %d wireframes" % (len(vals), N))

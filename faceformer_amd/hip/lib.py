@@ -144,6 +144,7 @@ SIGNATURES = {
     "ff_gather_rows": (C.c_int, [fptr, C.c_int, C.c_int, fptr, C.c_int, C.c_int, fptr, C.c_int, fptr]),
     "ff_assemble_embedding": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr,
                                         fptr]),
+    "ff_prepare_mask": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr]),
     "ff_encode_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.c_int, C.c_int]),
     "ff_encode": (C.c_int, [C.POINTER(Model), fptr, fptr, fptr, C.c_int, C.c_int, fptr, fptr,
                             C.c_size_t, fptr]),

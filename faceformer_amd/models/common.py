@@ -130,14 +130,17 @@ class SurfaceFormerBase(nn.Module):
             self._engine_obj = eng
         return eng
 
-    def _encode(self, inputs):
+    def _encode(self, inputs, eng=None):
         """(engine, memory [N,S,E], mask_u8 [N,S], kv_len [N])"""
         inp, input_mask = inputs["input"], inputs["input_mask"]
-        eng = self.engine()
+        eng = self.engine() if eng is None else eng
         if not inp.is_cuda:
             raise _L.HipExtensionError("inputs['input'] is on %s; expected a ROCm device tensor" % inp.device)
-        mask = self.process_masks(input_mask).to(torch.uint8).contiguous()
-        memory, kv_len = eng.encode(inp.to(torch.float32).flatten(-2, -1), mask)
+        if input_mask.dtype in (torch.bool, torch.uint8) and input_mask.dim() == 2 and input_mask.is_cuda:
+            mask, kv_len = eng.prepare_mask(input_mask)      # process_masks + key lengths in one launch
+        else:
+            mask, kv_len = self.process_masks(input_mask).to(torch.uint8).contiguous(), None
+        memory, kv_len = eng.encode(inp.to(torch.float32).flatten(-2, -1), mask, kv_len)
         return eng, memory, mask, kv_len
 
     def _extra_mask(self, inputs):

@@ -40,7 +40,9 @@ class SurfaceFormer_Parallel(SurfaceFormerBase):
         if label.size(2) < T - 1:
             raise ValueError("label has %d positions but max_face_length-1=%d query positions are "
                              "needed" % (label.size(2), T - 1))
-        num_input = [int(n) for n in inputs["num_input"]]
+        ni_in = inputs["num_input"]
+        # (a device tensor of counts comes over in ONE copy: int() per element is a synchronising copy per wireframe)
+        num_input = [int(n) for n in (ni_in.tolist() if torch.is_tensor(ni_in) else ni_in)]
         F = max(num_input)
         N = len(num_input)
         if N != inputs["input"].size(0):
@@ -53,12 +55,16 @@ class SurfaceFormer_Parallel(SurfaceFormerBase):
             order = sorted(range(N), key=lambda i: -num_input[i])
             idx = torch.tensor(order, device=inputs["input"].device)
             sub = {"input": inputs["input"].index_select(0, idx), "input_mask": inputs["input_mask"].index_select(0, idx)}
-            eng, memory, mask, kv_len = self._encode(sub)
             ni = [num_input[i] for i in order]
+            eng = self.engine()
+            staged = eng.stage_num_input(ni)       # (before the encoder is enqueued: see stage_num_input)
+            eng, memory, mask, kv_len = self._encode(sub, eng)
         else:
-            eng, memory, mask, kv_len = self._encode(inputs)
             ni = num_input
-        out = eng.decode(memory, mask, kv_len, _L.FF_PARALLEL, T=T, F=F, num_input=ni,
+            eng = self.engine()
+            staged = eng.stage_num_input(ni)
+            eng, memory, mask, kv_len = self._encode(inputs, eng)
+        out = eng.decode(memory, mask, kv_len, _L.FF_PARALLEL, T=T, F=F, num_input=ni, staged_num_input=staged,
                          chunk_wireframes=self.chunk_wireframes, chunk_seqs=self.chunk_seqs,
                          chunk_max_seqs=self.chunk_max_seqs,
                          num_streams=self.num_streams, sync_every=self.sync_every,

@@ -288,6 +288,12 @@ int ff_gather_rows(const float* memory, int S, int E, const int* tok, int B, int
 int ff_assemble_embedding(const float* tok_embed, int num_token, const float* edge_embed, int ld_edge,
                           int N, int L, int E, float* out, ff_stream_t stream);
 
+/* process_masks + key lengths in one launch: mask_out[n, 0:num_token] = 0 (special tokens are never masked, reference
+ * model.py:61-69 / model_para.py:62-70), mask_out[n, num_token + l] = (input_mask[n, l] != 0); kv_len[n] = 1 + the last
+ * unmasked key of wireframe n (0: every key masked).  input_mask: N x L bytes (a torch.bool tensor's storage), 1 = padding. */
+int ff_prepare_mask(const unsigned char* input_mask, int N, int L, int num_token, unsigned char* mask_out, int* kv_len,
+                    ff_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole-path engine.  Weights are the tensors of the reference state_dict,
  * fp32, on the device, passed by pointer -- no repacking.

@@ -632,3 +632,25 @@ def test_gemm_ln_argument_validation(hip_lib, ops):
         ops.linear_ln(x, W, row_table=torch.zeros(4, 512).cuda(), row_div=16, row_cols=512)
     with pytest.raises(L.HipExtensionError):       # not on the generic kernels
         ops.linear_ln(x, W, want_stats=True, tile=1)
+
+
+def test_prepare_mask_equals_process_masks_and_key_lengths(hip_lib, ops):
+    """ff_prepare_mask = reference process_masks (four never-masked special-token columns in front, model.py:61-69) + the key
+    length per wireframe, in one launch: against the torch formulation it replaces, incl. an all-masked row and a hole."""
+    from faceformer_amd.hip.engine import _kv_len_from_mask
+    g = torch.Generator().manual_seed(5)
+    for N, L_ in ((1, 256), (7, 40), (3, 1028), (130, 16)):
+        m = torch.rand(N, L_, generator=g) < 0.4
+        keep = torch.randint(0, L_ + 1, (N,), generator=g)
+        m |= torch.arange(L_)[None, :] >= keep[:, None]          # padded tails, plus random holes in front of them
+        m[0] = True                                               # every edge masked: the special tokens remain
+        md = m.cuda()
+        S = L_ + 4
+        mask_u8 = torch.empty(N, S, dtype=torch.uint8, device="cuda")
+        kv = torch.empty(N, dtype=torch.int32, device="cuda")
+        ops._L.check(hip_lib.ff_prepare_mask(md.data_ptr(), N, L_, 4, mask_u8.data_ptr(), kv.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "ff_prepare_mask")
+        want = torch.cat([torch.zeros(N, 4, dtype=torch.bool), m], dim=1).to(torch.uint8)
+        assert torch.equal(mask_u8.cpu(), want)
+        assert torch.equal(kv.cpu(), _kv_len_from_mask(want))
+        assert int(kv[0]) == 4
