@@ -48,6 +48,11 @@ CASES = [
          wseed=0, n_edges=[20, 13], seeds=[1, 2]),
     dict(name="seq_small_eos", kind="seq2seq", model=_m(SMALL, 16, 20), recipe="gain4",
          wseed=6, n_edges=[12], seeds=[3]),
+    # round 5: the seq2seq BATCH stop rule (cumulative EOS count == batch size, model.py:191,207-210) firing before every sample has
+    # produced its own EOS: wireframe 0 emits EOS at steps 5, 6 and 7, wireframe 1 its first at step 9 -> the reference stops after
+    # step 6 (searched with the oracle over weight seeds; tests/test_parity_golden.py builds its stop_each_eos test on the same pair)
+    dict(name="seq_small_repeat_eos", kind="seq2seq", model=_m(SMALL, 16, 20), recipe="gain4",
+         wseed=9, n_edges=[7, 12], seeds=[33, 30]),
     # config E style: ragged batch with up to 300 edges (S = 304 > 288: attention key chunking, pointer
     # tail), small model dims so the reference finishes in seconds
     dict(name="par_small_ragged300", kind="parallel", model=_m(SMALL, 300, 6), recipe="gain4",
