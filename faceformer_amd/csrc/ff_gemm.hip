@@ -794,11 +794,13 @@ struct StreamK {
   unsigned int* flags;         // [grid]: 1 = slot holds a partial tile
   int upt;                     // units per tile = K / 64
   int base, rem;               // block lb owns base + (lb < rem) units
-  // HYBRID launch (nA > 0; round 5): the first nA blocks take tilesA WHOLE tiles each (no exchange at all) and the units of the
-  // remaining tiles -- less than one tile per CU -- are dealt in equal ranges to the other gridDim.x - nA blocks, which run as
-  // the SECOND resident block of the CUs: a launch of 1.125 tiles per CU (t = 9: 288 tiles of the 512-column projections) costs
-  // the CU 8 + 1 units instead of 9 + the exchange of EVERY tile (unit ranges) or 16 (whole-tile rounds).
-  int nA, tilesA, uA;          // uA = nA * tilesA * upt: first unit of the dealt region
+  // HYBRID launch (nA > 0; round 5): hw = tiles / CUs WHOLE tiles per CU, spread over TWO resident blocks per CU as in the
+  // persistent kernel -- the first nA "heavy" blocks take tH = ceil(hw / 2) tiles each, the "light" blocks behind them tL =
+  // floor(hw / 2) -- and the units of the remaining tiles (less than one tile per CU) are dealt in equal ranges to the first gx
+  // light blocks, which run them BEFORE their whole tiles and exchange partial tiles among themselves.  A launch of 1.125 tiles per
+  // CU (t = 9: 288 tiles of the 512-column projections) costs the CU 8 + 1 units instead of 9 + the exchange of EVERY tile (unit
+  // ranges) or 16 (whole-tile rounds); one of 3.125 tiles per CU (t = 25) 3 tiles on two blocks + 2 units.
+  int nA, tH, tL, uA, gx;      // uA = (nA * (tH + tL)) * upt: first unit of the dealt region
 };
 
 template <int MODE>  // as gemm_persist_kernel
@@ -816,36 +818,44 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(GemmArgs g, StreamK s
 
   // logical block index: the blocks of one XCD (blockIdx % 8) own neighbouring unit ranges
   const int upt = sk.upt;
-  int lb, u0, u1;      // lb: index among the blocks that share unit ranges (slot of the partial-tile workspace)
-  if ((int)blockIdx.x < sk.nA) {          // hybrid launch, whole-tile block (block-uniform branch)
+  int lb = 0, u0 = 0, u1 = 0;   // lb: index among the blocks that share unit ranges (slot of the partial-tile workspace)
+  int main0 = 0, nmain = 0;     // hybrid launch: whole tiles [main0, main0 + nmain) of this block, run AFTER its unit range
+  if (sk.nA > 0 && (int)blockIdx.x < sk.nA) {          // heavy block (block-uniform branches)
     const int GA = sk.nA;
     const int la = ((GA & 7) == 0) ? (blockIdx.x & 7) * (GA >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    lb = 0;
-    u0 = la * sk.tilesA * upt;
-    u1 = u0 + sk.tilesA * upt;
+    main0 = la * sk.tH; nmain = sk.tH;
   } else {
     const int bb = blockIdx.x - sk.nA, G = gridDim.x - sk.nA;
     lb = ((G & 7) == 0) ? (bb & 7) * (G >> 3) + (bb >> 3) : bb;
-    u0 = sk.uA + lb * sk.base + (lb < sk.rem ? lb : sk.rem);
-    u1 = u0 + sk.base + (lb < sk.rem ? 1 : 0);
+    if (sk.nA == 0 || lb < sk.gx) {
+      u0 = sk.uA + lb * sk.base + (lb < sk.rem ? lb : sk.rem);
+      u1 = u0 + sk.base + (lb < sk.rem ? 1 : 0);
+    }
+    if (sk.nA > 0) { main0 = sk.nA * sk.tH + lb * sk.tL; nmain = sk.tL; }
   }
-  if (u0 >= u1) return;
+  const bool has_x = u0 < u1;
+  if (!has_x && nmain == 0) return;
   FF_EXP_SKSTAMP(0);
-  const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
+  const int k0 = has_x ? u0 / upt : 0, k1 = has_x ? (u1 - 1) / upt : 0;
   const int ja = u0 - k0 * upt;  // first unit of tile k0 in the range
-  const int jb = u1 - k1 * upt;  // one past the last unit of tile k1 in the range (1..upt)
-  const bool has_c = jb < upt;                           // beginning part of k1: contributed
-  const bool has_o = ja > 0 && !(k0 == k1 && has_c);     // end part of k0: owned, needs the fix-up
+  const int jb = has_x ? u1 - k1 * upt : upt;  // one past the last unit of tile k1 in the range (1..upt)
+  const bool has_c = has_x && jb < upt;                           // beginning part of k1: contributed
+  const bool has_o = has_x && ja > 0 && !(k0 == k1 && has_c);     // end part of k0: owned, needs the fix-up
   const int kf0 = k0 + (ja > 0 ? 1 : 0);
-  const int nfull = (k1 + (has_c ? 0 : 1) - kf0) > 0 ? (k1 + (has_c ? 0 : 1) - kf0) : 0;
-  const int nseg = (has_c ? 1 : 0) + nfull + (has_o ? 1 : 0);
+  const int nfull = (has_x && (k1 + (has_c ? 0 : 1) - kf0) > 0) ? (k1 + (has_c ? 0 : 1) - kf0) : 0;
+  const int nseg_x = (has_c ? 1 : 0) + nfull + (has_o ? 1 : 0);
+  const int nseg = nseg_x + nmain;
   // segment p in execution order -> (tile, first slice, slice count, kind 0 whole / 1 contribute / 2 own+fix)
+  // Order: the contributed part first (published at once), then every WHOLE tile (of the unit range, then the block's own tiles of
+  // a hybrid launch), the owned part last.  A one-unit (two-slice) segment is therefore only ever the first or the last one: the
+  // deferred LayerNorm statistics of MODE 1 need three slices between two tile switches of the load cursor.
   auto segment = [&](int p, int& tile, int& j0, int& n, int& kind) {
     if (has_c && p == 0) {
       tile = k1; j0 = 2 * (k1 == k0 ? ja : 0); n = 2 * jb - j0; kind = 1;
     } else {
       const int q = p - (has_c ? 1 : 0);
       if (q < nfull) { tile = kf0 + q; j0 = 0; n = nsl; kind = 0; }
+      else if (q < nfull + nmain) { tile = main0 + (q - nfull); j0 = 0; n = nsl; kind = 0; }
       else { tile = k0; j0 = 2 * ja; n = nsl - j0; kind = 2; }
     }
   };
@@ -1455,7 +1465,7 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   const long cus = SK_MAX_GRID / 2;
   const double whole_cost = (double)((tiles + cus - 1) / cus) * sk.upt;
   const double split_cost = (double)units / cus + g_sk_fix_units;
-  sk.nA = 0; sk.tilesA = 0; sk.uA = 0;
+  sk.nA = 0; sk.tH = 0; sk.tL = 0; sk.uA = 0; sk.gx = 0;
   // Hybrid (see StreamK): hw whole tiles per CU + the units of the remaining tiles dealt to a second block per CU.
   static const int hyb_on = getenv("FF_SK_HYBRID") ? atoi(getenv("FF_SK_HYBRID")) : 1;               // (A/B knob)
   static const double hyb_fix = getenv("FF_SK_HYBRID_FIX") ? 0.1 * atoi(getenv("FF_SK_HYBRID_FIX")) : 1.0;
@@ -1470,12 +1480,13 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
     if (gb < 1) gb = 1;
     const double hybrid_cost = (double)hw * sk.upt + (double)((left_units + gb - 1) / gb) + hyb_fix;
     if (hybrid_cost < whole_cost && hybrid_cost < split_cost) {
-      sk.nA = (int)cus; sk.tilesA = (int)hw; sk.uA = (int)(cus * hw * sk.upt);
+      sk.nA = (int)cus; sk.tH = (int)((hw + 1) / 2); sk.tL = (int)(hw / 2); sk.uA = (int)(cus * hw * sk.upt);
+      sk.gx = (int)gb;
       sk.base = (int)(left_units / gb);
       sk.rem = (int)(left_units % gb);
       FF_RETURN_IF(sk_acquire(st, &sk));
       const int lmh = gemm_mode(g);
-      const int gridh = (int)(cus + gb);
+      const int gridh = (int)(cus + (sk.tL > 0 ? cus : gb));   // light blocks: all 256 when they carry whole tiles
       if (lmh == 1) return launch_streamk_mode<1>(g, sk, gridh, st);
       if (lmh == 2) return launch_streamk_mode<2>(g, sk, gridh, st);
       return launch_streamk_mode<0>(g, sk, gridh, st);

@@ -170,7 +170,7 @@ def test_gemm_split_a_and_inplace_residual(ops, tile, M):
     assert rel_err(x, ref2) < 3e-6
 
 
-@pytest.mark.parametrize("M", [2304, 2560, 3072, 3840, 2100, 3333])
+@pytest.mark.parametrize("M", [2304, 2560, 3072, 3840, 2100, 3333, 4352, 5120, 6400, 6500])   # (from 4352: two / three whole tiles per CU)
 @pytest.mark.parametrize("N,K", [(512, 512), (1024, 512), (1536, 512), (512, 1024), (260, 512)])
 def test_gemm_hybrid_streamk_launch(ops, M, N, K):
     """Round 5: the hybrid launch of the 64x64 family (automatic choice, tile 0): whole tiles on the first 256 blocks, the units
@@ -571,7 +571,8 @@ def _seg_stats(x64):
 
 
 @pytest.mark.parametrize("tile", [0, 3, 6, 8, 11])
-@pytest.mark.parametrize("M,N,K", [(37, 512, 512), (300, 512, 1024), (1300, 512, 512), (5000, 512, 512), (640, 128, 256)])
+@pytest.mark.parametrize("M,N,K", [(37, 512, 512), (300, 512, 1024), (1300, 512, 512), (5000, 512, 512), (640, 128, 256),
+                                   (2304, 512, 512), (4864, 512, 1024), (6400, 512, 512)])   # (hybrid launches, round 5)
 def test_gemm_emits_layernorm_segment_statistics(hip_lib, ops, M, N, K, tile):
     """Producer side: C = A W^T + b + residual plus, per row and 32-column segment, (mean, M2) of the stored C."""
     if tile == 8 and M > 1024:
@@ -592,7 +593,12 @@ def test_gemm_emits_layernorm_segment_statistics(hip_lib, ops, M, N, K, tile):
 
 @pytest.mark.parametrize("tile", [0, 3, 6, 8, 11])
 @pytest.mark.parametrize("M,N,K,div", [(37, 1536, 512, 5), (300, 512, 512, 7), (1300, 1536, 512, 64), (5000, 1024, 512, 256),
-                                       (256, 512, 128, 16), (9216, 1536, 512, 256)])
+                                       (256, 512, 128, 16), (9216, 1536, 512, 256),
+                                       # round 5, the hybrid launch of the 64x64 family with this consumer form: unit ranges of
+                                       # 1 / 3 / 2 units behind one, two and three whole tiles per CU (a one-unit OWNED piece in
+                                       # front of whole tiles once normalised two slices with the previous tile's statistics)
+                                       (2304, 512, 512, 256), (4864, 512, 512, 256), (6400, 512, 512, 256), (5632, 512, 512, 256),
+                                       (2304, 1024, 512, 256), (2560, 1536, 512, 256)])
 def test_gemm_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, M, N, K, div, tile):
     """Consumer side: act((LN(x) + pos[row // div]) W^T + b) from raw x, its segment statistics, the folded
     weight / bias and the pos W^T table -- against the unfused arithmetic in float64."""
