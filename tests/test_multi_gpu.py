@@ -89,13 +89,14 @@ def test_bench_distributed_code_path_runs_with_one_rank():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist",
-           "--wireframes-per-gpu", "2", "--steps", "1", "--warmup", "1", "--no-roofline"]
+           "--wireframes-per-gpu", "2", "--steps", "1", "--warmup", "1"]   # (with the roofline / clock-probe leg: at config 3's
+    # 5.6 s passes the probe's spin once exceeded the hook's limit and cost the N > 1 line -- round 5)
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "weak_one_wireframe_per_gpu", "scaling_series"):
+              "dtype", "data", "config", "weak_one_wireframe_per_gpu", "scaling_series", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert "decode_sharded(local_shard=True)" in d["config"]["workload"] and d["config"]["wireframes_per_gpu"] == 2
