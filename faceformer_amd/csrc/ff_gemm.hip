@@ -1475,7 +1475,8 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   static const long hyb_max_left8 = getenv("FF_SK_HYBRID_MAXLEFT8") ? atol(getenv("FF_SK_HYBRID_MAXLEFT8")) : 4;   // (A/B knob: eighths of a round)
   if (mode == 0 && hyb_on && hw >= 1 && left > 0 && 8 * left <= hyb_max_left8 * cus) {
     const long left_units = left * sk.upt;
-    long gb = left_units / g_sk_min_units;
+    static const long hyb_min_units = getenv("FF_SK_HYBRID_MINU") ? atol(getenv("FF_SK_HYBRID_MINU")) : 2;   // (A/B knob)
+    long gb = left_units / (hyb_min_units > 0 ? hyb_min_units : 1);
     if (gb > cus) gb = cus;
     if (gb < 1) gb = 1;
     const double hybrid_cost = (double)hw * sk.upt + (double)((left_units + gb - 1) / gb) + hyb_fix;
