@@ -1473,14 +1473,15 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   // ... when at most half a round of tiles is left over: measured (profiles/r05/gemm_hybrid_ab.txt, 256 t rows) +15-26 % on the
   // 512-column projections at t = 9 / 10, +8-12 % at t = 12, -2...-4 % at t = 14 (0.75 rounds left: unit ranges stay).
   static const long hyb_max_left8 = getenv("FF_SK_HYBRID_MAXLEFT8") ? atol(getenv("FF_SK_HYBRID_MAXLEFT8")) : 4;   // (A/B knob: eighths of a round)
-  if (mode == 0 && hyb_on && hw >= 1 && left > 0 && 8 * left <= hyb_max_left8 * cus) {
+  static const int hyb_force = getenv("FF_SK_HYBRID_FORCE") ? atoi(getenv("FF_SK_HYBRID_FORCE")) : 0;   // (probe: whole rounds too)
+  if (mode == 0 && hyb_on && hw >= 1 && (left > 0 || hyb_force) && 8 * left <= hyb_max_left8 * cus) {
     const long left_units = left * sk.upt;
     static const long hyb_min_units = getenv("FF_SK_HYBRID_MINU") ? atol(getenv("FF_SK_HYBRID_MINU")) : 2;   // (A/B knob)
     long gb = left_units / (hyb_min_units > 0 ? hyb_min_units : 1);
     if (gb > cus) gb = cus;
-    if (gb < 1) gb = 1;
+    if (gb < 1) gb = 1;   // (left == 0 under the probe knob: one light block with an empty range)
     const double hybrid_cost = (double)hw * sk.upt + (double)((left_units + gb - 1) / gb) + hyb_fix;
-    if (hybrid_cost < whole_cost && hybrid_cost < split_cost) {
+    if ((hybrid_cost < whole_cost && hybrid_cost < split_cost) || hyb_force) {
       sk.nA = (int)cus; sk.tH = (int)((hw + 1) / 2); sk.tL = (int)(hw / 2); sk.uA = (int)(cus * hw * sk.upt);
       sk.gx = (int)gb;
       sk.base = (int)(left_units / gb);
