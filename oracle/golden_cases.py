@@ -66,6 +66,10 @@ CASES = [
     # configs/seq2seq.yml sizes (config A): L=110, T=259, one 64-edge wireframe
     dict(name="seq_full_A64_gain4", kind="seq2seq", model=_m(FULL, 110, 259), recipe="gain4",
          wseed=0, n_edges=[64], seeds=[3], slow=True),
+    # round 5: a BATCH of the single-sequence model at config A's sizes (four wireframes of different edge counts in one forward):
+    # pins the sequence-wise micro-batching of SurfaceFormer.forward_eval and the cumulative EOS rule at the full model size
+    dict(name="seq_full_A4_gain4", kind="seq2seq", model=_m(FULL, 110, 259), recipe="gain4",
+         wseed=0, n_edges=[64, 40, 90, 110], seeds=[3, 103, 104, 105], slow=True),
     # --- round 2: BASELINE configs C, D, E at the FULL model size ---------------------------------------
     # config C (per-GPU batch of 256-edge wireframes, ours.yml sizes): four distinct wireframes in ONE
     # reference batch; the GPU property test decodes a 16-wireframe batch whose first four must
