@@ -681,20 +681,28 @@ struct PointerArgs {
   int host_which;   // 0: count_ge, 1: count_eq
 };
 
-// Stop-rule counters of one finished sequence (lane 0 of its wavefront), and -- when the engine asks for it -- the launch's
-// total into host-mapped memory by the LAST sequence of the launch to get here: every sequence's atomic add is ordered
-// before its arrival (release), the last arrival reads the counter after it (acquire).  The host looks at the slot only
-// behind an event recorded after the launch, so it never sees a partial count.
-__device__ __forceinline__ void ff_pointer_count(const PointerArgs& a, int b, int idx) {
-  if (a.count_ge && idx >= a.ge_bound) atomicAdd(a.count_ge, 1);
-  if (a.count_eq && idx == a.eq_value) {
-    bool first = true;
-    if (a.seen) { first = a.seen[b] == 0; a.seen[b] = 1; }   // (only this sequence's wavefronts touch seen[b], one step at a time)
-    if (first) atomicAdd(a.count_eq, 1);
+// Stop-rule counters of the (up to four) sequences a 256-thread block has finished, by ONE thread of the block: one atomic per
+// counter and block instead of one per sequence (4096 sequences of a 16-wireframe micro-batch adding to one address, plus the
+// arrival count, had taken pointer_reduce_kernel from 54 to 119 us), and -- when the engine asks for it -- the launch's total
+// into host-mapped memory by the LAST block to get here: every block's adds are ordered before its arrival (release), the last
+// arrival reads the counter after it (acquire).  The host looks at the slot only behind an event recorded after the launch.
+// toks[i]: token of sequence b0 + i, nvalid of them exist.
+__device__ __forceinline__ void ff_pointer_count_block(const PointerArgs& a, int b0, const int* toks, int nvalid) {
+  int nge = 0, neq = 0;
+  for (int i = 0; i < nvalid; ++i) {
+    const int idx = toks[i];
+    if (a.count_ge && idx >= a.ge_bound) ++nge;
+    if (a.count_eq && idx == a.eq_value) {
+      bool first = true;
+      if (a.seen) { first = a.seen[b0 + i] == 0; a.seen[b0 + i] = 1; }   // (only this sequence's block touches seen[b], one step at a time)
+      if (first) ++neq;
+    }
   }
+  if (nge) atomicAdd(a.count_ge, nge);
+  if (neq) atomicAdd(a.count_eq, neq);
   if (a.arrive) {
-    const int prev = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == a.B - 1) {
+    const int prev = __hip_atomic_fetch_add(a.arrive, nvalid, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + nvalid == a.B) {
       const int v = __hip_atomic_load(a.host_which ? a.count_eq : a.count_ge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.host_slot, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -704,7 +712,8 @@ __device__ __forceinline__ void ff_pointer_count(const PointerArgs& a, int b, in
 // `logits` holds the raw dot products of every (sequence, key); mask the row in place and reduce (value, index) pairs --
 // per lane over its strided keys, then across the 64 lanes with a butterfly that keeps torch's tie rule (lowest index)
 // and the runner-up value.
-__device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int b, int lane) {
+// Returns the selected token (wave-uniform); the caller counts it (ff_pointer_count_block).
+__device__ __forceinline__ int ff_pointer_reduce_row(const PointerArgs& a, int b, int lane) {
   const int w = b / a.spg;
   int kv = a.S;
   if (a.kv_len) { const int k = ff_ldw(a.kv_len + w); kv = k < kv ? k : kv; }
@@ -737,7 +746,6 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
     ff_st4i(a.next_tok + b, i1);
     if (a.best) ff_st4(a.best + b, b1);
     if (a.second) ff_st4(a.second + b, b2);
-    ff_pointer_count(a, b, i1);
   }
   if (a.next_rows) {
     const float* src = a.memory + ((size_t)w * a.S + i1) * a.E;
@@ -745,4 +753,5 @@ __device__ __forceinline__ void ff_pointer_reduce_row(const PointerArgs& a, int 
     for (int vi = lane; vi < (a.E >> 2); vi += 64)
       ff_st16(dst + vi * 4, ff_ldw16(src + vi * 4));
   }
+  return i1;
 }

@@ -15,11 +15,9 @@
 namespace {
 
 
+// one sequence by one wavefront; returns its token (wave-uniform)
 template <int NV>
-__global__ __launch_bounds__(256) void pointer_kernel(PointerArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (b >= a.B) return;
+__device__ __forceinline__ int pointer_row(const PointerArgs& a, int b, int lane) {
   const int w = b / a.spg;
   const int nvec = a.E >> 2;
   f32x4 pv[NV];
@@ -104,7 +102,6 @@ __global__ __launch_bounds__(256) void pointer_kernel(PointerArgs a) {
     a.next_tok[b] = best_idx;
     if (a.best) a.best[b] = best;
     if (a.second) a.second[b] = second;
-    ff_pointer_count(a, b, best_idx);
   }
   if (a.next_rows) {
     const float* src = mem + (size_t)best_idx * a.E;
@@ -115,14 +112,33 @@ __global__ __launch_bounds__(256) void pointer_kernel(PointerArgs a) {
       if (vi < nvec) *reinterpret_cast<f32x4*>(dst + vi * 4) = *reinterpret_cast<const f32x4*>(src + vi * 4);
     }
   }
+  return best_idx;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void pointer_kernel(PointerArgs a) {
+  __shared__ int s_tok[4];
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b < a.B) s_tok[threadIdx.x >> 6] = pointer_row<NV>(a, b, lane);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int b0 = blockIdx.x * (blockDim.x >> 6);
+    ff_pointer_count_block(a, b0, s_tok, a.B - b0 < 4 ? a.B - b0 : 4);
+  }
 }
 
 // GEMM path, stage 2 (ff_pointer_reduce_row, ff_device.h): mask the raw logit row in place and reduce it.
 __global__ __launch_bounds__(256) void pointer_reduce_kernel(PointerArgs a) {
+  __shared__ int s_tok[4];
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (b >= a.B) return;
-  ff_pointer_reduce_row(a, b, lane);
+  if (b < a.B) s_tok[threadIdx.x >> 6] = ff_pointer_reduce_row(a, b, lane);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int b0 = blockIdx.x * (blockDim.x >> 6);
+    ff_pointer_count_block(a, b0, s_tok, a.B - b0 < 4 ? a.B - b0 : 4);
+  }
 }
 
 }  // namespace
