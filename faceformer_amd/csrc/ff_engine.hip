@@ -60,7 +60,7 @@ __global__ void init_tokens_kernel(int* tok, int Bc, int Fc, int f0, const int* 
 
 // steps_done from the per-step counters (the reference's stop rules, model_para.py:232 / model.py:207-210)
 // The counters are kept per (step, micro-batch) -- every pointer launch owns one, which it also publishes to the host
-// (ff_pointer_count) -- and summed here into cnt_tot[step].
+// (ff_pointer_count_block) -- and summed here into cnt_tot[step].
 __global__ void steps_kernel(const int* __restrict__ cnt_ge, const int* __restrict__ cnt_eq, int nch, int variant, int N,
                              int steps_enqueued, int no_stop, int* __restrict__ cnt_tot, int* __restrict__ steps_done_out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -697,7 +697,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
     const auto host_t0 = std::chrono::steady_clock::now();
     // Stop rule on the host WITHOUT draining the queue and WITHOUT a copy launch: every pointer launch owns the counter of
-    // its (step, micro-batch) and its last sequence stores the total into host-mapped pinned memory (ff_pointer_count).
+    // its (step, micro-batch) and its last block stores the total into host-mapped pinned memory (ff_pointer_count_block).
     // Every sync_every steps an event is recorded behind the steps enqueued so far (on every stream); it is waited for
     // when another sync_every steps have been enqueued -- by then the host is a whole period ahead of it, so the wait
     // normally returns at once and the GPU always has a period of steps queued.  A stop is noticed at most
