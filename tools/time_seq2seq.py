@@ -25,6 +25,8 @@ for cfgfile, n in CASES:
     model = SurfaceFormer(**cfg.model)
     model.load_state_dict(make_state_dict(state_dict_spec("seq2seq", L, T), "gain4", 0))
     model = model.eval().cuda()
+    if os.environ.get("FF_SEQ_X3_MIN_ROWS"):   # 0 = every product on the f32 matrix cores (default: the package default)
+        model.x3_min_rows = int(os.environ["FF_SEQ_X3_MIN_ROWS"])
     if os.environ.get("FF_SEQ_CHUNK"):   # sequences per micro-batch (default: the model's 256)
         model.chunk_max_seqs = int(os.environ["FF_SEQ_CHUNK"])
     for nb in BATCHES:
