@@ -473,7 +473,9 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
 }
 
 // Internal side streams + fork/join events: one pool per device, created on first use.
-constexpr int FF_PINNED_COUNTERS = 65536;   // host-mapped ints: one per (step, micro-batch) of a decode
+// host-mapped ints: one per (step, micro-batch) of a decode; a decode with more of them checks its stop rule by draining the
+// streams and copying (FF_PINNED_COUNTERS overrides the size: tests run that path with a handful of slots)
+const int FF_PINNED_COUNTERS = getenv("FF_PINNED_COUNTERS") && atoi(getenv("FF_PINNED_COUNTERS")) > 0 ? atoi(getenv("FF_PINNED_COUNTERS")) : 65536;
 struct StreamPool {
   hipStream_t side[FF_MAX_STREAMS];
   hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];

@@ -430,6 +430,30 @@ def test_seq2seq_batch_with_a_repeated_eos_keeps_every_wireframes_own_tokens(hip
     assert np.array_equal(one_each, singles[1])
 
 
+def test_stop_rule_without_host_slots_drains_and_copies(hip_lib):
+    """A decode with more (step, micro-batch) counters than host-mapped slots checks its stop rule the slow way (drain, copy,
+    sum).  FF_PINNED_COUNTERS=8 in a child process forces that path on the early-stopping and EOS goldens: same tokens, same
+    stop step as the golden (and as the slot path, which the other tests run)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import batch_to, build_model, case_weights_and_batch, load_golden\n"
+        "for name in ('par_small_earlybreak', 'par_small_break1', 'seq_small_eos', 'seq_small_repeat_eos', 'par_small_ragged'):\n"
+        "    case, z = load_golden(name)\n"
+        "    sd, batch = case_weights_and_batch(case)\n"
+        "    model = build_model(case, sd, 'cuda')\n"
+        "    model.chunk_wireframes = 1\n"
+        "    with torch.no_grad():\n"
+        "        pred = model(batch_to(batch, 'cuda'))['predict'].cpu().numpy()\n"
+        "    assert np.array_equal(pred.reshape(-1), z['predict'].reshape(-1)), name\n"
+        "print('ok')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, FF_PINNED_COUNTERS="8"))
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-2000:]
+
+
 def test_json_gather_over_rccl(hip_lib, tmp_path):
     """The north-star's 'RCCL all-gather of predicted face-loop JSON': decode_to_face_json on the nccl backend
     (world size 1 on this box; the gloo tests cover world sizes 2 and 3) incl. the co-edge post-processing
