@@ -385,6 +385,20 @@ def test_seq2seq_batch_is_micro_batched_by_sequences_and_equals_one_wireframe_de
     hit = np.nonzero(cum == N)[0]                # (equality, like the reference: a count that jumps past N never stops)
     steps = int(hit[0]) + 1 if hit.size else T - 1
     assert np.array_equal(fwd[:, :steps + 1], full[:, :steps + 1]) and (fwd[:, steps + 1:] == 0).all()
+    # inputs['pointer'] (project(decoder(...)) of every prefix row at the stop step, reference model.py:217) with SEVERAL
+    # micro-batches: one strided copy per micro-batch into [steps, N, E] -- against the one-micro-batch forward
+    with torch.no_grad():
+        one_mb = model(dict(batch))
+    model.chunk_max_seqs = 16
+    with torch.no_grad():
+        many_mb = model(dict(batch))
+    assert torch.equal(one_mb["predict"], many_mb["predict"]) or (one_mb["predict"] == many_mb["predict"]).float().mean() > 0.97
+    pa, pb = one_mb["pointer"], many_mb["pointer"]
+    assert pa.shape == pb.shape == (N, steps, m["E"])
+    same_prefix = (one_mb["predict"][:, :steps] == many_mb["predict"][:, :steps]).all(dim=1)    # rows fed the same tokens
+    assert same_prefix.float().mean() > 0.9
+    err = (pa[same_prefix] - pb[same_prefix]).abs().max() / pa.abs().max()
+    assert err < 2e-4, err
 
 
 def test_seq2seq_batch_with_a_repeated_eos_keeps_every_wireframes_own_tokens(hip_lib):
