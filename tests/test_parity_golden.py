@@ -491,6 +491,20 @@ def test_json_gather_over_rccl(hip_lib, tmp_path):
         model_m = build_model(case_m, sd_m, "cuda")
         out_m = ffd.decode_sharded(model_m, batch_to(batch_m, "cuda"), dist)
         out_l = ffd.decode_sharded(model, batch_to(batch, "cuda"), dist, local_shard=True)
+        # the single-sequence model through the same calls: the batch whose reference stop rule fires before wireframe 1's own EOS
+        # (golden seq_small_repeat_eos).  decode_sharded keeps the reference's rule; decode_to_face_json decodes until EVERY
+        # wireframe has produced an EOS (stop_each_eos inside the call, restored afterwards): records of one-wireframe decodes
+        case_s, z_s = load_golden("seq_small_repeat_eos")
+        sd_s, batch_s = case_weights_and_batch(case_s)
+        model_s = build_model(case_s, sd_s, "cuda")
+        out_s = ffd.decode_sharded(model_s, batch_to(batch_s, "cuda"), dist)
+        recs_s = ffd.decode_to_face_json(model_s, batch_to(batch_s, "cuda"), dist)
+        assert model_s.stop_each_eos is False
+        singles = []
+        for i in range(2):
+            one = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in batch_s.items()}
+            with torch.no_grad():
+                singles.append(model_s(batch_to(one, "cuda"))["predict"].cpu().numpy()[0])
     finally:
         if created:
             dist.destroy_process_group()
@@ -501,6 +515,12 @@ def test_json_gather_over_rccl(hip_lib, tmp_path):
         assert json.loads(r)["pred_faces"] == want
     assert np.array_equal(out_m["predict"].cpu().numpy(), z_m["predict"])
     assert np.array_equal(out_l["predict"].cpu().numpy(), z["predict"]) and out_l["shard_sizes"] == [2]
+    assert np.array_equal(out_s["predict"].cpu().numpy(), z_s["predict"])
+    for i, r in enumerate(recs_s):
+        n_i = int((~batch_s["input_mask"][i]).sum())
+        pf, _ = FZ.parse_faces(singles[i], batch_s["label"][i].numpy(), n_i, token_ns())
+        m = FZ.face_metrics(pf, FZ.parse_faces(singles[i], batch_s["label"][i].numpy(), n_i, token_ns())[1])
+        assert json.loads(r)["pred_faces"] == json.loads(FZ.dumps_record(FZ.faces_record([], [], m["predictions"], m["labels"])))["pred_faces"]
 
 
 FRESH_CASES = {
