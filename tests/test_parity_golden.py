@@ -754,6 +754,60 @@ def test_cli_decode_with_coedge_postprocessing_matches_reference(hip_lib, tmp_pa
         assert sorted(map(json.dumps, rec["label_faces"])) == sorted(map(json.dumps, smp["label_faces"]))
 
 
+def test_cli_single_sequence_model_batched_run_writes_the_one_sample_files(hip_lib, tmp_path):
+    """main.py's test branch with the single-sequence model (SurfaceFormer, reference model.py:169-219) and --batch-size 4.
+    The reference's test loader is fixed at one sample; its batch stop rule (cumulative EOS count == N, model.py:211-212)
+    would cut samples 1-3 of this batch short of their own EOS (weights picked for that: the oracle shows it below), so
+    run_test switches the model to the per-sequence rule (FF_STOP_EACH_EOS) and the files equal the one-sample run's."""
+    import json
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    import main as cli
+    from faceformer_amd import datasets as D
+    from faceformer_amd import faces as FZ
+    from faceformer_amd.config import load_cfg
+    from faceformer_amd.synth import make_state_dict, state_dict_spec
+    from oracle import refpath
+    root = tmp_path / "data"
+    (root / "json").mkdir(parents=True)
+    rng = np.random.default_rng(21)
+    names = []
+    for i in range(4):
+        n = 6 + 3 * i
+        raw = {"edges": [rng.uniform(-1, 1, size=(2, 2)).tolist() for _ in range(n)],
+               "faces_indices": [[[0, 1, 2]], [[3, 4, 5]]], "pairings": {}, "dominant_directions": [[1, 0, 0]]}
+        json.dump(raw, open(root / "json" / ("%08d.json" % i), "w"))
+        names.append("json/%08d.json" % i)
+    open(root / "test.txt", "w").write("\n".join(names) + "\n")
+    cfg = load_cfg("configs/seq2seq.yml", ["model.num_lines", "16", "model.label_seq_length", "24", "model.num_model", "128",
+                                            "model.num_head", "2", "model.num_feedforward", "256",
+                                            "model.num_encoder_layers", "2", "model.num_decoder_layers", "2",
+                                            "root_dir", str(root), "post_process.is_coedge", "False"])
+    assert cfg.model_class == "SurfaceFormer"
+    sd = make_state_dict(state_dict_spec("seq2seq", 16, 24, 128, 256, 2, 2), "gain4", 51)
+    ckpt = tmp_path / "last.ckpt"
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "hyper_parameters": dict(cfg)}, ckpt)
+    one = cli.run_test(cfg, str(ckpt), out_dir=str(tmp_path / "b1"), batch_size=1)
+    four = cli.run_test(cfg, str(ckpt), out_dir=str(tmp_path / "b4"), batch_size=4)
+    files = sorted(os.listdir(one))
+    assert len(files) == 4
+    for fn in files:
+        assert open(os.path.join(one, fn), "rb").read() == open(os.path.join(four, fn), "rb").read()
+    # the case is a real one: under the reference's batch rule the four-sample call stops before samples 1-3 reach their EOS
+    ds = D.ABCDataset(str(root), ["test.txt"], cfg.model)
+    items = [ds[i] for i in range(4)]
+    pb = refpath.seq2seq_forward_eval(sd, dict(D.collate(items)), num_head=2)["predict"].numpy()
+    short = []
+    for i in range(4):
+        ps = refpath.seq2seq_forward_eval(sd, dict(D.collate([items[i]])), num_head=2)["predict"].numpy()[0]
+        if not np.array_equal(FZ.apply_own_stop_rule(pb[i], cfg.model.token, False), ps):
+            short.append(i)
+        rec = json.load(open(os.path.join(one, "%08d.json" % i)))
+        text, _ = cli.record_of(cfg, ds.raw_datas[i], items[i], ps, False)
+        assert json.loads(text)["pred_faces"] == rec["pred_faces"]      # and the files carry the reference's one-sample faces
+    assert short == [1, 2, 3]
+
+
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_full_n40_gain4", "par_full_n40_default"])
 def test_error_against_fp64_truth_is_fp32_class(hip_lib, name):
     """Whose logits are closer to exact arithmetic?  The oracle restated in float64 is the truth; the
