@@ -7,7 +7,8 @@ operands toggle no matrix-core data lines), the launches run back to back for ~2
   * a one-wave probe kernel on a SECOND stream (ff_clock_probe_launch: s_memtime cycles / s_memrealtime wall time) measures
     the clock the SIMDs actually ran at during the middle of that loop, and
   * a child process samples `rocm-smi --showpower --showclocks --json` every ~100 ms.
-Printed per row: TF/s (fp32-equivalent flops / wall), effective GHz of the probe, the rate re-priced at that clock
+Printed per row: TF/s (fp32-equivalent flops / GPU time of the median ~20-ms chunk of launches; the share of chunks within 5 % of
+that median says how much of the loop the host kept the queue full), effective GHz of the probe, the rate re-priced at that clock
 (fraction of peak x 2.4 / GHz), board power [W] and the sclk the SMI tool reports (min / mean / max of the samples).
 """
 import ctypes
@@ -91,30 +92,40 @@ def run_case(name, fn, flops, peak, seconds=2.0):
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fn()
+    for _ in range(16):
+        fn()
     torch.cuda.synchronize()
-    one = max(time.perf_counter() - t0, 1e-6)
+    one = max((time.perf_counter() - t0) / 16, 1e-6)
     iters = max(8, int(seconds / one))
     smi = Smi()
     smi.start()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
+    # GPU-side timing in chunks of ~20 ms (an event per chunk boundary): the MEDIAN chunk rate is what the kernel does when the
+    # launch loop keeps the queue full; chunks far below it are host stalls (the interpreter was descheduled), counted in `steady`
+    ck = max(4, int(0.02 / one))
+    nchunks = max(4, iters // ck)
+    iters = ck * nchunks
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nchunks + 1)]
+    evs[0].record()
     launched = False
-    for i in range(iters):
-        fn()
-        if not launched and i >= iters // 4:      # the probe covers the middle half of the loop
+    for c in range(nchunks):
+        for _ in range(ck):
+            fn()
+        evs[c + 1].record()
+        if not launched and c >= nchunks // 4:      # the probe covers the middle half of the loop
             L.check(lib.ff_clock_probe_launch(ctypes.c_double(0.5 * seconds * 1e6), side.cuda_stream), "ff_clock_probe_launch")
             launched = True
-    ev1.record()
     torch.cuda.synchronize()
     smi.stop()
     ghz, us = ctypes.c_double(0.0), ctypes.c_double(0.0)
     L.check(lib.ff_clock_probe_read(ctypes.byref(ghz), ctypes.byref(us), side.cuda_stream), "ff_clock_probe_read")
-    sec = ev0.elapsed_time(ev1) * 1e-3
-    tf = flops * iters / sec / 1e12
+    secs = sorted(evs[c].elapsed_time(evs[c + 1]) * 1e-3 for c in range(nchunks))
+    med = secs[len(secs) // 2]
+    steady = sum(1 for v in secs if v <= 1.05 * med) / float(len(secs))
+    tf = flops * ck / med / 1e12
     frac = tf / peak
-    print("| %s | %d | %.1f | %.3f | %.3f | %.3f | %s | %s |" % (
-        name, iters, tf, frac, ghz.value, frac * NOMINAL_GHZ / ghz.value if ghz.value > 0 else float("nan"), mmm(smi.power), mmm(smi.sclk)))
+    print("| %s | %d | %.1f | %.2f | %.3f | %.3f | %.3f | %s | %s |" % (
+        name, iters, tf, steady, frac, ghz.value, frac * NOMINAL_GHZ / ghz.value if ghz.value > 0 else float("nan"), mmm(smi.power),
+        mmm(smi.sclk)))
     sys.stdout.flush()
 
 
@@ -131,8 +142,8 @@ def main():
     print()
     print("idle probe (no other work queued): %.3f GHz over %.0f us" % (g.value, u.value))
     print()
-    print("| kernel, shape, operands | launches | TF/s (fp32-eq) | frac of peak @2.4 GHz | effective GHz | frac of peak @effective clock | board power W (min / mean / max) | SMI sclk MHz (min / mean / max) |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| kernel, shape, operands | launches | TF/s (fp32-eq, median 20-ms chunk) | chunks within 5 % of the median | frac of peak @2.4 GHz | effective GHz | frac of peak @effective clock | board power W (min / mean / max) | SMI sclk MHz (min / mean / max) |")
+    print("|---|---|---|---|---|---|---|---|---|")
     for fill in ("random", "zeros"):
         for M, K, N in ((16384, 512, 1536), (9216, 1024, 512)):   # (launches of >= 60 us: the Python loop stays ahead of the GPU;
             # the config-B-sized launches are probed in situ by bench.py: bf16x3_projections.roofline.effective_clock_ghz)
