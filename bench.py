@@ -274,7 +274,7 @@ def compact_line(result):
             if e.get("bf16x3_projections"):
                 oc[name]["bf16x3"] = _pick(e["bf16x3_projections"], ("value", "ms_per_step"))
         out["other_configs"] = oc
-    for k in ("rccl_ranks", "collective_backend", "rccl_version", "wireframes_per_s", "bench_seconds"):
+    for k in ("rehearsal", "rccl_ranks", "collective_backend", "rccl_version", "wireframes_per_s", "bench_seconds"):
         if k in result:
             out[k] = result[k]
     for k in ("weak_one_wireframe_per_gpu", "face_json_gather"):
@@ -330,6 +330,8 @@ def spawn_ranks(args):
         return 2
     if not args.dry_spawn:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if args.rehearse_on_one_device and have >= 1:
+            have = n
         if have < n:
             sys.stderr.write("bench.py: --gpus %d requested but %d ROCm device(s) visible on this node; refusing to run a "
                              "smaller configuration in its place\n" % (n, have))
@@ -417,6 +419,9 @@ def main():
                     help="launch plumbing only, no GPU: spawn --gpus ranks the way a real run does, build a gloo group, agree the "
                          "shard sizes with the collectives decode_sharded(local_shard=True) uses and print them as one JSON line")
     ap.add_argument("--no-json-gather", action="store_true", help="N > 1: skip the timed face-loop JSON gather (second figure)")
+    ap.add_argument("--rehearse-on-one-device", action="store_true",
+                    help="N > 1 on a ONE-GPU box: all ranks share device 0 and gloo is the collective backend (RCCL refuses two ranks "
+                         "on one device).  Runs every line of the N-rank code path; the figures are NOT a measurement (the line says so)")
     args = ap.parse_args()
     t_start = time.perf_counter()
 
@@ -437,6 +442,9 @@ def main():
     multi = world > 1 or args.force_dist   # the distributed code path
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the decode path has no CPU fallback)")
+    rehearsal = bool(args.rehearse_on_one_device and world > 1)
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -444,7 +452,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node by contract: the host-side control group of decode_sharded
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from faceformer_amd.config import load_cfg
     from faceformer_amd.dist import decode_sharded, gather_predictions
@@ -606,7 +617,10 @@ def main():
         except Exception:   # noqa: BLE001 - the version string is informational
             rv = None
         result["rccl_ranks"] = dist.get_world_size()          # what the collective library saw, not what --gpus asked for
-        result["collective_backend"] = "%s (RCCL on ROCm)" % dist.get_backend()
+        result["collective_backend"] = "%s (RCCL on ROCm)" % dist.get_backend() if not rehearsal else "gloo"
+        if rehearsal:
+            result["rehearsal"] = ("NOT A MEASUREMENT: --rehearse-on-one-device, %d ranks share device 0 and gloo moves the device "
+                                   "tensors; run to exercise the N-rank code path on a one-GPU box" % world)
         result["rccl_version"] = rv
     if sharded_c:
         result["scaling_series"] = {

@@ -28,16 +28,20 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, name, ret):
+def _worker(rank, world, port, name, ret, backend="nccl"):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     from conftest import batch_to, build_model
     from faceformer_amd import dist as ffd
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=dev)
+    index = rank if backend == "nccl" else 0      # gloo: both ranks share device 0 (RCCL refuses two ranks on one device)
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         case, z = load_golden(name)
         sd, batch = case_weights_and_batch(case)
@@ -78,6 +82,26 @@ def test_sharded_decode_on_two_gpus_over_rccl(hip_lib, name):
     assert dict(ret) == {0: True, 1: True}
 
 
+@pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak", "seq_small_gain4", "seq_small_repeat_eos"])
+def test_sharded_decode_of_two_ranks_sharing_one_gpu(hip_lib, name):
+    """World size 2 with the REAL engine on a one-GPU box: two processes, both on device 0, gloo as the collective backend (it
+    moves device tensors on this image: tools/gloo_cuda_probe.py).  Everything of the two-GPU test above except RCCL itself runs
+    with two ranks: each rank's own ff_decode with the batch-global F, the in-decode GLOBAL stop rule (the engine's stop callback
+    -> all-reduce of the step counters over the host-side group -> both engines leave the loop at the same step), the all-gather of
+    the int32 tokens, the length-prefixed JSON gather; results = the golden (single-process) tensors on both ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret, "gloo")) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_bench_distributed_code_path_runs_with_one_rank():
     """`bench.py --gpus N` (N > 1) takes a code path the one-GPU boxes never see: process group over RCCL,
     `decode_sharded(local_shard=True)`, max-over-ranks timing, the one-wireframe weak line.  `--force-dist` runs exactly
@@ -100,3 +124,27 @@ def test_bench_distributed_code_path_runs_with_one_rank():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert "decode_sharded(local_shard=True)" in d["config"]["workload"] and d["config"]["wireframes_per_gpu"] == 2
+
+
+def test_bench_two_rank_path_rehearsed_on_one_device():
+    """`bench.py --gpus 2` with both ranks on device 0 and gloo in RCCL's place (`--rehearse-on-one-device`), launched the way
+    the driver launches N > 1: every line of the two-rank bench path runs on a one-GPU box -- rendezvous, sharded decode with
+    the in-decode global stop rule, max-over-ranks timing, the one-wireframe weak line, the JSON gather, rank 0's roofline leg
+    while rank 1 waits -- and the line says that it is a rehearsal, not a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-device",
+           "--wireframes-per-gpu", "2", "--steps", "1", "--warmup", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 prints, rank 1 does not
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo" and "NOT A MEASUREMENT" in d["rehearsal"]
+    assert d["config"]["wireframes_per_gpu"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    for k in ("weak_one_wireframe_per_gpu", "face_json_gather", "roofline", "scaling_series"):
+        assert k in d, k
