@@ -345,6 +345,21 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (native libraries that write to stdout behind Python's back)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def dry_rank(args, rank, world):
     """--dry-spawn, one rank: the rendezvous, the process group (gloo: no device) and the metadata exchange of
     decode_sharded(local_shard=True) -- every rank contributes (F, wireframes held, padded width) -- then rank 0 prints
@@ -352,7 +367,8 @@ def dry_rank(args, rank, world):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    with stdout_to_stderr():      # ("[Gloo] Rank r is connected to ..." goes to stdout of every rank)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     cfgE = args.config == "E"
     W = args.wireframes_per_gpu or (32 if cfgE else (min(128, max(1, 1024 // world)) if world > 1 else 1))
     n_local = config_e_edge_counts(world * W)[rank * W:(rank + 1) * W] if cfgE else [args.edges] * W
@@ -452,10 +468,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node by contract: the host-side control group of decode_sharded
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # gloo's C++ side reports its connections on STDOUT of every rank ("[Gloo] Rank r is connected to ..."): stdout is the
+        # driver's one JSON line, so the groups (RCCL's and the host-side control twin of decode_sharded) are made with fd 1
+        # pointed at stderr
+        with stdout_to_stderr():
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            from faceformer_amd.dist import ensure_control_group
+            ensure_control_group(dist)
 
     from faceformer_amd.config import load_cfg
     from faceformer_amd.dist import decode_sharded, gather_predictions

@@ -143,6 +143,14 @@ def _control_group(dist_mod, group):
     return _CONTROL_GROUPS[key]
 
 
+def ensure_control_group(dist_mod, group=None):
+    """Create (or fetch) the host-side control group of decode_sharded NOW -- collective over the ranks of `group` like the first
+    decode_sharded call would be.  For callers that own their stdout: gloo's C++ side prints "[Gloo] Rank r is connected to ..."
+    on STDOUT of every rank when a group is made (bench.py prints exactly one line there and makes the group with fd 1 pointed at
+    stderr)."""
+    return _control_group(dist_mod, group)
+
+
 # A rank that fails inside a stop check must not leave its peers blocked for ever -- but the first check of an early (or
 # idle) rank also waits for its slowest peer to GET there (data loading, first-call library build, a very large shard), so the
 # limit is torch's own 30 minutes unless the caller shortens it: FF_CONTROL_TIMEOUT_S, or dist.CONTROL_TIMEOUT_S before the

@@ -20,7 +20,11 @@ def test_dry_spawn_builds_a_two_rank_group_and_plans_the_shards():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-spawn"], cwd=ROOT, env=_env(),
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    # stdout is the one line and nothing else: gloo's "[Gloo] Rank r is connected to ..." (written to fd 1 of every rank by its
+    # native side when a group is made) is sent to stderr
+    out = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and out[0].startswith("{"), p.stdout[:500]
+    d = json.loads(out[0])
     assert d["dry_spawn"] is True and d["n_gpus"] == 2 and d["ranks_in_group"] == 2 and d["backend"] == "gloo"
     assert d["shard_sizes"] == [128, 128] and d["global_batch"] == 256 and d["global_F"] == 256
 

@@ -141,8 +141,8 @@ def test_bench_two_rank_path_rehearsed_on_one_device():
            "--wireframes-per-gpu", "2", "--steps", "1", "--warmup", "1"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                  # rank 0 prints, rank 1 does not
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[:500]   # rank 0's line and nothing else (no "[Gloo] ..." chatter)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo" and "NOT A MEASUREMENT" in d["rehearsal"]
     assert d["config"]["wireframes_per_gpu"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
