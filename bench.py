@@ -28,10 +28,10 @@ The JSON line also carries
                  step) / its summed duration, measured with HIP events on the launch stream by the library's profiling
                  hooks, NET of the event bracket (ff_profile_bracket_us: the interval an event pair reports around an
                  empty kernel), against the 157.3 TF/s f32 matrix peak;
-  cpu_baseline : the CPU oracle (op-for-op restatement of the reference, oracle/refpath.py) timed on the host's physical
-                 cores on ONE FULL wireframe of the workload (all anchor sequences, all steps); if that does not finish
-                 within --cpu-timeout, a 32-anchor sample of the same wireframe (sequences are independent, so the
-                 sample is faithful) -- `sample` says which; `first_divergence` names the first (sequence, step) at
+  cpu_baseline : the CPU oracle (op-for-op restatement of the reference, oracle/refpath.py) timed on min(physical cores, 32)
+                 host threads on a bounded sample of the workload: the first 128 anchor sequences of ONE wireframe, all steps
+                 (~22 s; --cpu-anchors 256 = the full wireframe; if it does not finish within --cpu-timeout, 32 anchors;
+                 sequences are independent, so the sample is faithful) -- `sample` says which; `first_divergence` names the first (sequence, step) at
                  which the GPU's tokens leave the oracle's, with the oracle's own top-2 margin there and the tolerance.
 """
 import argparse
@@ -413,7 +413,7 @@ def main():
     ap.add_argument("--no-dedup", action="store_true", help="decode every padding-anchor row like the reference does")
     ap.add_argument("--sync-every", type=int, default=1, help="host stop-rule check period in steps (0 = never; package default 1)")
     ap.add_argument("--cpu-anchors", type=int, default=0,
-                    help="anchor sequences in the CPU baseline (0 = all: the FULL wireframe, SURVEY 8d)")
+                    help="anchor sequences in the CPU baseline (0 = the first 128: ~22 s of CPU work; 256 = the FULL wireframe, ~44 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU oracle (0 = physical cores, at most 32)")
     ap.add_argument("--cpu-timeout", type=int, default=200, help="wall-clock cap of the CPU baseline [s]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -751,7 +751,7 @@ def main():
         # The oracle runs in child processes with hard wall-clock caps.  Threads: SURVEY 8(d) says all physical cores, but
         # torch's CPU eager path gets SLOWER beyond ~32 threads for these operator sizes (measured on the MI355X host:
         # 256 threads 1.4 edges/s, 64 threads 133, 32 threads 165-245; 128 threads: no result within 3 x the 32-thread time
-        # in every run of round 5).  The FULL wireframe runs at min(physical cores, 32) threads (`cores`); a 16-anchor
+        # in every run of round 5).  The baseline sample runs at min(physical cores, 32) threads (`cores`); a 16-anchor
         # sample is timed at that setting and at all physical cores afterwards (`threads_sweep`).
         import subprocess
         n_cpu = n_local[0] if not cfgE else min(n_local)      # config E: the smallest wireframe of the shard
@@ -801,12 +801,14 @@ def main():
         cpu_raw = {"sweep": {}, "tried": [], "rec": None, "k": None, "threads": threads, "rec_a": None}
 
         def cpu_job():
-            """The FULL wireframe (and config A's sizes) on a host thread BESIDE the GPU measurement of `other_configs.C128`
+            """The baseline sample (and config A's sizes) on a host thread BESIDE the GPU measurement of `other_configs.C128`
             only: C128 is GPU-bound (5.6 s per pass, unchanged beside 32 busy host threads), the launch-bound entries are not
             (profiles/r05: D 111.7 -> 133.2 ms beside 32 threads, E32 1318 -> 1788 ms beside the 128-thread sweep child), so
             they run first and the thread sweep runs after everything else, alone."""
             th_full = cpu_raw["threads"]
-            for k in ([args.cpu_anchors] if args.cpu_anchors > 0 else [n_cpu, 32]):
+            # (bounded sample: the first 128 anchor sequences are ~22 s at 32 threads and end with the GPU's C128 passes; the full
+            # wireframe -- 44 s, --cpu-anchors 256 -- was the default until round 5 and kept the whole run 20 s longer)
+            for k in ([args.cpu_anchors] if args.cpu_anchors > 0 else [min(n_cpu, 128), 32]):
                 k = max(1, min(k, n_cpu))
                 try:
                     cpu_raw["rec"] = run_cpu_child(child_code(k, th_full), args.cpu_timeout, th_full)
@@ -823,13 +825,13 @@ def main():
         def cpu_sweep():
             """SURVEY 8(d) says all physical cores; torch's CPU eager path is slower beyond ~32 threads for these operator
             sizes.  The first 16 anchor sequences at 32 threads and at all physical cores, alone on the host (after every GPU
-            measurement); the second setting gets 3 x the time of the first -- slower than that it cannot win."""
+            measurement); the second setting gets 2 x the time of the first -- slower than that it cannot win."""
             if not (args.cpu_threads <= 0 and phys > cpu_raw["threads"] and not args.cpu_anchors):
                 return
             ks = max(1, min(16, n_cpu))
             t_first = None
             for th in (cpu_raw["threads"], phys):
-                cap = 60 if t_first is None else max(8, int(3 * t_first) + 4)
+                cap = 60 if t_first is None else max(8, int(2 * t_first) + 3)
                 t0_ = time.perf_counter()
                 try:
                     r_ = run_cpu_child(child_code(ks, th), cap, th)
