@@ -148,3 +148,68 @@ def test_bench_two_rank_path_rehearsed_on_one_device():
     assert d["config"]["wireframes_per_gpu"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     for k in ("weak_one_wireframe_per_gpu", "face_json_gather", "roofline", "scaling_series"):
         assert k in d, k
+
+
+def _cli_setup(root):
+    """Five small wireframes + config + Lightning-style checkpoint of a small parallel model (as tests/test_cli.py)."""
+    import json
+    sys.path.insert(0, ROOT)
+    from faceformer_amd.config import load_cfg
+    from faceformer_amd.synth import make_state_dict, state_dict_spec
+    os.makedirs(os.path.join(root, "json"), exist_ok=True)
+    rng = np.random.default_rng(11)
+    names = []
+    for i in range(5):
+        n = 7 + 2 * i
+        raw = {"edges": [rng.uniform(-1, 1, size=(2, 2)).tolist() for _ in range(n)],
+               "faces_indices": [[0, [[0, 1, 2]]], [1, [[3, 4, 5, 6]]]], "pairings": {}, "dominant_directions": [[1, 0, 0]]}
+        with open(os.path.join(root, "json", "%08d.json" % i), "w") as f:
+            json.dump(raw, f)
+        names.append("json/%08d.json" % i)
+    with open(os.path.join(root, "test.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    cfg = load_cfg(os.path.join(ROOT, "configs", "ours.yml"),
+                   ["model.num_lines", "16", "model.max_face_length", "8", "model.num_model", "128", "model.num_head", "2",
+                    "model.num_feedforward", "256", "model.num_encoder_layers", "2", "model.num_decoder_layers", "2",
+                    "root_dir", str(root), "post_process.is_coedge", "False"])
+    ckpt = os.path.join(root, "last.ckpt")
+    if not os.path.exists(ckpt):
+        sd = make_state_dict(state_dict_spec("parallel", 16, 8, 128, 256, 2, 2), "gain4", 3)
+        torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "hyper_parameters": dict(cfg)}, ckpt)
+    return cfg, ckpt
+
+
+def _cli_rank(rank, world, port, root, out):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import main as cli
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        cfg, ckpt = _cli_setup(root)
+        cli.run_test(cfg, ckpt, out_dir=out, device="cuda", batch_size=2, dist_mod=dist)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cli_two_ranks_sharing_one_gpu_write_the_single_process_files(hip_lib, tmp_path):
+    """main.py's test branch with two processes on device 0 (gloo): contiguous shares of the test list (3 + 2 samples), each
+    rank's own engine, the records gathered as length-prefixed bytes, rank 0 writes -- the files of the one-process run."""
+    sys.path.insert(0, ROOT)
+    import main as cli
+    root = str(tmp_path / "data")
+    cfg, ckpt = _cli_setup(root)
+    one = cli.run_test(cfg, ckpt, out_dir=str(tmp_path / "one"), device="cuda", batch_size=1)
+    ref = {n: open(os.path.join(one, n), "rb").read() for n in sorted(os.listdir(one))}
+    assert len(ref) == 5
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    out = str(tmp_path / "two")
+    procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, root, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert {n: open(os.path.join(out, n), "rb").read() for n in sorted(os.listdir(out))} == ref
