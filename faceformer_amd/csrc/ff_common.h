@@ -78,6 +78,8 @@ struct ff_pointer_sync {
   int* arrive;      // device int, zero before the launch: arrivals of the launch's sequences
   int* host_slot;   // device-visible address of a host-mapped pinned int: receives the launch's counter
   int host_which;   // 0: count_ge, 1: count_eq
+  float* next_stats;  // [B, E/32, 2] or null: (mean, M2) per 32-column segment of the rows written to next_rows -- the
+                      // LayerNorm statistics the folded layer-0 projection of the NEXT step consumes (ff_gemm_f32_ln)
 };
 int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, int E, const unsigned char* mask,
                            const int* kv_len, const unsigned char* extra_mask, int ldextra, int B, int seqs_per_group,

@@ -679,6 +679,7 @@ struct PointerArgs {
   int* arrive;      // arrivals of this launch's B sequences (zeroed before the decode)
   int* host_slot;   // host-mapped pinned int: the last sequence to arrive stores the launch's counter there (system scope)
   int host_which;   // 0: count_ge, 1: count_eq
+  float* next_stats;  // [B, E/32, 2] or null: LayerNorm segment statistics of the appended rows (E % 32 == 0)
 };
 
 // Stop-rule counters of the (up to four) sequences a 256-thread block has finished, by ONE thread of the block: one atomic per
@@ -750,8 +751,27 @@ __device__ __forceinline__ int ff_pointer_reduce_row(const PointerArgs& a, int b
   if (a.next_rows) {
     const float* src = a.memory + ((size_t)w * a.S + i1) * a.E;
     float* dst = a.next_rows + (size_t)b * a.ldnext;
-    for (int vi = lane; vi < (a.E >> 2); vi += 64)
-      ff_st16(dst + vi * 4, ff_ldw16(src + vi * 4));
+    if (!a.next_stats) {
+      for (int vi = lane; vi < (a.E >> 2); vi += 64)
+        ff_st16(dst + vi * 4, ff_ldw16(src + vi * 4));
+    } else {
+      // the same copy, leaving (mean, M2) of every 32-column segment of the row (two passes like the LayerNorm kernel and the
+      // statistics-producing GEMM epilogue): a segment is the 8 float4 of 8 consecutive lanes
+      float* sdst = a.next_stats + (size_t)b * (a.E >> 5) * 2;
+      for (int v0 = 0; v0 < (a.E >> 2); v0 += 64) {      // (wave-uniform bound: the shuffles below need every lane)
+        const int vi = v0 + lane;
+        const bool in = vi < (a.E >> 2);
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (in) { x = ff_ldw16(src + vi * 4); ff_st16(dst + vi * 4, x); }
+        float sm = (x.x + x.y) + (x.z + x.w);
+        sm += __shfl_xor(sm, 1, FF_WAVE); sm += __shfl_xor(sm, 2, FF_WAVE); sm += __shfl_xor(sm, 4, FF_WAVE);
+        const float mean = sm * (1.0f / 32.0f);
+        const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+        float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        m2 += __shfl_xor(m2, 1, FF_WAVE); m2 += __shfl_xor(m2, 2, FF_WAVE); m2 += __shfl_xor(m2, 4, FF_WAVE);
+        if (in && (lane & 7) == 0) ff_st8(sdst + (vi >> 3) * 2, f32x2{mean, m2});
+      }
+    }
   }
   return i1;
 }

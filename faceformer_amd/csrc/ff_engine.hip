@@ -150,6 +150,7 @@ struct Scratch {
 struct DecodeBuffers {
   float *mem_pos, *kvc[FF_MAX_LAYERS];
   float *x0_all, *qkv0_all;
+  float* x0stat_all;   // [Btot, E/32, 2] LayerNorm segment statistics of the NEWEST x0 rows (written by the pointer launches)
   int* tok_all;   // [T, Btot] global, position-major
   Scratch scr[FF_MAX_STREAMS];
   int *cnt_ge, *cnt_eq;   // [T, nch] per (step, micro-batch)
@@ -166,6 +167,7 @@ struct Chunk {
   int w0, nw, Fc, f0, b0, Bc, sid;
   float* x0;     // [T, Bc, E]
   float* qkv0;   // [T, Bc, 3E] or null
+  float* x0stat; // [Bc, E/32, 2] statistics of the rows the last pointer launch appended to x0, or null
 };
 
 // Compact width of wireframe w: its num_input real anchors plus ONE padding-anchor sequence when it has fewer
@@ -210,7 +212,7 @@ void plan_chunks(const ff_decode_params* p, const int* num_input_host, int ns, s
       c.Fc = (Fm - f0) < fstep ? (Fm - f0) : fstep;
       c.b0 = b0; c.Bc = nw * c.Fc;
       c.sid = (int)(out ? out->size() % (size_t)ns : 0);
-      c.x0 = nullptr; c.qkv0 = nullptr;
+      c.x0 = nullptr; c.qkv0 = nullptr; c.x0stat = nullptr;
       b0 += c.Bc;
       mx = c.Bc > mx ? c.Bc : mx;
       ++nc;
@@ -228,6 +230,8 @@ int plan_streams(const ff_decode_params* p) {
 }
 
 // Workspace layout for `btot` compact sequences in micro-batches of at most `max_bc`.
+bool can_fuse_layernorm(const ff_model* m, const ff_decode_params* prm);
+
 size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, size_t Bch, size_t nch, Bump& bp,
                      DecodeBuffers* out) {
   const int E = m->E, FFd = m->FF, S = p->L + m->num_token, T = p->T;
@@ -240,6 +244,10 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, 
   b.x0_all = bp.take<float>((size_t)T * Btot * E);
   b.tok_all = bp.take<int>((size_t)T * Btot);
   b.qkv0_all = (p->flags & FF_REUSE_LAYER0_QKV) ? bp.take<float>((size_t)T * Btot * 3 * E) : nullptr;
+  // (FF_L0_FOLD=0: the newest rows' LayerNorm as its own launch, as before round 5 -- A/B runs and tests of that form)
+  static const bool l0_fold = !(getenv("FF_L0_FOLD") && atoi(getenv("FF_L0_FOLD")) == 0);
+  b.x0stat_all = (l0_fold && (p->flags & FF_REUSE_LAYER0_QKV) && can_fuse_layernorm(m, p)) ? bp.take<float>(Btot * (size_t)(E / 32) * 2)
+                                                                                 : nullptr;   // (size query: take() returns null)
   for (int s = 0; s < ns; ++s) {
     Scratch& c = b.scr[s];
     c.x = bp.take<float>(Rmax * E);
@@ -347,10 +355,19 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     const float* QKV;
     // ---- self attention: q = k = LN1(x) + qpos, v = LN1(x), no mask (transformer.py:242-246) ----
     if (l == 0 && reuse0) {
-      FF_RETURN_IF(ff_layernorm(xin + newoff * E, E, w.norm1_w, w.norm1_b, m->ln_eps, buf.y, E, buf.yq, E,
-                                qpos_new, E, Bc, 1, Bc, E, st));
-      FF_RETURN_IF(gemm(buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
-                        ck.qkv0 + newoff * 3 * E, 3 * E, Bc, 3 * E, E, 0, st));
+      if (full_rows) {
+        // (the pass behind the loop: every position < t went through a decode step, its layer-0 q|k|v is in the cache)
+      } else if (fuse && t > 1 && ck.x0stat) {
+        // the newest rows were appended by the previous step's pointer launch together with their segment statistics: the
+        // folded projection normalises them itself (no LayerNorm launch left in a decode step after the first)
+        FF_RETURN_IF(gemm_ln(xin + newoff * E, E, w.ln1_w, E, w.ln1_b, nullptr, 0, ck.qkv0 + newoff * 3 * E, 3 * E, Bc, 3 * E, E,
+                             0, ck.x0stat, w.ln1_pos + (size_t)(t - 1) * 2 * E, 2 * E, 2 * E, nullptr));
+      } else {
+        FF_RETURN_IF(ff_layernorm(xin + newoff * E, E, w.norm1_w, w.norm1_b, m->ln_eps, buf.y, E, buf.yq, E,
+                                  qpos_new, E, Bc, 1, Bc, E, st));
+        FF_RETURN_IF(gemm(buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
+                          ck.qkv0 + newoff * 3 * E, 3 * E, Bc, 3 * E, E, 0, st));
+      }
       QKV = ck.qkv0;
     } else if (fuse && l > 0) {
       FF_RETURN_IF(first_proj(l));
@@ -643,6 +660,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   for (Chunk& c : chunks) {
     c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
     c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
+    c.x0stat = buf.x0stat_all ? buf.x0stat_all + (size_t)c.b0 * (E / 32) * 2 : nullptr;
   }
   const int ns = ns_req < (int)chunks.size() ? ns_req : (int)chunks.size();
   const bool forked = ns > 1;
@@ -733,7 +751,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
         const size_t trow = (size_t)step * ((size_t)N * F) + c.b0;  // traces: step stride N*F (caller sizes them so)
         const size_t slot = (size_t)step * nch + (size_t)(&c - chunks.data());
         ff_pointer_sync psync{each_eos ? buf.seen + c.b0 : nullptr, lagged ? buf.arrive + slot : nullptr,
-                              lagged ? pool->hpin_dev + slot : nullptr, p->variant == FF_PARALLEL ? 0 : 1};
+                              lagged ? pool->hpin_dev + slot : nullptr, p->variant == FF_PARALLEL ? 0 : 1, c.x0stat};
         auto pointer_head = [&]() -> int {
           return ff_pointer_argmax_sync(
               sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
@@ -741,7 +759,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
               buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
               trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
               c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + slot, m->num_token, buf.cnt_eq + slot, p->tok_eos,
-              (each_eos || lagged) ? &psync : nullptr, st);
+              (each_eos || lagged || c.x0stat) ? &psync : nullptr, st);
         };
         FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
         FF_RETURN_IF(pointer_head());

@@ -173,7 +173,7 @@ int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, 
                 next_tok, best, second, logits, ldlogits, next_rows, ldnext,
                 count_ge, ge_bound, count_eq, eq_value,
                 sync ? sync->seen : nullptr, sync ? sync->arrive : nullptr, sync ? sync->host_slot : nullptr,
-                sync ? sync->host_which : 0};
+                sync ? sync->host_which : 0, sync ? sync->next_stats : nullptr};
   FF_CHECK_ARG(!a.arrive || (a.host_slot && (a.host_which ? count_eq : count_ge)), "ff_pointer_argmax: counter hand-over without a counter");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ff_cdiv(B, 4)), block(256);

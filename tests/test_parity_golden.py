@@ -468,6 +468,43 @@ def test_stop_rule_without_host_slots_drains_and_copies(hip_lib):
     assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-2000:]
 
 
+def test_decode_steps_after_the_first_launch_no_layernorm(hip_lib):
+    """Round 5: the pointer launch that appends a step's input rows also leaves their LayerNorm segment statistics, so the
+    layer-0 q|k|v projection of the next step normalises them itself (ff_gemm_f32_ln) like every other projection of the
+    decoder.  Counted with the library's profiling hooks on a golden: the standalone LayerNorm kernel runs in the encoder
+    (2 per layer + the final norm) and in decode step 1 (rows from init_tokens_kernel) only; FF_L0_FOLD=0 in a child process
+    (the previous form, one launch per step more) passes the same parity checks."""
+    import ctypes
+    import subprocess
+    import sys
+    case, z = load_golden("par_small_gain4")
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    b = batch_to(batch, "cuda")
+    with torch.no_grad():
+        pred = model(dict(b))["predict"]
+    assert np.array_equal(pred.cpu().numpy(), z["predict"])
+    ncat = 7
+    ms, work, cnt = (ctypes.c_double * ncat)(), (ctypes.c_double * ncat)(), (ctypes.c_longlong * ncat)()
+    torch.cuda.synchronize()
+    hip_lib.ff_profile_begin()
+    with torch.no_grad():
+        model(dict(b))
+    assert hip_lib.ff_profile_end(ms, work, cnt, ncat) == 0
+    n_enc = case["model"]["enc"]
+    steps = int((z["predict"].reshape(-1, z["predict"].shape[-1])[:, 1:] != 0).any(axis=0).nonzero()[0].max()) + 1
+    assert steps >= 3
+    ln = int(cnt[2])                         # category 2 = layernorm_kernel (bench.py CAT_NAMES)
+    # encoder (2 per layer + final norm) + step 1 of every micro-batch (wireframes of different compact width decode apart);
+    # one more per step and micro-batch in the previous form
+    assert 2 * n_enc + 1 < ln <= 2 * n_enc + 1 + len(case["n_edges"]) < 2 * n_enc + 1 + steps, (ln, n_enc, steps)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_golden.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_golden_parity and (par_small_gain4 or seq_small_gain4 or par_small_ragged or seq_small_eos)"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, FF_L0_FOLD="0"))
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-1000:]
+
+
 def test_json_gather_over_rccl(hip_lib, tmp_path):
     """The north-star's 'RCCL all-gather of predicted face-loop JSON': decode_to_face_json on the nccl backend
     (world size 1 on this box; the gloo tests cover world sizes 2 and 3) incl. the co-edge post-processing
