@@ -340,9 +340,14 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
 
   // the LayerNorm-folded projection over all R rows that opens layer l2 > 0: q|k|v, or k|v alone when the layer is pruned to
   // its newest position (its q then covers Bc rows only)
+  // The pruned last layer needs k | v of every row and q of the newest position only: two launches.  On launch-bound steps
+  // (few rows) ONE q | k | v launch over all rows is cheaper than the second launch it saves (FF_LAST_QKV_ONE_LAUNCH_ROWS: up
+  // to this many active rows; 0 = never); the q of the older rows is computed and not used.
+  static const int one_launch_rows = getenv("FF_LAST_QKV_ONE_LAUNCH_ROWS") ? atoi(getenv("FF_LAST_QKV_ONE_LAUNCH_ROWS")) : 512;
+  const bool last_qkv_one = R <= one_launch_rows;
   auto first_proj = [&](int l2) -> int {
     const ff_layer_weights& w2 = m->dec[l2];
-    if (prune_last && l2 == nd - 1 && t > 1)
+    if (prune_last && l2 == nd - 1 && t > 1 && !last_qkv_one)
       return gemm_ln(buf.x, E, w2.ln1_w + (size_t)E * E, E, w2.ln1_b + E, nullptr, 0, buf.qkv + E, 3 * E, R, 2 * E, E, 0,
                      buf.lnstat, w2.ln1_pos + E, 2 * E, E, nullptr, w2.ln1_planes, 3 * E, E, w2.ln1_csum);
     return gemm_ln(buf.x, E, w2.ln1_w, E, w2.ln1_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, buf.lnstat, w2.ln1_pos, 2 * E,
@@ -371,7 +376,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
       QKV = ck.qkv0;
     } else if (fuse && l > 0) {
       FF_RETURN_IF(first_proj(l));
-      if (last && t > 1) {
+      if (last && t > 1 && !last_qkv_one) {
         // the pruned last layer attends from its newest position only: k | v for every row (above), q for the last Bc rows
         FF_RETURN_IF(gemm_ln(xin + newoff * E, E, w.ln1_w, E, w.ln1_b, nullptr, 0, buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E,
                              0, buf.lnstat + newoff * nseg * 2, w.ln1_pos + (size_t)(t - 1) * 2 * E, 2 * E, E, nullptr));
