@@ -80,12 +80,16 @@ struct ff_pointer_sync {
   int host_which;   // 0: count_ge, 1: count_eq
   float* next_stats;  // [B, E/32, 2] or null: (mean, M2) per 32-column segment of the rows written to next_rows -- the
                       // LayerNorm statistics the folded layer-0 projection of the NEXT step consumes (ff_gemm_f32_ln)
+  int logits_ready;   // 1: `logits` already holds the raw dot products (the engine's folded project + pointer GEMM): p is not read
 };
 int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, int E, const unsigned char* mask,
                            const int* kv_len, const unsigned char* extra_mask, int ldextra, int B, int seqs_per_group,
                            int* next_tok, float* best, float* second, float* logits, int ldlogits, float* next_rows,
                            int ldnext, int* count_ge, int ge_bound, int* count_eq, int eq_value,
                            const ff_pointer_sync* sync, ff_stream_t stream);
+
+// out[c, r] = in[r, c] for an [rows, cols] fp32 matrix (ff_rowops.hip; the engine's per-call transposes)
+int ff_transpose(const float* in, int ld_in, int rows, int cols, float* out, int ld_out, hipStream_t st);
 
 // partial-tile workspace of the 3 x bf16 kernel for (current device, stream): allocate now (ff_gemm_x3.hip)
 extern "C" int ff_x3_prepare_stream(hipStream_t st);

@@ -151,6 +151,8 @@ struct DecodeBuffers {
   float *mem_pos, *kvc[FF_MAX_LAYERS];
   float *x0_all, *qkv0_all;
   float* x0stat_all;   // [Btot, E/32, 2] LayerNorm segment statistics of the NEWEST x0 rows (written by the pointer launches)
+  float *projT, *pg_all, *pc_all;   // folded project + pointer GEMM of one-wireframe micro-batches (see pointer_fold): the transposed
+                                    // folded project weight [E, E]; per micro-batch G = memory_w W' [S, E] and c = memory_w b' [S4]
   int* tok_all;   // [T, Btot] global, position-major
   Scratch scr[FF_MAX_STREAMS];
   int *cnt_ge, *cnt_eq;   // [T, nch] per (step, micro-batch)
@@ -168,6 +170,7 @@ struct Chunk {
   float* x0;     // [T, Bc, E]
   float* qkv0;   // [T, Bc, 3E] or null
   float* x0stat; // [Bc, E/32, 2] statistics of the rows the last pointer launch appended to x0, or null
+  float *pg, *pc; // one-wireframe micro-batch with the folded forms bound: G [S, E] and c [S] (logits = LN(x) G^T + c), or null
 };
 
 // Compact width of wireframe w: its num_input real anchors plus ONE padding-anchor sequence when it has fewer
@@ -212,7 +215,7 @@ void plan_chunks(const ff_decode_params* p, const int* num_input_host, int ns, s
       c.Fc = (Fm - f0) < fstep ? (Fm - f0) : fstep;
       c.b0 = b0; c.Bc = nw * c.Fc;
       c.sid = (int)(out ? out->size() % (size_t)ns : 0);
-      c.x0 = nullptr; c.qkv0 = nullptr; c.x0stat = nullptr;
+      c.x0 = nullptr; c.qkv0 = nullptr; c.x0stat = nullptr; c.pg = nullptr; c.pc = nullptr;
       b0 += c.Bc;
       mx = c.Bc > mx ? c.Bc : mx;
       ++nc;
@@ -248,6 +251,12 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, 
   static const bool l0_fold = !(getenv("FF_L0_FOLD") && atoi(getenv("FF_L0_FOLD")) == 0);
   b.x0stat_all = (l0_fold && (p->flags & FF_REUSE_LAYER0_QKV) && can_fuse_layernorm(m, p)) ? bp.take<float>(Btot * (size_t)(E / 32) * 2)
                                                                                  : nullptr;   // (size query: take() returns null)
+  // (FF_POINTER_FOLD=0: project and the pointer GEMM as two launches, as before round 5)
+  static const bool pointer_fold = !(getenv("FF_POINTER_FOLD") && atoi(getenv("FF_POINTER_FOLD")) == 0);
+  const bool pf = pointer_fold && can_fuse_layernorm(m, p);
+  b.projT = pf ? bp.take<float>((size_t)E * E) : nullptr;
+  b.pg_all = pf ? bp.take<float>(nch * (size_t)S * E) : nullptr;
+  b.pc_all = pf ? bp.take<float>(nch * (size_t)((S + 3) & ~3)) : nullptr;
   for (int s = 0; s < ns; ++s) {
     Scratch& c = b.scr[s];
     c.x = bp.take<float>(Rmax * E);
@@ -282,6 +291,20 @@ bool can_fuse_layernorm(const ff_model* m, const ff_decode_params* prm) {
   return true;
 }
 
+// Does a decode step with R active rows take the LayerNorm-folded projections?  (decoder_pass and the engine loop ask.)
+bool step_fuses(const ff_model* m, const ff_decode_params* prm, long R) {
+  const int nd = m->num_dec_layers, E = m->E;
+  const bool x3_bound = prm->x3_min_rows > 0 && nd > 0 && m->dec[0].in_proj_planes != nullptr;
+  const bool x3_folds = x3_bound && m->dec[0].ln1_planes != nullptr && m->dec[0].ln2_planes != nullptr &&
+                        m->dec[0].ln3_planes != nullptr && E == 512;
+  // f32 only: since round 4 the LDS-DMA kernel of the f32 family carries the folded forms at every size too (K = E = 512), so
+  // the steps fold at every size as well (128 wireframes per call: 5 053 -> 301 LayerNorm launches, 206 -> 214 k selections/s).
+  const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows
+                       : ((x3_folds || (!x3_bound && E == 512)) ? (1 << 30)
+                          : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288));
+  return can_fuse_layernorm(m, prm) && R <= fuse_max;
+}
+
 // One decoder pass over the current prefix (t positions) of one micro-batch.
 // full_rows: evaluate every layer for all rows and project all rows into proj_all (ld = E rows
 // position-major within the chunk); otherwise the result is p[Bc, E] for the newest position.
@@ -292,7 +315,7 @@ bool can_fuse_layernorm(const ff_model* m, const ff_decode_params* prm) {
 // folded weights (ff_gemm_f32_ln).  19 -> 1 LayerNorm launches per decode step of a 6-layer decoder.
 int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuffers& bufs, const Scratch& buf,
                  const Chunk& ck, const unsigned char* mask, const int* kv_len, int t, bool full_rows,
-                 float* proj_all, hipStream_t st) {
+                 float* proj_all, hipStream_t st, float* logits_out = nullptr) {
   const int E = m->E, FFd = m->FF, H = m->H, S = prm->L + m->num_token, F = ck.Fc, T = prm->T;
   const int Bc = ck.Bc, R = t * Bc, nd = m->num_dec_layers;
   const size_t newoff = (size_t)(t - 1) * Bc;
@@ -307,15 +330,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   // has no folded form, and LayerNorm + split product beats the folded f32 forms there (config B 60.1 vs 61.9 ms).
   // Round 4: the 3 x bf16 kernel has the folded forms as well (ff_gemm_x3_ln).  With the planes of the folded weights bound the
   // steps fold at EVERY size (the large launches then take the split kernel, which has no 128x64-tile problem).
-  const bool x3_bound = prm->x3_min_rows > 0 && nd > 0 && m->dec[0].in_proj_planes != nullptr;
-  const bool x3_folds = x3_bound && m->dec[0].ln1_planes != nullptr && m->dec[0].ln2_planes != nullptr &&
-                        m->dec[0].ln3_planes != nullptr && E == 512;
-  // f32 only: since round 4 the LDS-DMA kernel of the f32 family carries the folded forms at every size too (K = E = 512), so
-  // the steps fold at every size as well (128 wireframes per call: 5 053 -> 301 LayerNorm launches, 206 -> 214 k selections/s).
-  const int fuse_max = prm->ln_fuse_max_rows > 0 ? prm->ln_fuse_max_rows
-                       : ((x3_folds || (!x3_bound && E == 512)) ? (1 << 30)
-                          : (x3_bound && prm->x3_min_rows - 1 < 12288 ? prm->x3_min_rows - 1 : 12288));
-  const bool fuse = can_fuse_layernorm(m, prm) && R <= fuse_max;
+  const bool fuse = step_fuses(m, prm, R);
   const int nseg = E / 32;
   const float* qpos = m->qpos_table;
   const float* qpos_new = qpos + (size_t)(t - 1) * E;
@@ -479,6 +494,11 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
     if (full_rows)
       FF_RETURN_IF(gemm_ln(buf.x, E, m->proj_fold_w, E, m->proj_fold_b, nullptr, 0, proj_all, E, R, E, E, 0, buf.lnstat,
                            nullptr, 0, 0, nullptr));
+    else if (logits_out && ck.pg)
+      // pointer_fold: logits = <project(LN(x)), memory_s> = LN(x) (memory W')^T + memory b' -- ONE launch for decoder.norm,
+      // project and the pointer's dot products of a one-wireframe micro-batch (G and c are made once per call)
+      FF_RETURN_IF(gemm_ln(buf.x + newoff * E, E, ck.pg, E, ck.pc, nullptr, 0, logits_out, S, Bc, S, E, 0,
+                           buf.lnstat + newoff * nseg * 2, nullptr, 0, 0, nullptr));
     else
       FF_RETURN_IF(gemm_ln(buf.x + newoff * E, E, m->proj_fold_w, E, m->proj_fold_b, nullptr, 0, buf.p, E, Bc, E, E, 0,
                            buf.lnstat + newoff * nseg * 2, nullptr, 0, 0, nullptr));
@@ -666,6 +686,10 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
     c.qkv0 = buf.qkv0_all ? buf.qkv0_all + (size_t)T * c.b0 * 3 * E : nullptr;
     c.x0stat = buf.x0stat_all ? buf.x0stat_all + (size_t)c.b0 * (E / 32) * 2 : nullptr;
+    const size_t ci = (size_t)(&c - chunks.data());
+    const bool one = c.nw == 1 && buf.pg_all != nullptr;
+    c.pg = one ? buf.pg_all + ci * (size_t)(p->L + m->num_token) * E : nullptr;
+    c.pc = one ? buf.pc_all + ci * (size_t)((p->L + m->num_token + 3) & ~3) : nullptr;
   }
   const int ns = ns_req < (int)chunks.size() ? ns_req : (int)chunks.size();
   const bool forked = ns > 1;
@@ -706,6 +730,23 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     if (forked) {  // fork
       FF_CHECK_HIP(hipEventRecord(pool->fork_ev, main_st));
       for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], pool->fork_ev, 0));
+    }
+    // pointer_fold operands of the one-wireframe micro-batches: G = memory_w W' ([S, E]; W' = the folded project weight, used
+    // transposed), c = memory_w b'
+    bool any_pg = false;
+    for (const Chunk& c : chunks) any_pg = any_pg || c.pg != nullptr;
+    if (any_pg) {
+      FF_RETURN_IF(ff_transpose(m->proj_fold_w, E, E, E, buf.projT, E, main_st));
+      if (forked) {
+        FF_CHECK_HIP(hipEventRecord(pool->fork_ev, main_st));
+        for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], pool->fork_ev, 0));
+      }
+      for (const Chunk& c : chunks) {
+        if (!c.pg) continue;
+        const float* mem_w = memory + (size_t)c.w0 * S * E;
+        FF_RETURN_IF(gemm(mem_w, E, nullptr, 0, buf.projT, E, nullptr, nullptr, 0, c.pg, E, S, E, E, 0, sts[c.sid]));
+        FF_RETURN_IF(gemm(mem_w, E, nullptr, 0, m->proj_fold_b, E, nullptr, nullptr, 0, c.pc, 1, S, 1, E, 0, sts[c.sid]));
+      }
     }
     // start tokens (anchors / SOS) and first decoder input rows of every micro-batch
     for (const Chunk& c : chunks) {
@@ -755,18 +796,21 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
         const Scratch& sc = buf.scr[c.sid];
         const size_t trow = (size_t)step * ((size_t)N * F) + c.b0;  // traces: step stride N*F (caller sizes them so)
         const size_t slot = (size_t)step * nch + (size_t)(&c - chunks.data());
+        const bool folded_head = c.pg != nullptr && step_fuses(m, p, (long)t * c.Bc);
+        float* logits_dst = trace_logits ? trace_logits + trow * S : sc.logits;
         ff_pointer_sync psync{each_eos ? buf.seen + c.b0 : nullptr, lagged ? buf.arrive + slot : nullptr,
-                              lagged ? pool->hpin_dev + slot : nullptr, p->variant == FF_PARALLEL ? 0 : 1, c.x0stat};
+                              lagged ? pool->hpin_dev + slot : nullptr, p->variant == FF_PARALLEL ? 0 : 1, c.x0stat,
+                              folded_head ? 1 : 0};
         auto pointer_head = [&]() -> int {
           return ff_pointer_argmax_sync(
-              sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
+              folded_head ? nullptr : sc.p, E, memory + (size_t)c.w0 * S * E, S, E, mask + (size_t)c.w0 * S, kv_len + c.w0,
               extra_mask ? extra_mask + (size_t)c.b0 * S : nullptr, S, c.Bc, c.Fc,
               buf.tok_all + (size_t)t * Btot + c.b0, trace_best ? trace_best + trow : nullptr,
-              trace_second ? trace_second + trow : nullptr, trace_logits ? trace_logits + trow * S : sc.logits, S,
+              trace_second ? trace_second + trow : nullptr, logits_dst, S,
               c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + slot, m->num_token, buf.cnt_eq + slot, p->tok_eos,
-              (each_eos || lagged || c.x0stat) ? &psync : nullptr, st);
+              (each_eos || lagged || c.x0stat || folded_head) ? &psync : nullptr, st);
         };
-        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st));
+        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, folded_head ? logits_dst : nullptr));
         FF_RETURN_IF(pointer_head());
       }
       return FF_OK;

@@ -164,8 +164,13 @@ int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, 
   if (B == 0) return FF_OK;
   FF_CHECK_ARG(B > 0 && S > 0 && E > 0 && (E & 3) == 0 && E <= 2048 && seqs_per_group > 0,
                "ff_pointer_argmax: bad sizes B=%d S=%d E=%d", B, S, E);
-  FF_CHECK_ARG(p && memory && next_tok, "ff_pointer_argmax: null pointer");
-  FF_CHECK_ARG((ldp & 3) == 0 && ff_aligned16(p) && ff_aligned16(memory), "ff_pointer_argmax: p/memory misaligned");
+  const bool logits_ready = sync && sync->logits_ready;
+  FF_CHECK_ARG((p || logits_ready) && memory && next_tok, "ff_pointer_argmax: null pointer");
+  FF_CHECK_ARG(!logits_ready || (logits && (B % seqs_per_group) == 0), "ff_pointer_argmax: logits_ready without a logits buffer");
+  FF_CHECK_ARG(!(sync && sync->next_stats) || (logits && (B % seqs_per_group) == 0 && (E & 31) == 0),
+               "ff_pointer_argmax: next_stats needs the GEMM path (a logits buffer) and E %% 32 == 0");
+  FF_CHECK_ARG((logits_ready && !p) || ((ldp & 3) == 0 && ff_aligned16(p)), "ff_pointer_argmax: p misaligned");
+  FF_CHECK_ARG(ff_aligned16(memory), "ff_pointer_argmax: memory misaligned");
   FF_CHECK_ARG(!next_rows || ((ldnext & 3) == 0 && ff_aligned16(next_rows)), "ff_pointer_argmax: next_rows misaligned");
   FF_CHECK_ARG(!logits || ldlogits >= S, "ff_pointer_argmax: ldlogits < S");
   FF_CHECK_ARG(!extra_mask || ldextra >= S, "ff_pointer_argmax: ldextra < S");
@@ -179,10 +184,11 @@ int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, 
   dim3 grid(ff_cdiv(B, 4)), block(256);
   if (logits != nullptr && (B % seqs_per_group) == 0) {
     // logits[w*spg + f, s] = < p[w*spg + f, :], memory[w, s, :] > : one GEMM problem per wireframe
-    FF_RETURN_IF(ff_gemm_f32_batched(p, ldp, nullptr, 0, memory, E, nullptr, nullptr, 0, logits, ldlogits,
-                                     seqs_per_group, S, E, 0, 0, B / seqs_per_group,
-                                     (long long)seqs_per_group * ldp, (long long)S * E,
-                                     (long long)seqs_per_group * ldlogits, stream));
+    if (!logits_ready)
+      FF_RETURN_IF(ff_gemm_f32_batched(p, ldp, nullptr, 0, memory, E, nullptr, nullptr, 0, logits, ldlogits,
+                                       seqs_per_group, S, E, 0, 0, B / seqs_per_group,
+                                       (long long)seqs_per_group * ldp, (long long)S * E,
+                                       (long long)seqs_per_group * ldlogits, stream));
     FFProfScope prof(FF_CAT_POINTER, (double)B * S * 8.0, st);
     hipLaunchKernelGGL(pointer_reduce_kernel, grid, block, 0, st, a);
     FF_CHECK_LAUNCH();

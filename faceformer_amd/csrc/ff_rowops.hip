@@ -273,6 +273,27 @@ __global__ __launch_bounds__(256) void gelu_kernel(float* __restrict__ x, int ld
     *p = v;
   }
 }
+// out[c, r] = in[r, c]: 32 x 32 tiles through LDS (padded), coalesced both ways
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ld_in, int rows, int cols,
+                                                        float* __restrict__ out, int ld_out) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(size_t)(r0 + i) * ld_in + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * ld_out + r0 + tx] = tile[tx][i];
+}
+
+int ff_transpose(const float* in, int ld_in, int rows, int cols, float* out, int ld_out, hipStream_t st) {
+  FF_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, "ff_transpose: bad arguments");
+  FFProfScope prof(FF_CAT_ROWOP, (double)rows * cols * 8.0, st);
+  hipLaunchKernelGGL(transpose_kernel, dim3(ff_cdiv(cols, 32), ff_cdiv(rows, 32)), dim3(256), 0, st, in, ld_in, rows, cols, out, ld_out);
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
 extern "C" int ff_gelu(float* x, int ldx, int rows, int E, ff_stream_t stream) {
   if (rows == 0) return FF_OK;
   FF_CHECK_ARG(rows > 0 && E > 0 && (E & 3) == 0 && x && (ldx & 3) == 0 && ldx >= E && ff_aligned16(x), "ff_gelu: bad arguments");

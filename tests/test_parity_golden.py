@@ -472,8 +472,10 @@ def test_decode_steps_after_the_first_launch_no_layernorm(hip_lib):
     """Round 5: the pointer launch that appends a step's input rows also leaves their LayerNorm segment statistics, so the
     layer-0 q|k|v projection of the next step normalises them itself (ff_gemm_f32_ln) like every other projection of the
     decoder.  Counted with the library's profiling hooks on a golden: the standalone LayerNorm kernel runs in the encoder
-    (2 per layer + the final norm) and in decode step 1 (rows from init_tokens_kernel) only; FF_L0_FOLD=0 in a child process
-    (the previous form, one launch per step more) passes the same parity checks."""
+    (2 per layer + the final norm) and in decode step 1 (rows from init_tokens_kernel) only.  The previous launch forms stay
+    selectable -- FF_L0_FOLD=0 (that LayerNorm as its own launch), FF_POINTER_FOLD=0 (project and the pointer GEMM as two launches
+    instead of logits = LN(x) (memory W')^T + memory b'), FF_LAST_QKV_ONE_LAUNCH_ROWS=0 (pruned last layer: k|v and q apart) -- and
+    pass the same parity checks in a child process."""
     import ctypes
     import subprocess
     import sys
@@ -502,7 +504,8 @@ def test_decode_steps_after_the_first_launch_no_layernorm(hip_lib):
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_golden.py"), "-q", "-m", "gpu", "-x",
                         "-k", "test_golden_parity and (par_small_gain4 or seq_small_gain4 or par_small_ragged or seq_small_eos)"],
                        capture_output=True, text=True, timeout=900, cwd=root,
-                       env={k: v for k, v in dict(os.environ, FF_L0_FOLD="0").items() if k != "FF_PARITY_MARGINS"})
+                       env={k: v for k, v in dict(os.environ, FF_L0_FOLD="0", FF_POINTER_FOLD="0", FF_LAST_QKV_ONE_LAUNCH_ROWS="0").items()
+                            if k != "FF_PARITY_MARGINS"})
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-1000:]
 
 
