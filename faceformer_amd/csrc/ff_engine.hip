@@ -269,7 +269,7 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, 
     c.logits = bp.take<float>(Bch * (size_t)S);
     c.lnstat = bp.take<float>(Rmax * (size_t)(E / 32 + 1) * 2);
   }
-  b.cnt_ge = bp.take<int>((size_t)T * nch);
+  b.cnt_ge = bp.take<int>((size_t)T * nch);   // (these four stay in this order, back to back: ff_decode zeroes them with one fill)
   b.cnt_eq = bp.take<int>((size_t)T * nch);
   b.arrive = bp.take<int>((size_t)T * nch);
   b.seen = bp.take<int>(Btot);
@@ -723,10 +723,9 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       FF_RETURN_IF(gemm(buf.mem_pos, E, memory, E, c.in_proj_w + (size_t)E * E, E, c.in_proj_b + E, nullptr, 0,
                         buf.kvc[l], 2 * E, RS, 2 * E, E, 0, main_st));
     }
-    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, sizeof(int) * (size_t)T * nch, main_st));
-    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_eq, 0, sizeof(int) * (size_t)T * nch, main_st));
-    FF_CHECK_HIP(hipMemsetAsync(buf.arrive, 0, sizeof(int) * (size_t)T * nch, main_st));
-    if (each_eos) FF_CHECK_HIP(hipMemsetAsync(buf.seen, 0, sizeof(int) * (size_t)Btot, main_st));
+    // cnt_ge | cnt_eq | arrive | seen are consecutive in the workspace (layout_decode): ONE fill
+    FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, (size_t)(reinterpret_cast<char*>(buf.seen + Btot) - reinterpret_cast<char*>(buf.cnt_ge)),
+                                main_st));
     if (forked) {  // fork
       FF_CHECK_HIP(hipEventRecord(pool->fork_ev, main_st));
       for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamWaitEvent(sts[s], pool->fork_ev, 0));
