@@ -259,8 +259,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(ff_attn_desc d, int 
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 a = {o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv, o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv};
       f32x4 b = {o1[g4 * 4 + 0] * inv, o1[g4 * 4 + 1] * inv, o1[g4 * 4 + 2] * inv, o1[g4 * 4 + 3] * inv};
-      *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
-      *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = b;
+      ff_st16(op + 8 * g4, a);
+      ff_st16(op + 32 + 8 * g4, b);
     }
   }
 }
@@ -600,8 +600,8 @@ __global__ __launch_bounds__(64 * RK_NW, 2) void attention_resident_kernel(ff_at
         for (int g4 = 0; g4 < 4; ++g4) {
           f32x4 a = {st.o0[g4 * 4 + 0] * inv, st.o0[g4 * 4 + 1] * inv, st.o0[g4 * 4 + 2] * inv, st.o0[g4 * 4 + 3] * inv};
           f32x4 b = {st.o1[g4 * 4 + 0] * inv, st.o1[g4 * 4 + 1] * inv, st.o1[g4 * 4 + 2] * inv, st.o1[g4 * 4 + 3] * inv};
-          *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
-          *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = b;
+          ff_st16(op + 8 * g4, a);
+          ff_st16(op + 32 + 8 * g4, b);
         }
       }
     };

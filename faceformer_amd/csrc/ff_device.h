@@ -11,11 +11,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long ff_u64;
 
 __device__ __forceinline__ f32x4 ff_ld16(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void ff_st16(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x2 ff_ld8(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
-__device__ __forceinline__ void ff_st8(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
 __device__ __forceinline__ float ff_ld4(const float* p) { return *p; }
+__device__ __forceinline__ void ff_st16(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void ff_st8(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
 __device__ __forceinline__ void ff_st4(float* p, float v) { *p = v; }
+// (Round 6: agent-scope `sc1` write-through forms of these result stores -- the lines leave the XCD's L2 while the kernel runs
+//  instead of in the end-of-kernel release -- were built and measured: config B 59.1-59.2 ms against 58.0-58.4; not kept,
+//  profiles/r06/wt_stores_ab.txt.)
 __device__ __forceinline__ int ff_ld4i(const int* p) { return *p; }
 __device__ __forceinline__ void ff_st4i(int* p, int v) { *p = v; }
 // The 16 accumulator rows of a lane (row0 + (e&3) + 8*(e>>2), one column) -> C.  Whole tiles -- the wave's 32 rows inside M --

@@ -659,7 +659,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_CHECK_ARG(!p->stop_fn || (p->flags & FF_NO_STOP) || p->sync_every > 0, "ff_decode: stop_fn needs sync_every > 0");
   // The callback's cadence is a CONTRACT with callers that replay it elsewhere (an idle rank of a sharded decode joins the
   // same host collectives: faceformer_amd/dist.py check_points): the counters of the first n = enq - sync_every steps when
-  // enq = 2 sync_every, 3 sync_every, ... steps are enqueued.  Only the lag-free path below has that cadence.
+  // enq = 2 sync_every, 3 sync_every, ... steps are enqueued.  Both check paths below (host-mapped counters; drain + copy when
+  // there are more counters than slots) keep that cadence for a stop_fn (tests: FF_PINNED_COUNTERS=8 in a child process).
   FF_CHECK_ARG(!(p->flags & FF_STOP_EACH_EOS) || p->variant == FF_SEQ2SEQ, "ff_decode: FF_STOP_EACH_EOS is a seq2seq rule");
   const int E = m->E, S = p->L + m->num_token, T = p->T, F = p->F, N = p->N;
   FF_CHECK_ARG(S <= m->pos_len, "ff_decode: S=%d exceeds the position table (%d rows)", S, m->pos_len);
@@ -830,12 +831,18 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
             pending_enq = enq;
           }
         } else {   // more (step, micro-batch) counters than host slots: drain and copy
-          std::vector<int> hcnt((size_t)enq * nch);
-          FF_RETURN_IF(sync_all());
-          FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
-                                      sizeof(int) * hcnt.size(), hipMemcpyDeviceToHost, main_st));
-          FF_CHECK_HIP(hipStreamSynchronize(main_st));
-          stopped = eval_counts(host_totals(hcnt.data(), enq), enq);
+          // A caller's stop_fn is asked at the SAME cadence as on the lagged path (the first enq - sync_every steps, from
+          // enq = 2 sync_every on): peers and idle ranks of a sharded decode replay exactly that sequence of host collectives
+          // (dist.check_points).  The local rule has no such contract and looks at everything that has run.
+          const int n_eval = p->stop_fn ? enq - p->sync_every : enq;
+          if (n_eval > 0) {
+            std::vector<int> hcnt((size_t)n_eval * nch);
+            FF_RETURN_IF(sync_all());
+            FF_CHECK_HIP(hipMemcpyAsync(hcnt.data(), (p->variant == FF_PARALLEL) ? buf.cnt_ge : buf.cnt_eq,
+                                        sizeof(int) * hcnt.size(), hipMemcpyDeviceToHost, main_st));
+            FF_CHECK_HIP(hipStreamSynchronize(main_st));
+            stopped = eval_counts(host_totals(hcnt.data(), n_eval), n_eval);
+          }
         }
       }
     }

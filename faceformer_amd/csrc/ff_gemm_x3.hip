@@ -321,17 +321,20 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
     for (int q = 0; q < 4; ++q) {     // piece = 8 rows x 128 B
       int row = m0 + 32 * wm + 8 * q + (lane >> 3);
       row = row < g.M ? row : g.M - 1;
-      __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + (lane & 7) * 4,
+      // (16-byte chunk c of patch row r sits at position c ^ ((r >> 1) & 7): the merge's reads are then bank-conflict free)
+      __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + ((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 4,
                                        X3_LDS_PTR(lds + 3 * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
     }
   };
   auto stats_merge = [&](float& mean, float& rstd) {   // Chan's update for 16 equal parts (as ff_ln_finish of the f32 family)
     if (MODE != 1) return;
+    // Row l32 of the patch, chunk c at position c ^ ((l32 >> 1) & 7) (see stats_fetch): the 16 lanes of a ds_read_b128 lane
+    // group then touch 16 different 16-byte slots of the 256-byte bank row.  (Unswizzled, 128-byte row strides put 8 lanes of
+    // a group on the same four banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.40 for this kernel form in round 5.)
     u32x4 s[8];
-    s[0] = x3_lds_read16<0>(stat_lds + l32 * 128);   s[1] = x3_lds_read16<16>(stat_lds + l32 * 128);
-    s[2] = x3_lds_read16<32>(stat_lds + l32 * 128);  s[3] = x3_lds_read16<48>(stat_lds + l32 * 128);
-    s[4] = x3_lds_read16<64>(stat_lds + l32 * 128);  s[5] = x3_lds_read16<80>(stat_lds + l32 * 128);
-    s[6] = x3_lds_read16<96>(stat_lds + l32 * 128);  s[7] = x3_lds_read16<112>(stat_lds + l32 * 128);
+    const unsigned srow = stat_lds + l32 * 128, skx = ((l32 >> 1) & 7) << 4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = x3_lds_read16<0>(srow + ((16u * c) ^ skx));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7])::"memory");
     float sm = 0.f, m2 = 0.f;
 #pragma unroll
@@ -849,17 +852,20 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
     for (int q = 0; q < 4; ++q) {     // piece = 8 rows x 128 B
       int row = m0 + 32 * wm + 8 * q + (lane >> 3);
       row = row < g.M ? row : g.M - 1;
-      __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + (lane & 7) * 4,
+      // (16-byte chunk c of patch row r sits at position c ^ ((r >> 1) & 7): the merge's reads are then bank-conflict free)
+      __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + ((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 4,
                                        X3_LDS_PTR(lds + 3 * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
     }
   };
   auto stats_merge = [&](float& mean, float& rstd) {   // Chan's update for 16 equal parts (as ff_ln_finish of the f32 family)
     if (MODE != 1) return;
+    // Row l32 of the patch, chunk c at position c ^ ((l32 >> 1) & 7) (see stats_fetch): the 16 lanes of a ds_read_b128 lane
+    // group then touch 16 different 16-byte slots of the 256-byte bank row.  (Unswizzled, 128-byte row strides put 8 lanes of
+    // a group on the same four banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.40 for this kernel form in round 5.)
     u32x4 s[8];
-    s[0] = x3_lds_read16<0>(stat_lds + l32 * 128);   s[1] = x3_lds_read16<16>(stat_lds + l32 * 128);
-    s[2] = x3_lds_read16<32>(stat_lds + l32 * 128);  s[3] = x3_lds_read16<48>(stat_lds + l32 * 128);
-    s[4] = x3_lds_read16<64>(stat_lds + l32 * 128);  s[5] = x3_lds_read16<80>(stat_lds + l32 * 128);
-    s[6] = x3_lds_read16<96>(stat_lds + l32 * 128);  s[7] = x3_lds_read16<112>(stat_lds + l32 * 128);
+    const unsigned srow = stat_lds + l32 * 128, skx = ((l32 >> 1) & 7) << 4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = x3_lds_read16<0>(srow + ((16u * c) ^ skx));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7])::"memory");
     float sm = 0.f, m2 = 0.f;
 #pragma unroll

@@ -21,7 +21,7 @@ RECIPES = ("default", "gain4", "bias05")
 
 
 def state_dict_spec(kind, num_lines, seq_len, num_model=512, num_feedforward=1024,
-                    num_encoder_layers=6, num_decoder_layers=6, in_dim=100, num_token=4):
+                    num_encoder_layers=6, num_decoder_layers=6, in_dim=100, num_token=4, encoder_norm=True):
     """[(name, shape, role)] in the reference's registration order. role in
     {'matrix','ln_w','ln_b','lin_b','attn_b','buffer'}; `kind` is 'parallel' or 'seq2seq' (same
     tensors, `seq_len` = max_face_length or label_seq_length)."""
@@ -53,7 +53,8 @@ def state_dict_spec(kind, num_lines, seq_len, num_model=512, num_feedforward=102
     for i in range(num_encoder_layers):
         p = "encoder.layers.%d" % i
         spec += attn(p + ".self_attn") + ffn(p) + norm(p + ".norm1") + norm(p + ".norm2")
-    spec += norm("encoder.norm")
+    if encoder_norm:      # (a post-norm model has no final encoder norm: reference model.py:36)
+        spec += norm("encoder.norm")
     for i in range(num_decoder_layers):
         p = "decoder.layers.%d" % i
         spec += (attn(p + ".self_attn") + attn(p + ".multihead_attn") + ffn(p)

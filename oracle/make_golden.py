@@ -62,12 +62,14 @@ def run_case(case, ref_models):
     common = dict(num_model=m["E"], num_head=m["H"], num_feedforward=m["FF"],
                   num_encoder_layers=m["enc"], num_decoder_layers=m["dec"], dropout=0.2,
                   num_lines=m["L"], token=tok)
+    ctor = dict(normalize_before=m.get("normalize_before", True), activation=m.get("activation", "relu"))
+    common.update(ctor)     # (model.py:14-18 / model_para.py:14-19: handed on to every layer)
     if kind == "parallel":
         model = ref_models.SurfaceFormer_Parallel(max_face_length=seq_len, **common)
     else:
         model = ref_models.SurfaceFormer(label_seq_length=seq_len, **common)
     model.eval()
-    spec = state_dict_spec(kind, m["L"], seq_len, m["E"], m["FF"], m["enc"], m["dec"])
+    spec = state_dict_spec(kind, m["L"], seq_len, m["E"], m["FF"], m["enc"], m["dec"], encoder_norm=ctor["normalize_before"])
     keys = list(model.state_dict().keys())
     assert [s[0] for s in spec] == keys, "state_dict key order differs from SURVEY Appendix B"
     sd = make_state_dict(spec, case["recipe"], case["wseed"])
@@ -103,9 +105,9 @@ def run_case(case, ref_models):
     trace = {}
     t0 = time.time()
     if kind == "parallel":
-        out_orc = refpath.parallel_forward_eval(sd, b_orc, num_head=m["H"], trace=trace, extra_mask=extra)
+        out_orc = refpath.parallel_forward_eval(sd, b_orc, num_head=m["H"], trace=trace, extra_mask=extra, **ctor)
     else:
-        out_orc = refpath.seq2seq_forward_eval(sd, b_orc, num_head=m["H"], trace=trace, extra_mask=extra)
+        out_orc = refpath.seq2seq_forward_eval(sd, b_orc, num_head=m["H"], trace=trace, extra_mask=extra, **ctor)
     t_orc = time.time() - t0
 
     ref_logits = [r.squeeze(-1) for r in rec]

@@ -208,6 +208,20 @@ def select_next(memory, pointer, input_mask, extra_mask=None):
     return next_token, logit.squeeze(-1)
 
 
+def _stacks(sd, num_head, n_enc, n_dec, normalize_before, activation):
+    """(encoder, decoder) callables of a model built with these constructor arguments.  The defaults of every reference config
+    (pre-norm, relu) take the functions above; anything else the general stacks (post-norm: no `encoder.norm`, model.py:36)."""
+    if normalize_before and activation == "relu":
+        return (lambda src, mask, pos: encoder(sd, src, mask, pos, num_head, n_enc),
+                lambda tgt, memory, mask, pos, qpos: decoder(sd, tgt, memory, mask, pos, qpos, num_head, n_dec))
+    return (lambda src, mask, pos: encoder_stack(sd, "encoder.", src, num_head, n_enc, normalize_before,
+                                                 final_norm=normalize_before, src_key_padding_mask=mask, pos=pos,
+                                                 activation=activation),
+            lambda tgt, memory, mask, pos, qpos: decoder_stack(sd, "decoder.", tgt, memory, num_head, n_dec, normalize_before,
+                                                               final_norm=True, memory_key_padding_mask=mask, pos=pos,
+                                                               query_pos=qpos, activation=activation))
+
+
 def _dims(sd):
     num_model = sd["project.weight"].shape[0]
     n_enc = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
@@ -218,7 +232,8 @@ def _dims(sd):
 
 @torch.no_grad()
 def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=None,
-                          anchor_limit=None, stop_rule=True, num_anchors=None, extra_mask=None):
+                          anchor_limit=None, stop_rule=True, num_anchors=None, extra_mask=None,
+                          normalize_before=True, activation="relu"):
     """SurfaceFormer_Parallel.forward_eval (reference model_para.py:181-241).
 
     `trace`: optional dict; receives 'logits' (list of BxS tensors per step) and 'memory'.
@@ -228,8 +243,12 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
     `stop_rule=False` / `num_anchors`: ONLY for the multi-process tests -- run all T-1 steps and record
     the per-step special-token counts in trace['counts'] (a shard cannot evaluate the batch-global
     stop rule alone), and pad the anchor set to the batch-global F = max(num_input).
+    `normalize_before` / `activation`: the constructor arguments the reference hands to its layers (model_para.py:14-19,
+    33-45; no reference config changes them): post-norm layers (transformer.py:148-162, 211-233; `encoder.norm` is then
+    None, model_para.py:36) and gelu feed-forward layers.
     """
     num_model, n_enc, n_dec, num_token = _dims(sd)
+    run_encoder, run_decoder = _stacks(sd, num_head, n_enc, n_dec, normalize_before, activation)
     inp, input_mask, label = inputs["input"], inputs["input_mask"], inputs["label"]
     T = max_face_length if max_face_length is not None else sd["query_pos_enc.pos_embed.weight"].shape[0]
     batch_size = inp.size(0)
@@ -256,7 +275,7 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
     query_pos_embed = query_pos_embed.transpose(0, 1)
     predicts = anchors.flatten(1, 2)
 
-    memory = encoder(sd, source, input_mask, pos_embed, num_head, n_enc)
+    memory = run_encoder(source, input_mask, pos_embed)
     if trace is not None:
         trace["memory"] = memory.transpose(0, 1).clone()
         trace["logits"] = []
@@ -269,8 +288,7 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
     for step in range(T - 1):
         target = predicts.unsqueeze(-1).repeat(1, 1, num_model)
         tgt = torch.gather(memory, 0, target)
-        pointer = decoder(sd, tgt, memory, input_mask, pos_embed, query_pos_embed[: step + 1],
-                          num_head, n_dec)
+        pointer = run_decoder(tgt, memory, input_mask, pos_embed, query_pos_embed[: step + 1])
         pointer = F.linear(pointer, sd["project.weight"], sd["project.bias"])
         next_token, logit = select_next(memory, pointer, input_mask, extra_mask)
         if trace is not None:
@@ -289,9 +307,10 @@ def parallel_forward_eval(sd, inputs, num_head=8, max_face_length=None, trace=No
 
 @torch.no_grad()
 def seq2seq_forward_eval(sd, inputs, num_head=8, label_seq_length=None, token_sos=1, token_eos=3,
-                         trace=None, extra_mask=None):
-    """SurfaceFormer.forward_eval (reference model.py:169-219)."""
+                         trace=None, extra_mask=None, normalize_before=True, activation="relu"):
+    """SurfaceFormer.forward_eval (reference model.py:169-219); `normalize_before` / `activation` as above (model.py:14-18)."""
     num_model, n_enc, n_dec, num_token = _dims(sd)
+    run_encoder, run_decoder = _stacks(sd, num_head, n_enc, n_dec, normalize_before, activation)
     inp, input_mask, label = inputs["input"], inputs["input_mask"], inputs["label"]
     T = label_seq_length if label_seq_length is not None else sd["query_pos_enc.pos_embed.weight"].shape[0]
     batch_size = inp.size(0)
@@ -308,7 +327,7 @@ def seq2seq_forward_eval(sd, inputs, num_head=8, label_seq_length=None, token_so
     source, pos_embed = val_embed.transpose(0, 1), pos_embed.transpose(0, 1)
     query_pos_embed = query_pos_embed.transpose(0, 1)
 
-    memory = encoder(sd, source, input_mask, pos_embed, num_head, n_enc)
+    memory = run_encoder(source, input_mask, pos_embed)
     if trace is not None:
         trace["memory"] = memory.transpose(0, 1).clone()
         trace["logits"] = []
@@ -319,8 +338,7 @@ def seq2seq_forward_eval(sd, inputs, num_head=8, label_seq_length=None, token_so
     for step in range(T - 1):
         target = predicts.unsqueeze(-1).repeat(1, 1, num_model)
         tgt = torch.gather(memory, 0, target)
-        pointer = decoder(sd, tgt, memory, input_mask, pos_embed, query_pos_embed[: step + 1],
-                          num_head, n_dec)
+        pointer = run_decoder(tgt, memory, input_mask, pos_embed, query_pos_embed[: step + 1])
         pointer = F.linear(pointer, sd["project.weight"], sd["project.bias"])
         next_token, logit = select_next(memory, pointer, input_mask, extra_mask)
         if trace is not None:

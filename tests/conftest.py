@@ -52,16 +52,30 @@ def load_golden(name):
     return case, z
 
 
-def golden_names(include_slow=True):
+def is_module_path(case):
+    """Constructor arguments the native engine does not implement (post-norm layers, gelu): `forward_eval` then runs the
+    reference's loop on the HIP sub-modules (models/common.py: _forward_eval_modules)."""
+    m = case["model"]
+    return (not m.get("normalize_before", True)) or m.get("activation", "relu") != "relu"
+
+
+def golden_names(include_slow=True, module_path=False):
+    """Names of the golden cases: the ones the native engine decodes (default) or the ones that take the sub-module loop."""
     from oracle.golden_cases import CASES
-    return [c["name"] for c in CASES if include_slow or not c.get("slow")]
+    return [c["name"] for c in CASES if (include_slow or not c.get("slow")) and is_module_path(c) == module_path]
+
+
+def ctor_kwargs(case):
+    m = case["model"]
+    return dict(normalize_before=m.get("normalize_before", True), activation=m.get("activation", "relu"))
 
 
 def case_weights_and_batch(case):
     """Regenerate (state_dict, batch) of a golden case from its seeds."""
     from faceformer_amd.synth import make_state_dict, make_wireframes, state_dict_spec
     m = case["model"]
-    spec = state_dict_spec(case["kind"], m["L"], m["seq_len"], m["E"], m["FF"], m["enc"], m["dec"])
+    spec = state_dict_spec(case["kind"], m["L"], m["seq_len"], m["E"], m["FF"], m["enc"], m["dec"],
+                           encoder_norm=m.get("normalize_before", True))
     sd = make_state_dict(spec, case["recipe"], case["wseed"])
     batch = make_wireframes(case["n_edges"], m["L"], m["seq_len"], case["kind"], seeds=case["seeds"])
     if case.get("extra_mask_seed") is not None:
@@ -75,7 +89,7 @@ def build_model(case, sd, device):
     m = case["model"]
     common = dict(num_model=m["E"], num_head=m["H"], num_feedforward=m["FF"],
                   num_encoder_layers=m["enc"], num_decoder_layers=m["dec"], dropout=0.2,
-                  num_lines=m["L"], token=token_ns())
+                  num_lines=m["L"], token=token_ns(), **ctor_kwargs(case))
     if case["kind"] == "parallel":
         model = SurfaceFormer_Parallel(max_face_length=m["seq_len"], **common)
     else:

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import case_weights_and_batch, golden_names, load_golden
+from conftest import case_weights_and_batch, ctor_kwargs, golden_names, load_golden
 from oracle import refpath
 
 
@@ -15,9 +15,11 @@ def _check(name):
     trace = {}
     extra = batch.pop("extra_mask", None)
     if case["kind"] == "parallel":
-        out = refpath.parallel_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace, extra_mask=extra)
+        out = refpath.parallel_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace, extra_mask=extra,
+                                            **ctor_kwargs(case))
     else:
-        out = refpath.seq2seq_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace, extra_mask=extra)
+        out = refpath.seq2seq_forward_eval(sd, batch, num_head=case["model"]["H"], trace=trace, extra_mask=extra,
+                                           **ctor_kwargs(case))
     assert np.array_equal(out["predict"].numpy(), z["predict"])
     assert len(trace["logits"]) == int(z["steps"])
     rows = z["logit_rows"]
@@ -34,7 +36,7 @@ def _check(name):
         assert np.array_equal(out["pointer"][:, -1].numpy(), z["pointer_last"])
 
 
-@pytest.mark.parametrize("name", golden_names(include_slow=False))
+@pytest.mark.parametrize("name", golden_names(include_slow=False) + golden_names(include_slow=False, module_path=True))
 def test_oracle_matches_golden(name):
     _check(name)
 

@@ -73,13 +73,17 @@ def compare_with_golden(case, z, out):
     alive = np.ones(B, dtype=bool)      # sequences whose prefix still equals the reference's
     n_cmp = n_skip = 0
     worst = 0.0
+    worst_rel, worst_at = 0.0, (0, 0)   # |dlogit| / max|logit_ref| of the step (SURVEY 7.3-1's relative reading), and where
     for s in range(steps):
         tol = _tol(z["logits"][s])
+        scale = tol / LOGIT_TOL * LOGIT_SCALE          # = max(LOGIT_SCALE, max|logit_ref| of the step)
         # logits of the stored rows (only while the prefix is identical)
         for ri, b in enumerate(rows):
             if alive[b]:
                 d = np.abs(logits[s, b] - z["logits"][s, ri]).max()
                 worst = max(worst, d / tol)
+                if d / scale > worst_rel:
+                    worst_rel, worst_at = d / scale, (s, int(b))
                 assert d <= tol, "step %d seq %d: |dlogit|=%g > tol %g" % (s, b, d, tol)
         same = pred[:, s + 1] == gold[:, s + 1]
         must = alive & (margin[s] > 2 * tol)
@@ -94,7 +98,40 @@ def compare_with_golden(case, z, out):
     if kind == "parallel":
         # the benchmark configs must be decisive almost everywhere, otherwise the test is vacuous
         assert n_cmp >= 0.9 * (n_cmp + n_skip)
-    return dict(worst_logit_over_tol=worst, compared=n_cmp, skipped=n_skip, identical=float(alive.mean()))
+    return dict(worst_logit_over_tol=worst, compared=n_cmp, skipped=n_skip, identical=float(alive.mean()),
+                worst_rel=worst_rel, worst_rel_at=worst_at)
+
+
+# ---- the bar, frozen (round 6) -------------------------------------------------------------------------------------------------
+# Besides the bar above (|dlogit| <= 1e-3 max(1, max|logit| / 40), i.e. 2.5e-5 of the logit scale for the gain-4 weights), every
+# FULL-SIZE golden (E = 512, the BASELINE configurations) must
+#   (1) stay below FROZEN_FRACTION of that bar in every arithmetic form (today's worst full-size line is 0.63), and
+#   (2) with the gain-4 parity weights, meet SURVEY 7.3-1's tighter reading -- |dlogit| <= 1e-5 x the step's logit scale --
+#       except for the goldens listed in REL_1E5_EXCEPTIONS with the bound they are held to instead (measured value, rounded up;
+#       where it comes from is in profiles/r06/parity_margins.txt: `worst_rel ... at step/sequence`).
+# More folding / re-association that pushes a line past these fails the suite instead of creeping towards the bar.
+FROZEN_FRACTION = 0.70
+REL_1E5 = 1.0e-5
+REL_1E5_EXCEPTIONS = {
+    # name: relative bound it is held to.  Long key sets (516 / 1028 keys x 37 steps) and the 258-step single-sequence decode
+    # accumulate the most; all of them are below 0.64 of the 2.5e-5 bar.
+    "par_full_E512_T38_gain4": 1.7e-5,
+    "seq_full_A64_gain4": 1.2e-5,
+    "par_full_E1024_gain4": 1.1e-5,
+    "par_full_n40_gain4": 1.6e-5,
+}
+
+
+def check_frozen_bar(name, stats):
+    if "_full_" not in name:
+        return
+    assert stats["worst_logit_over_tol"] <= FROZEN_FRACTION, (
+        "%s: worst |dlogit| / tol = %.3f exceeds the frozen fraction %.2f of the bar" % (name, stats["worst_logit_over_tol"], FROZEN_FRACTION))
+    if "gain4" in name or "extramask" in name:
+        bound = REL_1E5_EXCEPTIONS.get(name, REL_1E5)
+        assert stats["worst_rel"] <= bound, (
+            "%s: |dlogit| = %.3g of the logit scale at step %d, sequence %d (bound %.3g)"
+            % (name, stats["worst_rel"], stats["worst_rel_at"][0], stats["worst_rel_at"][1], bound))
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -112,11 +149,13 @@ def _record_margin(name, form, stats):
     """FF_PARITY_MARGINS=<file>: one line per (golden, arithmetic form) with the worst |dlogit| / tol of the run -- kept
     under profiles/<round>/parity_margins.txt so that drift towards the bar is visible between rounds."""
     path = os.environ.get("FF_PARITY_MARGINS")
-    if path:
+    if path:   # (the frozen-bar check below runs either way)
         with open(path, "a") as f:
             f.write("%-28s %-34s worst_logit_over_tol %.3f  decisive_selections_equal %d  skipped_near_ties %d  "
-                    "sequences_identical %.4f\n" % (name, form, stats["worst_logit_over_tol"], stats["compared"],
-                                                    stats["skipped"], stats["identical"]))
+                    "sequences_identical %.4f  worst_rel %.2e at step %d seq %d\n" % (
+                        name, form, stats["worst_logit_over_tol"], stats["compared"], stats["skipped"], stats["identical"],
+                        stats["worst_rel"], stats["worst_rel_at"][0], stats["worst_rel_at"][1]))
+    check_frozen_bar(name, stats)
 
 
 @pytest.mark.parametrize("name", ["par_full_B256_gain4", "par_full_B256_default", "par_full_n40_gain4", "par_small_ragged300"])
@@ -672,6 +711,22 @@ def test_external_stop_rule_through_the_c_callback(hip_lib, name, period):
         else:
             eng.decode(memory, mask, kv_len, variant, F=1, tok_sos=model.token.SOS, tok_eos=model.token.EOS,
                        **dict(kw, stop_callback=broken))
+
+
+def test_c_callback_keeps_its_cadence_on_the_drain_path(hip_lib):
+    """with more (step, micro-batch) counters than host-mapped slots ff_decode drains and copies -- and a
+    caller's stop_fn must still be asked at dist.check_points' cadence (the first enq - sync_every steps, from enq = 2
+    sync_every on), because the peers and idle ranks of a sharded decode replay exactly that sequence of host collectives.
+    FF_PINNED_COUNTERS=8 in a child process puts every case of the callback test on the drain path: the same assertions
+    (`seen == check_points`, stop step, golden tokens, exceptions from the rule) must hold there."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_parity_golden.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "test_external_stop_rule_through_the_c_callback", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here),
+                       env=dict(os.environ, FF_PINNED_COUNTERS="8"))
+    assert p.returncode == 0 and " passed" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
 
 
 @pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak", "par_small_break1", "seq_small_gain4"])
