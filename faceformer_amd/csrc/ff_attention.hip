@@ -759,10 +759,10 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
     if (c > qt32) c = qt32;
     if (c < 1) c = 1;
     const int nblocks = P <= cus ? P * c : cus;
-    static const int w_old = getenv("FF_RK_SPLIT_OLD") ? atoi(getenv("FF_RK_SPLIT_OLD")) : 1;      // (probe knobs: tools/run_r04_attn.sh)
-    static const int w_young = getenv("FF_RK_SPLIT_YOUNG") ? atoi(getenv("FF_RK_SPLIT_YOUNG")) : 1;
-    static const int phase_knob = getenv("FF_RK_PHASE") ? atoi(getenv("FF_RK_PHASE")) : 0;
-    static const int rot_on = getenv("FF_RK_ROTATE") ? atoi(getenv("FF_RK_ROTATE")) : 1;   // (probe: 0 = every block loads K / V in the same order)
+    const int w_old = ff_knob(FF_K_RK_SPLIT_OLD);      // (probe knobs: tools/run_r04_attn.sh)
+    const int w_young = ff_knob(FF_K_RK_SPLIT_YOUNG);
+    const int phase_knob = ff_knob(FF_K_RK_PHASE);
+    const int rot_on = ff_knob(FF_K_RK_ROTATE);   // (probe: 0 = every block loads K / V in the same order)
     float* scratch = nullptr;   // first partial records: one per wave
     FF_RETURN_IF(ff_stream_scratch(st, (size_t)nblocks * RK_NW * RK_REC * sizeof(float), &scratch));
     hipLaunchKernelGGL(attention_resident_kernel, dim3(nblocks), dim3(64 * RK_NW), lds_bytes, st, d, P, c, qt32,

@@ -72,6 +72,25 @@ void ff_tuning_changed();
 // compute units of the current device (cached per device; 256 on an MI355X in SPX mode)
 int ff_num_cus();
 
+// ---- tuning knobs (round 6): ONE table, read from the environment once, settable per process through ff_set_tuning() ----------
+// Every A/B switch of the library lives here: the name is the environment variable that initialises it, the value
+// an int.  Defaults are the product; tests and tools flip them in-process (no child process needed) and the engine takes ONE
+// snapshot of the ones that shape a decode at the top of ff_decode / ff_decode_workspace_bytes.
+enum FFKnob {
+  FF_K_L0_FOLD = 0,               // 1: the pointer launch leaves the appended rows' LayerNorm statistics (0: a LayerNorm launch)
+  FF_K_POINTER_FOLD,              // 1: decoder.norm + project + pointer dot products as one GEMM for one-wireframe micro-batches
+  FF_K_LAST_QKV_ONE_LAUNCH_ROWS,  // pruned last layer: one q|k|v launch up to this many active rows
+  FF_K_PINNED_COUNTERS,           // host-mapped stop-counter slots a decode may use (<= the 65536 allocated)
+  FF_K_DEBUG_TIMING,              // ff_decode prints host-side enqueue / wait times
+  FF_K_DMA_MIN_ROWS, FF_K_DMA_MIN_ROWS_N512, FF_K_DMA_MIN_ROWS_WIDE,   // rows from which a projection takes the LDS-DMA f32 kernel
+  FF_K_SK_HYBRID, FF_K_SK_HYBRID_FIX, FF_K_SK_HYBRID_MAXLEFT8, FF_K_SK_HYBRID_MINU, FF_K_SK_HYBRID_FORCE,
+  FF_K_NO_PANEL,                  // 1: small-M launches never take gemm_panel_kernel
+  FF_K_X3_SMALL_SPLIT,            // split kernel: K-pieces on idle CUs below one tile per CU
+  FF_K_RK_SPLIT_OLD, FF_K_RK_SPLIT_YOUNG, FF_K_RK_PHASE, FF_K_RK_ROTATE,   // K/V-resident attention probes
+  FF_K_COUNT
+};
+int ff_knob(int id);
+
 // ff_pointer_argmax with the decode engine's stop-rule hand-over (ff_pointer.hip)
 struct ff_pointer_sync {
   int* seen;        // [B] or null: count_eq counts a sequence's first eq_value only (FF_STOP_EACH_EOS)

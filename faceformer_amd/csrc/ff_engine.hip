@@ -232,11 +232,30 @@ int plan_streams(const ff_decode_params* p) {
   return p->num_streams < 1 ? 1 : (p->num_streams > FF_MAX_STREAMS ? FF_MAX_STREAMS : p->num_streams);
 }
 
+// The tuning knobs that shape a decode, read ONCE per ff_decode / ff_decode_workspace_bytes call: the workspace
+// layout and every step of that call see the same values whatever ff_set_tuning() does meanwhile.  The two that change the
+// LAYOUT can also be switched off per call through ff_decode_params.flags (FF_NO_L0_FOLD, FF_NO_POINTER_FOLD).
+constexpr int FF_PINNED_SLOTS = 65536;   // host-mapped stop counters allocated per device (knob FF_PINNED_COUNTERS: how many a decode may use)
+struct EngineKnobs {
+  bool l0_fold, pointer_fold, dbg_timing;
+  int one_launch_rows, pinned;
+};
+EngineKnobs engine_knobs(const ff_decode_params* p) {
+  EngineKnobs k;
+  k.l0_fold = ff_knob(FF_K_L0_FOLD) != 0 && !(p->flags & FF_NO_L0_FOLD);
+  k.pointer_fold = ff_knob(FF_K_POINTER_FOLD) != 0 && !(p->flags & FF_NO_POINTER_FOLD);
+  k.dbg_timing = ff_knob(FF_K_DEBUG_TIMING) != 0;
+  k.one_launch_rows = ff_knob(FF_K_LAST_QKV_ONE_LAUNCH_ROWS);
+  const int pc = ff_knob(FF_K_PINNED_COUNTERS);
+  k.pinned = pc > 0 && pc < FF_PINNED_SLOTS ? pc : FF_PINNED_SLOTS;
+  return k;
+}
+
 // Workspace layout for `btot` compact sequences in micro-batches of at most `max_bc`.
 bool can_fuse_layernorm(const ff_model* m, const ff_decode_params* prm);
 
-size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, size_t Bch, size_t nch, Bump& bp,
-                     DecodeBuffers* out) {
+size_t layout_decode(const ff_model* m, const ff_decode_params* p, const EngineKnobs& kn, size_t Btot, size_t Bch, size_t nch,
+                     Bump& bp, DecodeBuffers* out) {
   const int E = m->E, FFd = m->FF, S = p->L + m->num_token, T = p->T;
   const int ns = plan_streams(p);
   const size_t Rmax = (size_t)(T - 1 > 0 ? T - 1 : 1) * Bch;
@@ -247,13 +266,11 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, size_t Btot, 
   b.x0_all = bp.take<float>((size_t)T * Btot * E);
   b.tok_all = bp.take<int>((size_t)T * Btot);
   b.qkv0_all = (p->flags & FF_REUSE_LAYER0_QKV) ? bp.take<float>((size_t)T * Btot * 3 * E) : nullptr;
-  // (FF_L0_FOLD=0: the newest rows' LayerNorm as its own launch, as before round 5 -- A/B runs and tests of that form)
-  static const bool l0_fold = !(getenv("FF_L0_FOLD") && atoi(getenv("FF_L0_FOLD")) == 0);
-  b.x0stat_all = (l0_fold && (p->flags & FF_REUSE_LAYER0_QKV) && can_fuse_layernorm(m, p)) ? bp.take<float>(Btot * (size_t)(E / 32) * 2)
+  // (FF_L0_FOLD=0 / FF_NO_L0_FOLD: the newest rows' LayerNorm as its own launch, as before round 5 -- A/B runs and tests of that form)
+  b.x0stat_all = (kn.l0_fold && (p->flags & FF_REUSE_LAYER0_QKV) && can_fuse_layernorm(m, p)) ? bp.take<float>(Btot * (size_t)(E / 32) * 2)
                                                                                  : nullptr;   // (size query: take() returns null)
-  // (FF_POINTER_FOLD=0: project and the pointer GEMM as two launches, as before round 5)
-  static const bool pointer_fold = !(getenv("FF_POINTER_FOLD") && atoi(getenv("FF_POINTER_FOLD")) == 0);
-  const bool pf = pointer_fold && can_fuse_layernorm(m, p);
+  // (FF_POINTER_FOLD=0 / FF_NO_POINTER_FOLD: project and the pointer GEMM as two launches, as before round 5)
+  const bool pf = kn.pointer_fold && can_fuse_layernorm(m, p);
   b.projT = pf ? bp.take<float>((size_t)E * E) : nullptr;
   b.pg_all = pf ? bp.take<float>(nch * (size_t)S * E) : nullptr;
   b.pc_all = pf ? bp.take<float>(nch * (size_t)((S + 3) & ~3)) : nullptr;
@@ -313,7 +330,7 @@ bool step_fuses(const ff_model* m, const ff_decode_params* prm, long R) {
 // by a projection with a residual (out-proj, linear2), which leaves per-row segment statistics in `lnstat`; the
 // projection that consumes LN(x) (+ qpos) reads x and the statistics and applies gamma / beta / qpos W^T through
 // folded weights (ff_gemm_f32_ln).  19 -> 1 LayerNorm launches per decode step of a 6-layer decoder.
-int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuffers& bufs, const Scratch& buf,
+int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKnobs& kn, const DecodeBuffers& bufs, const Scratch& buf,
                  const Chunk& ck, const unsigned char* mask, const int* kv_len, int t, bool full_rows,
                  float* proj_all, hipStream_t st, float* logits_out = nullptr) {
   const int E = m->E, FFd = m->FF, H = m->H, S = prm->L + m->num_token, F = ck.Fc, T = prm->T;
@@ -358,8 +375,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
   // The pruned last layer needs k | v of every row and q of the newest position only: two launches.  On launch-bound steps
   // (few rows) ONE q | k | v launch over all rows is cheaper than the second launch it saves (FF_LAST_QKV_ONE_LAUNCH_ROWS: up
   // to this many active rows; 0 = never); the q of the older rows is computed and not used.
-  static const int one_launch_rows = getenv("FF_LAST_QKV_ONE_LAUNCH_ROWS") ? atoi(getenv("FF_LAST_QKV_ONE_LAUNCH_ROWS")) : 512;
-  const bool last_qkv_one = R <= one_launch_rows;
+  const bool last_qkv_one = R <= kn.one_launch_rows;
   auto first_proj = [&](int l2) -> int {
     const ff_layer_weights& w2 = m->dec[l2];
     if (prune_last && l2 == nd - 1 && t > 1 && !last_qkv_one)
@@ -517,7 +533,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const DecodeBuf
 // Internal side streams + fork/join events: one pool per device, created on first use.
 // host-mapped ints: one per (step, micro-batch) of a decode; a decode with more of them checks its stop rule by draining the
 // streams and copying (FF_PINNED_COUNTERS overrides the size: tests run that path with a handful of slots)
-const int FF_PINNED_COUNTERS = getenv("FF_PINNED_COUNTERS") && atoi(getenv("FF_PINNED_COUNTERS")) > 0 ? atoi(getenv("FF_PINNED_COUNTERS")) : 65536;
+// (knob FF_PINNED_COUNTERS: how many of them a decode may use)
 struct StreamPool {
   hipStream_t side[FF_MAX_STREAMS];
   hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];
@@ -548,7 +564,7 @@ int pool_get(int n, StreamPool** out) {
     }
     // coherent (fine-grained) host memory mapped into the device's address space: the pointer launches store their stop-rule
     // counters straight into it (system-scope stores; no copy launch between two decode steps)
-    FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.hpin), sizeof(int) * FF_PINNED_COUNTERS,
+    FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.hpin), sizeof(int) * FF_PINNED_SLOTS,
                                hipHostMallocMapped | hipHostMallocCoherent));
     FF_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&pool.hpin_dev), pool.hpin, 0));
     pool.events = true;
@@ -640,7 +656,7 @@ extern "C" size_t ff_decode_workspace_bytes(const ff_model* m, const ff_decode_p
   int btot = 0, max_bc = 0, nch = 0;
   plan_chunks(p, num_input_host, 1, nullptr, &btot, &max_bc, &nch);
   Bump bp(nullptr, 0);
-  return layout_decode(m, p, (size_t)btot, (size_t)max_bc, (size_t)nch, bp, nullptr) + 256;
+  return layout_decode(m, p, engine_knobs(p), (size_t)btot, (size_t)max_bc, (size_t)nch, bp, nullptr) + 256;
 }
 
 extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const float* memory,
@@ -681,7 +697,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   Bump bp(workspace, workspace_bytes);
   DecodeBuffers buf;
   const int nch = (int)chunks.size();
-  layout_decode(m, p, (size_t)Btot, (size_t)max_bc, (size_t)nch, bp, &buf);
+  const EngineKnobs kn = engine_knobs(p);
+  layout_decode(m, p, kn, (size_t)Btot, (size_t)max_bc, (size_t)nch, bp, &buf);
   if (!bp.ok) { ff_set_error("ff_decode: workspace too small (%zu needed, %zu given)", bp.off, workspace_bytes); return FF_ERR_WORKSPACE; }
   for (Chunk& c : chunks) {
     c.x0 = buf.x0_all + (size_t)T * c.b0 * E;
@@ -760,7 +777,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
 
     // ---- greedy loop -----------------------------------------------------------------------------------
     const int max_steps = T - 1;
-    const bool dbg_timing = getenv("FF_DEBUG_TIMING") != nullptr;
+    const bool dbg_timing = kn.dbg_timing;
     const auto host_t0 = std::chrono::steady_clock::now();
     // Stop rule on the host WITHOUT draining the queue and WITHOUT a copy launch: every pointer launch owns the counter of
     // its (step, micro-batch) and its last block stores the total into host-mapped pinned memory (ff_pointer_count_block).
@@ -770,7 +787,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
     // 2 * sync_every - 1 steps late; those surplus steps are dropped by the finalize kernels (exact results).
     bool stopped = false;
     int pending_enq = 0;   // > 0: events covering steps [0, pending_enq) are in flight
-    const bool lagged = (size_t)T * (size_t)nch <= (size_t)FF_PINNED_COUNTERS;
+    const bool lagged = (size_t)T * (size_t)nch <= (size_t)kn.pinned;
     std::vector<int> tot;
     auto host_totals = [&](const int* per_chunk, int n) -> const int* {   // [n][nch] -> per-step totals
       tot.assign((size_t)n, 0);
@@ -810,7 +827,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
               c.x0 + (size_t)t * c.Bc * E, E, buf.cnt_ge + slot, m->num_token, buf.cnt_eq + slot, p->tok_eos,
               (each_eos || lagged || c.x0stat || folded_head) ? &psync : nullptr, st);
         };
-        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, t, false, nullptr, st, folded_head ? logits_dst : nullptr));
+        FF_RETURN_IF(decoder_pass(m, p, kn, buf, sc, c, mask, kv_len, t, false, nullptr, st, folded_head ? logits_dst : nullptr));
         FF_RETURN_IF(pointer_head());
       }
       return FF_OK;
@@ -902,7 +919,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
         // one micro-batch: its [steps * Bc, E] rows ARE pointer_out [steps, Btot, E]; several: through the FF-wide scratch
         // and one strided copy per micro-batch (was one copy launch per position: 258 of them for configs A / D)
         float* proj_all = nch == 1 ? pointer_out : sc.h;
-        FF_RETURN_IF(decoder_pass(m, p, buf, sc, c, mask, kv_len, steps, true, proj_all, main_st));
+        FF_RETURN_IF(decoder_pass(m, p, kn, buf, sc, c, mask, kv_len, steps, true, proj_all, main_st));
         if (nch > 1)
           FF_CHECK_HIP(hipMemcpy2DAsync(pointer_out + (size_t)c.b0 * E, sizeof(float) * (size_t)Btot * E, proj_all,
                                         sizeof(float) * (size_t)c.Bc * E, sizeof(float) * (size_t)c.Bc * E, (size_t)steps,

@@ -1398,12 +1398,12 @@ int launch_panel(const GemmArgs& g, dim3 grid, hipStream_t st) {
 #endif
 int g_small_wide_blocks = FF_SMALL_WIDE_BLOCKS;  // launches with at most this many tiles split K over eight waves instead of four
 
-const int g_small_panel = getenv("FF_NO_PANEL") ? 0 : 1;   // 1: launches of at most one tile per CU take gemm_panel_kernel (0: the eight-wave gemm_small_kernel)
+inline int small_panel() { return ff_knob(FF_K_NO_PANEL) ? 0 : 1; }   // 1: launches of at most one tile per CU take gemm_panel_kernel (0: the eight-wave gemm_small_kernel)
 
 template <int MODE>
 int launch_small_mode(const GemmArgs& g, dim3 grid, hipStream_t st) {
   const bool wide = (long)grid.x * grid.y <= g_small_wide_blocks;
-  const bool panel = wide && g_small_panel != 0;
+  const bool panel = wide && small_panel() != 0;
   switch (g.K) {
     case 512:
       if (panel) FF_RETURN_IF((launch_panel<512, MODE>(g, grid, st)));
@@ -1467,16 +1467,18 @@ int launch_streamk(GemmArgs g, int batch, hipStream_t st, int mode) {
   const double split_cost = (double)units / cus + g_sk_fix_units;
   sk.nA = 0; sk.tH = 0; sk.tL = 0; sk.uA = 0; sk.gx = 0;
   // Hybrid (see StreamK): hw whole tiles per CU + the units of the remaining tiles dealt to a second block per CU.
-  static const int hyb_on = getenv("FF_SK_HYBRID") ? atoi(getenv("FF_SK_HYBRID")) : 1;               // (A/B knob)
-  static const double hyb_fix = getenv("FF_SK_HYBRID_FIX") ? 0.1 * atoi(getenv("FF_SK_HYBRID_FIX")) : 1.0;
+  const int hyb_on = ff_knob(FF_K_SK_HYBRID);               // (A/B knob)
+  const double hyb_fix = 0.1 * ff_knob(FF_K_SK_HYBRID_FIX);
   const long hw = tiles / cus, left = tiles % cus;
   // ... when at most half a round of tiles is left over: measured (profiles/r05/gemm_hybrid_ab.txt, 256 t rows) +15-26 % on the
   // 512-column projections at t = 9 / 10, +8-12 % at t = 12, -2...-4 % at t = 14 (0.75 rounds left: unit ranges stay).
-  static const long hyb_max_left8 = getenv("FF_SK_HYBRID_MAXLEFT8") ? atol(getenv("FF_SK_HYBRID_MAXLEFT8")) : 4;   // (A/B knob: eighths of a round)
-  static const int hyb_force = getenv("FF_SK_HYBRID_FORCE") ? atoi(getenv("FF_SK_HYBRID_FORCE")) : 0;   // (probe: whole rounds too)
-  if (mode == 0 && hyb_on && hw >= 1 && (left > 0 || hyb_force) && 8 * left <= hyb_max_left8 * cus) {
+  const long hyb_max_left8 = ff_knob(FF_K_SK_HYBRID_MAXLEFT8);   // (A/B knob: eighths of a round)
+  const int hyb_force = ff_knob(FF_K_SK_HYBRID_FORCE);   // (probe: whole rounds too)
+  // (the hybrid plan -- 256 heavy + up to 256 light blocks, light blocks waiting for partials of lower-numbered ones -- is made for
+  //  and measured on the 256 CUs of an MI355X in SPX mode; a partition with another CU count keeps the older launch shapes)
+  if (mode == 0 && hyb_on && ff_num_cus() == (int)cus && hw >= 1 && (left > 0 || hyb_force) && 8 * left <= hyb_max_left8 * cus) {
     const long left_units = left * sk.upt;
-    static const long hyb_min_units = getenv("FF_SK_HYBRID_MINU") ? atol(getenv("FF_SK_HYBRID_MINU")) : 2;   // (A/B knob)
+    const long hyb_min_units = ff_knob(FF_K_SK_HYBRID_MINU);   // (A/B knob)
     long gb = left_units / (hyb_min_units > 0 ? hyb_min_units : 1);
     if (gb > cus) gb = cus;
     if (gb < 1) gb = 1;   // (left == 0 under the probe knob: one light block with an empty range)
@@ -1536,14 +1538,14 @@ namespace {
 // (profiles/r04/dma_threshold_ab.txt, gemm_dma_f32.txt): +3-8 % over the 64x64 / 128x64 families from ~8 k rows, LayerNorm-folded
 // forms +6-12 % from ~9 k rows, equal around 4-6 k, slower below; config B 59.9 -> 59.4 ms, 128 wireframes per call 206 -> 214 k/s
 // (with the LayerNorms folded at every size, which the 128x64 kernel could not).
-const long g_dma_min_rows = getenv("FF_DMA_MIN_ROWS") ? atol(getenv("FF_DMA_MIN_ROWS")) : 4096;
+inline long dma_min_rows() { return ff_knob(FF_K_DMA_MIN_ROWS); }
 // ... and for the 512-column projections (out-proj, cross-q, linear2): 64 x 128 tiles give them only 4 tile columns, and since the
 // 64x64 family has the hybrid launch (round 5) it is 3-14 % faster on them up to ~7.5 k rows (profiles/r05/gemm_families_4k_9k.txt:
 // LayerNorm-folded forms, 4096 ... 6400 rows), equal at 7680, slower from 8448.
-const long g_dma_min_rows_n512 = getenv("FF_DMA_MIN_ROWS_N512") ? atol(getenv("FF_DMA_MIN_ROWS_N512")) : 7680;
+inline long dma_min_rows_n512() { return ff_knob(FF_K_DMA_MIN_ROWS_N512); }
 // ... and for the 1536-column q|k|v projection (12 tile columns): its LayerNorm-folded form wins from ~2.5 k rows on (same file:
 // 89.7 / 91.4 / 91.0 / 94.4 against 79.5 / 79.7 / 81.6 / 85.4 TF/s at 2816 / 3072 / 3584 / 3840 rows, equal at 2304 / 2560 / 3328).
-const long g_dma_min_rows_wide = getenv("FF_DMA_MIN_ROWS_WIDE") ? atol(getenv("FF_DMA_MIN_ROWS_WIDE")) : 2560;
+inline long dma_min_rows_wide() { return ff_knob(FF_K_DMA_MIN_ROWS_WIDE); }
 int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
   const bool split128 = !g.A2 || (g.n_split % 128) == 0;
   if (tile == 0) tile = 7;  // stream-K kernel, launch shape by cost model (falls back by itself for K tails)
@@ -1557,8 +1559,8 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
     FF_CHECK_ARG(dma_ok, "ff_gemm_f32: tile 11 needs K %% 32 == 0, K >= 64, N %% 4 == 0, leading dimensions %% 4, 16-byte aligned operands, batch 1");
     return ff_gemm_dma_f32(g, st);
   }
-  const long dma_from = N <= 512 ? (g_dma_min_rows_n512 > g_dma_min_rows ? g_dma_min_rows_n512 : g_dma_min_rows)
-                                 : (N >= 1536 && g_dma_min_rows_wide < g_dma_min_rows ? g_dma_min_rows_wide : g_dma_min_rows);
+  const long dmr = dma_min_rows(), dmr512 = dma_min_rows_n512(), dmrw = dma_min_rows_wide();
+  const long dma_from = N <= 512 ? (dmr512 > dmr ? dmr512 : dmr) : (N >= 1536 && dmrw < dmr ? dmrw : dmr);
   if (tile == 7 && dma_ok && (long)M >= dma_from) return ff_gemm_dma_f32(g, st);
   switch (tile) {
     case 1: return launch_generic<64, 64, 32, 32>(g, batch, st);

@@ -47,6 +47,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct X3Args {
@@ -159,16 +160,24 @@ constexpr int X3_STAT_BYTES = 16384;   // MODE 1: one 4 KB patch per wave (32 ro
 
 // BM: 128 (4 x 1 waves) or 64 (2 x 2 waves).  MODE: 0 plain, 1 LayerNorm consumer (rows normalised before the split),
 // 2 statistics producer, 3 LayerNorm consumer with the normalisation applied in the EPILOGUE (see x3_ln_linear).
-template <int BM, int MODE>
+// NT: terms per operand.  3 = the bf16 split above (six products).  2 = the fp16 split of round 6 ("2 x fp16", ff_gemm_x2h):
+// x = x1 + x2 with x1 = fp16(x), x2' = fp16((x - x1) 2^11) (the second term is stored scaled by 2^11: it then has the magnitude of
+// the first and stays out of fp16's subnormal range), 22 mantissa bits, THREE products x1 y1 + (x1 y2' + x2' y1) 2^-11 on
+// v_mfma_f32_32x32x16_f16 -- half the matrix-core work (and energy: the bf16 form is power-limited) for an error that stays in
+// the fp32 class (profiles/r06/fp16_split_error_table.txt; tests/test_hip_ops.py::test_gemm_x2h_*).  fp16 has 5 exponent
+// bits: |x| must stay below 65504, which the callers guarantee (LayerNorm output is bounded by sqrt(K); the engine checks the
+// norm bounds of the other operands when it binds the planes: faceformer_amd/hip/engine.py).
+template <int BM, int MODE, int NT>
 __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3_kernel(X3Args g) {
   constexpr int BN = X3_BN, BK = X3_BK;
   constexpr int WN = 128 / BM;              // waves along N: 1 or 2
   constexpr int NI = BN / WN / 32;          // 32-column accumulators per wave: 4 or 2
   constexpr int NPA = BM / 64;              // A pieces (16 rows x 64 B) per wave and slice
-  constexpr int NP = NPA + 3;               // DMA pieces per wave and slice
-  constexpr int A_REG = BM * 64, SLOT = A_REG + 3 * BN * 32;
-  constexpr int NMF = 6 * NI;               // MFMAs per wave and slice
-  constexpr int NRD = 2 + 3 * NI;           // fragment reads per wave and slice
+  constexpr int NP = NPA + NT;              // DMA pieces per wave and slice
+  constexpr int A_REG = BM * 64, SLOT = A_REG + NT * BN * 32;
+  constexpr int NPROD = NT == 3 ? 6 : 3;    // partial products per fp32 product
+  constexpr int NMF = NPROD * NI;           // MFMAs per wave and slice
+  constexpr int NRD = 2 + NT * NI;          // fragment reads per wave and slice
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
   unsigned p1_[4], p2_[4], p3_[4];
   auto split_step = [&](int st) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int q = st >> 1;
     if ((st & 1) == 0) {
@@ -369,10 +379,21 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
         x0 = x3_fmul(x3_fsub(x0, mean_s), rstd_s);
         x1 = x3_fmul(x3_fsub(x1, mean_s), rstd_s);
       }
+      if (NT == 2) {     // fp16 terms: x1 = fp16(x) (round to nearest), residual exact in fp32
+        const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+        p1_[q] = __builtin_bit_cast(unsigned, h);
+        r_[q][0] = x3_fsub(x0, (float)h[0]);
+        r_[q][1] = x3_fsub(x1, (float)h[1]);
+        asm volatile("" : "+v"(p1_[q]), "+v"(r_[q][0]), "+v"(r_[q][1]));
+        return;
+      }
       p1_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
       r_[q][0] = x3_fsub(x0, __builtin_bit_cast(float, p1_[q] << 16));
       r_[q][1] = x3_fsub(x1, __builtin_bit_cast(float, p1_[q] & 0xffff0000u));
       asm volatile("" : "+v"(p1_[q]), "+v"(r_[q][0]), "+v"(r_[q][1]));
+    } else if (NT == 2) {   // second term, scaled by 2^11 (exact)
+      p2_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x3_fmul(r_[q][0], 2048.0f), x3_fmul(r_[q][1], 2048.0f)}, f16x2));
+      asm volatile("" : "+v"(p2_[q]));
     } else {
       p2_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r_[q][0], r_[q][1]}, bf16x2));
       const float s0 = x3_fsub(r_[q][0], __builtin_bit_cast(float, p2_[q] << 16));
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
   auto split_collect = [&](u32x4 (&dst)[3]) {
     dst[0] = u32x4{p1_[0], p1_[1], p1_[2], p1_[3]};
     dst[1] = u32x4{p2_[0], p2_[1], p2_[2], p2_[3]};
-    dst[2] = u32x4{p3_[0], p3_[1], p3_[2], p3_[3]};
+    if (NT == 3) dst[2] = u32x4{p3_[0], p3_[1], p3_[2], p3_[3]};
   };
 
   // ---- compute-side segment state ----
@@ -412,7 +433,10 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[ni][e] += accs[ni][e]; accs[ni][e] = 0.f; }
+      for (int e = 0; e < 16; ++e) {   // (fp16 terms: the small products were accumulated at 2^11 times their weight)
+        acc[ni][e] += NT == 2 ? accs[ni][e] * (1.0f / 2048.0f) : accs[ni][e];
+        accs[ni][e] = 0.f;
+      }
     if (cp_kind == 1) {
       f32x4* wp = reinterpret_cast<f32x4*>(g.ws + (size_t)lb * (BM * BN)) + tid;
 #pragma unroll
@@ -596,7 +620,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
     ar[0] = x3_lds_read16(lds0 + fa_r0);
     ar[1] = x3_lds_read16(lds0 + fa_r1);
 #pragma unroll
-    for (int r = 0; r < 3 * NI; ++r) x3_read_w_i<NI>(wf[0], lds0 + fw, r);
+    for (int r = 0; r < NT * NI; ++r) x3_read_w_i<NI>(wf[0], lds0 + fw, r);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
 #pragma unroll
     for (int st = 0; st < 8; ++st) split_step(st);
@@ -604,9 +628,12 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
   }
   __builtin_amdgcn_s_barrier();
 
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // (A plane, W plane), small terms first
+  // (A plane, W plane) of the partial products, small terms first; the LAST one (x1 y1) has its own accumulator
+  constexpr int PA[6] = {NT == 3 ? 2 : 1, NT == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NT == 3 ? 2 : 0, 0, 1, 0};
   // where the split steps and the DMA pieces go among the MFMA gaps
   constexpr int SP0 = NI == 4 ? 5 : 3;            // first split step (the two row reads are the oldest of SP0 + 1 reads)
+  constexpr int SPG = (8 + (NMF - SP0) - 1) / (NMF - SP0);   // split steps per gap (1 with six products, 3 with three)
+  constexpr int SPC = SP0 + (8 + SPG - 1) / SPG;  // gap behind which the split is complete
   constexpr int DM0 = NI == 4 ? NRD : NMF - NP;   // first DMA piece
   int s0 = 0, s1 = 1;   // ring slots of slice s, s + 1  (slice s + 3 goes to slot s0)
   const int total = 2 * (u1 - u0);
@@ -622,10 +649,17 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
         const int t = i / NI, ni = i % NI;
-        if (t < 5) accs[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
-                                                                      __builtin_bit_cast(bf16x8, af[u][PA[t]]), accs[ni], 0, 0, 0);
-        else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
-                                                               __builtin_bit_cast(bf16x8, af[u][PA[t]]), acc[ni], 0, 0, 0);
+        if (NT == 3) {
+          if (t < 5) accs[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
+                                                                        __builtin_bit_cast(bf16x8, af[u][PA[t]]), accs[ni], 0, 0, 0);
+          else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
+                                                                 __builtin_bit_cast(bf16x8, af[u][PA[t]]), acc[ni], 0, 0, 0);
+        } else {
+          if (t < 2) accs[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[u][PB[t]][ni]),
+                                                                       __builtin_bit_cast(f16x8, af[u][PA[t]]), accs[ni], 0, 0, 0);
+          else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[u][PB[t]][ni]),
+                                                                __builtin_bit_cast(f16x8, af[u][PA[t]]), acc[ni], 0, 0, 0);
+        }
         if (i == 0) ar[0] = x3_lds_read16(nb + fa_r0);
         else if (i == 1) ar[1] = x3_lds_read16(nb + fa_r1);
         else if (i < NRD) x3_read_w_i<NI>(wf[u ^ 1], nb + fw, i - 2);
@@ -633,17 +667,21 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
           if (SP0 == 5) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
           else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
         }
-        if (i >= SP0 && i < SP0 + 8) split_step(i - SP0);
-        if (i == SP0 + 8) split_collect(af[u ^ 1]);
+        if (i >= SP0) {
+#pragma unroll
+          for (int k = 0; k < SPG; ++k)
+            if ((i - SP0) * SPG + k < 8) split_step((i - SP0) * SPG + k);
+        }
+        if (i == SPC) split_collect(af[u ^ 1]);
         if (i >= DM0 && i < DM0 + NP) issue_piece(i - DM0, s0);
         if (i == NMF - 1) advance();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (SP0 + 8 >= NMF) split_collect(af[u ^ 1]);
+      if (SPC >= NMF) split_collect(af[u ^ 1]);
       // slice s + 2 has landed (own pieces), every fragment of slice s + 1 is in registers
       __builtin_amdgcn_s_waitcnt(0x0070 | NP);   // vmcnt(NP) lgkmcnt(0)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NT; ++p)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[u ^ 1][p][ni]));
       if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
@@ -658,10 +696,10 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
           ar[0] = x3_lds_read16(nb + fa_r0);
           ar[1] = x3_lds_read16(nb + fa_r1);
 #pragma unroll
-          for (int r = 0; r < 3 * NI; ++r) x3_read_w_i<NI>(wf[u ^ 1], nb + fw, r);
+          for (int r = 0; r < NT * NI; ++r) x3_read_w_i<NI>(wf[u ^ 1], nb + fw, r);
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < NT; ++p)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[u ^ 1][p][ni]));
           mean_s = mean_n; rstd_s = rstd_n;   // (MODE 1: these rows belong to the segment that starts now)
@@ -1279,7 +1317,7 @@ int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
   int hs = 0;
   for (int c = 8; c >= 2; c >>= 1)
     if (hr * c <= cus && g.upt % c == 0 && g.upt / c >= 2) { hs = c; break; }
-  static const int small_split = getenv("FF_X3_SMALL_SPLIT") ? atoi(getenv("FF_X3_SMALL_SPLIT")) : 0;   // (probe: K-pieces for launches below one tile per CU)
+  const int small_split = ff_knob(FF_K_X3_SMALL_SPLIT);   // (probe: K-pieces for launches below one tile per CU)
   if (!g_x3_force_shape && ((hw >= 1 && hr > 0) || (small_split && hw == 0 && hr * 2 <= cus)) && hs > 0) {
     g.hyb = 1; g.hw = (int)hw; g.hs = hs; g.cus = cus;
     g.ha = (spc == 2 || hw == 1) ? 1 : 2;   // (one slot stays for the K-piece blocks)

@@ -2,6 +2,8 @@
 // assembly.  All are HBM/L2-bandwidth bound: one wavefront per row, 16-byte loads/stores,
 // butterfly reductions through __shfl_xor (no LDS).
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <mutex>
@@ -29,6 +31,65 @@ int ff_num_cus() {
     cached[dev].store(n, std::memory_order_relaxed);
   }
   return n;
+}
+
+// ---- tuning knobs -------------------------------------------------------------------------------------------------------------------
+namespace {
+struct KnobDef { const char* name; int def; bool presence; };   // presence: the variable being set at all means 1
+const KnobDef g_knob_defs[FF_K_COUNT] = {
+    {"FF_L0_FOLD", 1, false}, {"FF_POINTER_FOLD", 1, false}, {"FF_LAST_QKV_ONE_LAUNCH_ROWS", 512, false},
+    {"FF_PINNED_COUNTERS", 65536, false}, {"FF_DEBUG_TIMING", 0, true},
+    {"FF_DMA_MIN_ROWS", 4096, false}, {"FF_DMA_MIN_ROWS_N512", 7680, false}, {"FF_DMA_MIN_ROWS_WIDE", 2560, false},
+    {"FF_SK_HYBRID", 1, false}, {"FF_SK_HYBRID_FIX", 10, false}, {"FF_SK_HYBRID_MAXLEFT8", 4, false},
+    {"FF_SK_HYBRID_MINU", 2, false}, {"FF_SK_HYBRID_FORCE", 0, false},
+    {"FF_NO_PANEL", 0, true}, {"FF_X3_SMALL_SPLIT", 0, false},
+    {"FF_RK_SPLIT_OLD", 1, false}, {"FF_RK_SPLIT_YOUNG", 1, false}, {"FF_RK_PHASE", 0, false}, {"FF_RK_ROTATE", 1, false},
+};
+std::atomic<int> g_knobs[FF_K_COUNT];
+std::once_flag g_knobs_once;
+void knobs_init() {
+  std::call_once(g_knobs_once, [] {
+    for (int i = 0; i < FF_K_COUNT; ++i) {
+      const char* e = getenv(g_knob_defs[i].name);
+      g_knobs[i].store(e ? (g_knob_defs[i].presence ? 1 : atoi(e)) : g_knob_defs[i].def, std::memory_order_relaxed);
+    }
+  });
+}
+int knob_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < FF_K_COUNT; ++i)
+    if (strcmp(name, g_knob_defs[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+int ff_knob(int id) {
+  knobs_init();
+  return g_knobs[id].load(std::memory_order_relaxed);
+}
+
+extern "C" int ff_set_tuning(const char* name, int value) {
+  const int i = knob_index(name);
+  FF_CHECK_ARG(i >= 0, "ff_set_tuning: unknown knob '%s'", name ? name : "(null)");
+  FF_CHECK_ARG(i != FF_K_PINNED_COUNTERS || (value > 0 && value <= 65536), "ff_set_tuning: FF_PINNED_COUNTERS must be in 1..65536");
+  knobs_init();
+  g_knobs[i].store(value, std::memory_order_relaxed);
+  ff_tuning_changed();
+  return FF_OK;
+}
+
+extern "C" int ff_get_tuning(const char* name, int* value) {
+  const int i = knob_index(name);
+  FF_CHECK_ARG(i >= 0 && value, "ff_get_tuning: unknown knob '%s'", name ? name : "(null)");
+  *value = ff_knob(i);
+  return FF_OK;
+}
+
+extern "C" int ff_reset_tuning(void) {   // back to the defaults (NOT the environment's values): tests
+  knobs_init();
+  for (int i = 0; i < FF_K_COUNT; ++i) g_knobs[i].store(g_knob_defs[i].def, std::memory_order_relaxed);
+  ff_tuning_changed();
+  return FF_OK;
 }
 
 extern "C" int ff_version(void) { return FF_ABI_VERSION; }

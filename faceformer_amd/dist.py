@@ -164,7 +164,7 @@ def check_points(T, sync_every):
     return [(enq, enq - sync_every) for enq in range(2 * sync_every, T - 1, sync_every)] if sync_every > 0 else []
 
 
-def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callback=None, sync_every=0):
+def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callback=None, sync_every=0, stop_each_eos=None):
     """Decode of the wireframes in `sub` with the batch-global F and WITHOUT the local stop rule (the batch-global one arrives
     through `stop_callback`, or afterwards) -> (predict [n, F, T], counts of the executed steps)."""
     parallel = variant == _L.FF_PARALLEL
@@ -180,7 +180,8 @@ def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callbac
                      chunk_wireframes=model.chunk_wireframes, chunk_seqs=model.chunk_seqs,
                      chunk_max_seqs=getattr(model, "chunk_max_seqs", 0),
                      num_streams=model.num_streams, sync_every=sync_every if stop_callback else 0,
-                     flags=model.decode_flags | (_L.FF_STOP_EACH_EOS if (not parallel and getattr(model, "stop_each_eos", False)) else 0),
+                     flags=model.decode_flags | (_L.FF_STOP_EACH_EOS if (not parallel and (
+                         getattr(model, "stop_each_eos", False) if stop_each_eos is None else stop_each_eos)) else 0),
                      x3_min_rows=model.x3_min_rows, ln_fuse_max_rows=getattr(model, "ln_fuse_max_rows", 0), extra_mask=extra_rows,
                      tok_sos=model.token.SOS if not parallel else 1,
                      tok_eos=model.token.EOS if not parallel else 3, no_stop=stop_callback is None,
@@ -193,7 +194,7 @@ def _decode_local(model, sub, variant, T, F, num_input, extra_rows, stop_callbac
     return pred, out["step_counts"]
 
 
-def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False, control_group=None):
+def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False, control_group=None, stop_each_eos=None):
     """Decode a batch across the ranks of `group`; returns `inputs` with 'predict' [N, F, T] (parallel) /
     [N, T] (seq2seq) for the WHOLE batch on every rank, identical to a single-process
     `model(inputs)['predict']` of that batch.
@@ -203,7 +204,9 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False, contr
     local_shard=True : `inputs` holds only this rank's wireframes (any number, also zero rows); the batch is
         their concatenation in rank order.  Also returns inputs['shard_sizes'] (wireframes per rank).
     control_group: a host-side (gloo) process group over the same ranks for the in-decode stop checks; None = the twin that
-        `_control_group` makes (collective over the ranks of `group`: EVERY rank of `group` must call decode_sharded)."""
+        `_control_group` makes (collective over the ranks of `group`: EVERY rank of `group` must call decode_sharded).
+    stop_each_eos: single-sequence model only -- None = the module's own `stop_each_eos`; True / False = this call's rule,
+        passed down as an argument (the module attribute is NOT touched: other host threads may be decoding with the model)."""
     from .models import SurfaceFormer_Parallel
     rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
     parallel = isinstance(model, SurfaceFormer_Parallel)
@@ -284,7 +287,7 @@ def decode_sharded(model, inputs, dist_mod, group=None, local_shard=False, contr
                 rows = extra.view(N, F if parallel else 1, -1).index_select(0, idx.to(extra.device))
                 ex = rows.reshape(-1, extra.size(-1)).contiguous()
         pred, c = _decode_local(model, sub, variant, T, F, ni, ex, stop_callback=global_stop if checks else None,
-                                sync_every=sync_every)
+                                sync_every=sync_every, stop_each_eos=stop_each_eos)
         local[: len(mine)] = pred
         counts[: len(c)] = torch.tensor(c, dtype=torch.int64, device=dev)
     dist_mod.all_reduce(counts, group=group)
@@ -350,14 +353,9 @@ def decode_to_face_json(model, inputs, dist_mod, group=None, edges=None, dominan
     parallel = isinstance(model, SurfaceFormer_Parallel)
     # seq2seq: the reference's batch rule counts a sample's repeated EOS too and can stop the batch before another sample's own
     # EOS; the records must be those of one-wireframe decodes, so the batch runs until EVERY wireframe has produced one
-    each = None if parallel else getattr(model, "stop_each_eos", False)
-    if each is False:
-        model.stop_each_eos = True
-    try:
-        out = decode_sharded(model, inputs, dist_mod, group, local_shard=local_shard)
-    finally:
-        if each is False:
-            model.stop_each_eos = False
+    # (the rule goes down as an ARGUMENT: toggling the module attribute would change what a concurrent model(inputs) on another
+    #  host thread decodes with, and a rank that raised in between would leave its peers on a different rule)
+    out = decode_sharded(model, inputs, dist_mod, group, local_shard=local_shard, stop_each_eos=None if parallel else True)
     rank, world = dist_mod.get_rank(group), dist_mod.get_world_size(group)
     if local_shard:
         sizes = out["shard_sizes"]

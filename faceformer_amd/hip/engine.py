@@ -33,6 +33,7 @@ class PathEngine:
                  ln_in_epilogue=True):
         self._lib = _L.load()
         self._keep = {}
+        self._bound_at = {}
         self._planes = {}
         self._want_planes = bool(bf16_split_planes)
         self.ln_in_epilogue = bool(ln_in_epilogue)
@@ -138,7 +139,11 @@ class PathEngine:
         self.E, self.H, self.num_token = E, num_head, num_token
         self.device = tensors["project.weight"].device
         self._ws = None
-        self._versions = {k: v._version for k, v in self._keep.items()} if (self._planes or self._folded) else {}
+        # address and in-place version of every bound tensor AS CAPTURED WHEN IT WAS BOUND (_get): a parameter moved or updated
+        # between that moment and the first forward is then seen as stale by pointers_current(), not recorded as current
+        self._versions = {k: self._bound_at[k][1] for k in self._keep} if (self._planes or self._folded) else {}
+        self._fast_check = ([self.tensors[k] for k in self._keep], tuple(self._bound_at[k][0] for k in self._keep),
+                            [self.tensors[k] for k in self._versions], tuple(self._versions.values()))
         # the stream-K exchange buffer of the launch stream is allocated here, not inside the first decode
         with torch.cuda.device(self.device):
             _L.check(self._lib.ff_gemm_prepare_stream(_stream()), "ff_gemm_prepare_stream")
@@ -164,6 +169,7 @@ class PathEngine:
         if t.data_ptr() % 16:
             raise ValueError("parameter %s is not 16-byte aligned" % name)
         self._keep[name] = t
+        self._bound_at[name] = (t.data_ptr(), t._version)      # what the struct / the derived copies were made from
         return t.data_ptr()
 
     def pointers_current(self):
@@ -171,12 +177,7 @@ class PathEngine:
         derived copies of the weights exist (the bf16 planes), while no bound tensor was updated in place
         since they were made (load_state_dict / optimizer.step bump `_version`).  Runs in front of EVERY forward:
         two C-level passes over the ~200 tensors (33 us; the dict / generator form took 60 us of a 58.6 ms call)."""
-        chk = getattr(self, "_fast_check", None)
-        if chk is None:
-            kt = [self.tensors[k] for k in self._keep]
-            vt = [self.tensors[k] for k in self._versions]
-            chk = self._fast_check = (kt, tuple(v.data_ptr() for v in self._keep.values()), vt, tuple(self._versions.values()))
-        kt, ptrs, vt, vers = chk
+        kt, ptrs, vt, vers = self._fast_check
         return tuple(map(torch.Tensor.data_ptr, kt)) == ptrs and tuple(map(_VERSION_OF, vt)) == vers
 
     @property

@@ -15,7 +15,9 @@ FF_PARALLEL, FF_SEQ2SEQ = 0, 1
 FF_REUSE_LAYER0_QKV, FF_LAST_LAYER_LAST_ROW, FF_RETURN_POINTER, FF_NO_STOP, FF_DEDUP_PAD_ANCHORS = 1, 2, 4, 8, 16
 FF_FUSE_LAYERNORM = 32
 FF_STOP_EACH_EOS = 512
-FF_ABI_VERSION = 101   # include/faceformer_hip.h: the struct layouts below are this version's
+FF_NO_L0_FOLD = 1024
+FF_NO_POINTER_FOLD = 2048
+FF_ABI_VERSION = 102   # include/faceformer_hip.h: the struct layouts below are this version's
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -137,6 +139,9 @@ SIGNATURES = {
     "ff_set_x3_tuning": (C.c_int, [C.c_int]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),
+    "ff_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "ff_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "ff_reset_tuning": (C.c_int, []),
     "ff_set_gemm_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ff_pointer_argmax": (C.c_int, [fptr, C.c_int, fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_int,
                                     C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int,

@@ -302,6 +302,28 @@ def set_attention_algo(algo):
     return _L.load().ff_set_attention_algo(int(algo))
 
 
+def set_tuning(name, value):
+    """One tuning knob of the library (include/faceformer_hip.h: ff_set_tuning; DESIGN.md 9), e.g. set_tuning("FF_L0_FOLD", 0);
+    returns the previous value.  Process-wide; a decode snapshots the knobs that shape it when it starts."""
+    import ctypes
+    lib, old = _L.load(), ctypes.c_int(0)
+    _L.check(lib.ff_get_tuning(name.encode(), ctypes.byref(old)), "ff_get_tuning")
+    _L.check(lib.ff_set_tuning(name.encode(), int(value)), "ff_set_tuning")
+    return old.value
+
+
+def get_tuning(name):
+    import ctypes
+    v = ctypes.c_int(0)
+    _L.check(_L.load().ff_get_tuning(name.encode(), ctypes.byref(v)), "ff_get_tuning")
+    return v.value
+
+
+def reset_tuning():
+    """Every knob back to its built-in default."""
+    _L.check(_L.load().ff_reset_tuning(), "ff_reset_tuning")
+
+
 def set_gemm_tuning(min_units=2, two_per_cu_units=2048, fix_tenths=25, small_max_rows=1024):
     """Launch shape of the stream-K projection kernel and row limit of the small-M kernel (see
     include/faceformer_hip.h); no arguments = the defaults."""

@@ -104,12 +104,83 @@ class SurfaceFormerBase(nn.Module):
             "build; this package implements the greedy eval path")
 
     # ---- native engine binding --------------------------------------------------------------------
+    def engine_supported(self):
+        """The native engine (ff_encode / ff_decode) implements what every reference config uses: pre-norm layers with relu
+        feed-forward blocks.  The other constructor arguments of the reference (model.py:14-18: `normalize_before=False`,
+        `activation="gelu"`) decode through `_forward_eval_modules`."""
+        return bool(self.normalize_before) and self.activation_name == "relu"
+
     def _check_supported(self):
         if not self.normalize_before:
             raise NotImplementedError("the native decode engine implements the pre-norm path "
                                       "(normalize_before=True, what every reference config uses)")
         if self.activation_name != "relu":
             raise NotImplementedError("the native decode engine implements relu feed-forward layers")
+
+    def _forward_eval_modules(self, inputs, parallel):
+        """Greedy decode of a model the native engine does not implement (post-norm layers, gelu), driven from Python over
+        this package's HIP sub-modules: `encoder` / `decoder` / `project` run ff_layernorm / ff_gemm_f32 / ff_attention /
+        ff_gelu, the pointer head is ff_pointer_argmax.  Same semantics as the reference's loops (model_para.py:181-241,
+        model.py:169-219): whole prefix re-decoded every step, `finfo.min` mask fill, lowest index on ties, the parallel
+        model's current-step stop rule / the single-sequence model's cumulative EOS count, zero padding afterwards.
+        One launch per operator and a host synchronisation per step (the stop rule): a module-level path for constructor
+        arguments no reference config uses, not the tuned engine -- still HIP kernels only, no CPU fallback."""
+        inp, label = inputs["input"], inputs["label"]
+        if not inp.is_cuda:
+            raise _L.HipExtensionError("inputs['input'] is on %s; expected a ROCm device tensor" % inp.device)
+        N, E, nt = inp.size(0), self.num_model, self.num_token
+        T = self.max_face_length if parallel else self.num_labels
+        mask = self.process_masks(inputs["input_mask"]).to(torch.bool)               # N x S, True = never a key / never selected
+        val, pos, qpos = self.get_embeddings(inp.to(torch.float32), label)
+        src, pos = self.patch_source(val, pos)                                          # S x N x E, S x 1 x E
+        qpos = qpos.transpose(0, 1)[: T - 1]                                            # (T-1) x 1 x E
+        memory = self.encoder(src, src_key_padding_mask=mask, pos=pos)                  # S x N x E
+        mem_rows = memory.transpose(0, 1).contiguous()                                  # N x S x E: pointer keys, one copy per wireframe
+        if parallel:
+            ni_in = inputs["num_input"]
+            num_input = [int(n) for n in (ni_in.tolist() if torch.is_tensor(ni_in) else ni_in)]
+            F = max(num_input)
+            start = torch.arange(F, device=inp.device, dtype=torch.long).repeat(N, 1)   # anchors WITHOUT the token offset
+            for i, n in enumerate(num_input):
+                start[i, n:] = nt - 1                                                    # padding anchors (model_para.py:204-205)
+            tokens = start.reshape(1, N * F)
+            mem_seq, mask_seq = memory.repeat_interleave(F, 1), mask.repeat_interleave(F, 0)
+        else:
+            F = 1
+            tokens = torch.full((1, N), self.token.SOS, dtype=torch.long, device=inp.device)
+            mem_seq, mask_seq = memory, mask
+        mask_u8 = mask.to(torch.uint8).contiguous()
+        extra = self._extra_mask(inputs)
+        eos_seen, pointer = 0, None
+        trace = getattr(self, "_module_trace", None)        # tests: a list that receives the masked logits of every step
+        if trace is not None:
+            self._module_memory = mem_rows
+        for step in range(T - 1):
+            tgt = torch.gather(mem_seq, 0, tokens.unsqueeze(-1).expand(-1, -1, E))        # (step+1) x B x E
+            pointer = self.project(self.decoder(tgt, mem_seq, memory_key_padding_mask=mask_seq, pos=pos,
+                                                query_pos=qpos[: step + 1]))
+            res = ops.pointer_argmax(pointer[-1].contiguous(), mem_rows, mask=mask_u8, extra_mask=extra,
+                                     seqs_per_group=F, want_logits=trace is not None)
+            nxt = res["next"].to(torch.long).unsqueeze(0)
+            if trace is not None:
+                trace.append(res["logits"])
+            tokens = torch.cat((tokens, nxt), dim=0)
+            if parallel:
+                if bool((nxt < nt).all()):
+                    break
+            else:
+                eos_seen += int((nxt == self.token.EOS).sum())
+                if eos_seen == N:
+                    break
+        pad = torch.zeros((T - tokens.size(0), tokens.size(1)), dtype=torch.long, device=inp.device)
+        predict = torch.cat((tokens, pad), dim=0).transpose(0, 1)
+        if parallel:
+            inputs["predict"] = predict.reshape(N, F, T)
+        else:
+            inputs["embedding"] = mem_rows
+            inputs["pointer"] = pointer.transpose(0, 1)
+            inputs["predict"] = predict
+        return inputs
 
     def engine(self):
         """PathEngine bound to this module's parameters (rebuilt when they moved, e.g. after .to())."""

@@ -39,6 +39,8 @@ class SurfaceFormer(SurfaceFormerBase):
         Adds predict N x T (int64), embedding N x S x E, pointer N x t_last x E."""
         label = inputs["label"]
         T = self.num_labels
+        if not self.engine_supported():      # post-norm / gelu constructor arguments: the sub-module loop (models/common.py)
+            return self._forward_eval_modules(inputs, parallel=False)
         if label.size(1) < T - 1:
             raise ValueError("label has %d positions but label_seq_length-1=%d query positions are "
                              "needed" % (label.size(1), T - 1))

@@ -37,6 +37,8 @@ class SurfaceFormer_Parallel(SurfaceFormerBase):
         only), num_input: N edge counts.  Adds predict N x F x T (int64), F = max(num_input)."""
         label = inputs["label"]
         T = self.max_face_length
+        if not self.engine_supported():      # post-norm / gelu constructor arguments: the sub-module loop (models/common.py)
+            return self._forward_eval_modules(inputs, parallel=True)
         if label.size(2) < T - 1:
             raise ValueError("label has %d positions but max_face_length-1=%d query positions are "
                              "needed" % (label.size(2), T - 1))

@@ -41,7 +41,7 @@ enum ff_status {
 /* Library version (major*10000 + minor*100 + patch).  101: the struct layouts of this header (round 5: ff_decode_params lost
  * chain_max_rows / flow_min_rows, FF_STOP_EACH_EOS added; round 4: ff_layer_weights grew by the ln*_planes / ln*_csum
  * pointers).  A caller built against another header must refuse to run: hip/lib.py asserts equality with FF_ABI_VERSION. */
-#define FF_ABI_VERSION 101
+#define FF_ABI_VERSION 102
 int ff_version(void);
 /* Thread-local text of the last error returned by this library ("" if none). */
 const char* ff_last_error(void);
@@ -248,6 +248,17 @@ int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
  * allocates: 24 MB per (device, stream), shared with the projection kernels of that stream in stream order). */
 int ff_set_attention_algo(int algo);
 
+/* Tuning knobs (round 6): every A/B switch of the library is one int in one table.  `name` is the environment
+ * variable that initialises the knob when the library is first used (FF_L0_FOLD, FF_POINTER_FOLD, FF_LAST_QKV_ONE_LAUNCH_ROWS,
+ * FF_PINNED_COUNTERS, FF_DEBUG_TIMING, FF_DMA_MIN_ROWS, FF_DMA_MIN_ROWS_N512, FF_DMA_MIN_ROWS_WIDE, FF_SK_HYBRID, FF_SK_HYBRID_FIX,
+ * FF_SK_HYBRID_MAXLEFT8, FF_SK_HYBRID_MINU, FF_SK_HYBRID_FORCE, FF_NO_PANEL, FF_X3_SMALL_SPLIT, FF_RK_SPLIT_OLD, FF_RK_SPLIT_YOUNG,
+ * FF_RK_PHASE, FF_RK_ROTATE).  ff_set_tuning changes it for the process (tests and tools flip knobs without child processes);
+ * a decode takes ONE snapshot of the knobs that shape it when it starts.  ff_reset_tuning restores the built-in defaults.
+ * Returns FF_ERR_ARG for an unknown name.  The defaults are the product; no reference interface corresponds to these. */
+int ff_set_tuning(const char* name, int value);
+int ff_get_tuning(const char* name, int* value);
+int ff_reset_tuning(void);
+
 /* ---------------------------------------------------------------------------------------------
  * G7/G8/G9  Pointer head: logits of every sequence against the edge embeddings of its wireframe,
  * padding mask, argmax, and the feedback gather of the chosen embedding row.  Replaces
@@ -379,6 +390,11 @@ enum ff_decode_flags {
                                 (start token num_token-1, reference model_para.py:204-205) are identical by
                                 construction; decode ONE of them and copy its tokens into all those rows of
                                 `predict`.  Needs num_input_host; ignored when an extra mask is given */
+  FF_NO_L0_FOLD = 1024,      /* this call: the LayerNorm of the rows a step appends as its own launch (the pointer launch leaves no
+                                statistics); as tuning knob FF_L0_FOLD = 0, but per call -- it changes the workspace layout, so
+                                ff_decode_workspace_bytes must see the same flags */
+  FF_NO_POINTER_FOLD = 2048, /* this call: decoder.norm + project and the pointer's dot products as two launches also for
+                                one-wireframe micro-batches (knob FF_POINTER_FOLD = 0, per call; changes the workspace layout) */
   FF_STOP_EACH_EOS = 512     /* seq2seq variant: the per-step counter counts a sequence's FIRST EOS only, so the cumulative
                                 rule "count == N" fires at the first step by which EVERY wireframe has produced an EOS -- the
                                 rule a caller needs when the records of a batch must equal those of one-wireframe decodes

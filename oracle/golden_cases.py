@@ -17,6 +17,13 @@ def _m(base, L, seq_len):
     return d
 
 
+def _mc(base, L, seq_len, **ctor):
+    """... with constructor arguments no reference config sets (model.py:14-18: normalize_before, activation)."""
+    d = _m(base, L, seq_len)
+    d.update(ctor)
+    return d
+
+
 CASES = [
     # --- SurfaceFormer_Parallel -------------------------------------------------------------------
     dict(name="par_small_default", kind="parallel", model=_m(SMALL, 24, 9), recipe="default",
@@ -63,6 +70,15 @@ CASES = [
          wseed=2, n_edges=[20, 13], seeds=[1, 2], extra_mask_seed=9),
     dict(name="par_small_extramask", kind="parallel", model=_m(SMALL, 24, 9), recipe="gain4",
          wseed=0, n_edges=[20, 13], seeds=[1, 2], extra_mask_seed=4),
+    # --- round 6: the constructor arguments the reference hands to its layers and no config sets (model.py:14-18,33-45) ---------
+    # post-norm layers (transformer.py:148-162, 211-233; encoder.norm is None then, model.py:36) and gelu feed-forward blocks:
+    # the package decodes these through its HIP sub-modules (models/common.py: _forward_eval_modules), not the engine
+    dict(name="par_small_postnorm_gelu", kind="parallel", model=_mc(SMALL, 24, 9, normalize_before=False, activation="gelu"),
+         recipe="gain4", wseed=0, n_edges=[20, 13], seeds=[1, 2]),
+    dict(name="par_small_prenorm_gelu", kind="parallel", model=_mc(SMALL, 24, 9, activation="gelu"),
+         recipe="gain4", wseed=1, n_edges=[20, 13], seeds=[1, 2]),
+    dict(name="seq_small_postnorm", kind="seq2seq", model=_mc(SMALL, 24, 30, normalize_before=False),
+         recipe="gain4", wseed=0, n_edges=[20, 13], seeds=[1, 2]),
     # configs/seq2seq.yml sizes (config A): L=110, T=259, one 64-edge wireframe
     dict(name="seq_full_A64_gain4", kind="seq2seq", model=_m(FULL, 110, 259), recipe="gain4",
          wseed=0, n_edges=[64], seeds=[3], slow=True),

@@ -214,6 +214,12 @@ def _stacks(sd, num_head, n_enc, n_dec, normalize_before, activation):
     if normalize_before and activation == "relu":
         return (lambda src, mask, pos: encoder(sd, src, mask, pos, num_head, n_enc),
                 lambda tgt, memory, mask, pos, qpos: decoder(sd, tgt, memory, mask, pos, qpos, num_head, n_dec))
+    # The reference's weights are nn.Parameters (requires_grad=True, also under torch.no_grad()), and ATen's matmul folds a
+    # NON-CONTIGUOUS 3-D input into one GEMM only when nothing requires grad -- otherwise it takes another GEMM shape, with
+    # another summation order.  A post-norm encoder hands its first projections the transposed (non-contiguous) embedding
+    # (model.py:186), so a bit-exact restatement has to present its weights the same way.  (The pre-norm path normalises
+    # first: every projection input is contiguous there and the flag changes nothing.)
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     return (lambda src, mask, pos: encoder_stack(sd, "encoder.", src, num_head, n_enc, normalize_before,
                                                  final_norm=normalize_before, src_key_padding_mask=mask, pos=pos,
                                                  activation=activation),

@@ -226,3 +226,35 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device(hip_lib):
     g.ln_stats_in, g.ln_nseg, g.row_table, g.row_div, g.row_cols, g.ld_row_table = None, 0, p, 4, 512, 512
     assert hip_lib.ff_gemm_f32_ln(ctypes.byref(g), None) == FF_ERR_ARG
     assert hip_lib.ff_set_gemm_tuning(0, 1, 1, 1) == FF_ERR_ARG
+
+
+def test_tuning_table_is_one_settable_struct(hip_lib):
+    """Round 6: every A/B knob of the library is one int in ONE table, initialised from the environment
+    variable of the same name and settable per process (ff_set_tuning / ff_get_tuning / ff_reset_tuning) -- no function-local
+    statics frozen on first use.  No GPU needed: the table is host state."""
+    FF_ERR_ARG = -1
+    v = ctypes.c_int(-7)
+    defaults = {b"FF_L0_FOLD": 1, b"FF_POINTER_FOLD": 1, b"FF_LAST_QKV_ONE_LAUNCH_ROWS": 512, b"FF_PINNED_COUNTERS": 65536,
+                b"FF_DMA_MIN_ROWS": 4096, b"FF_DMA_MIN_ROWS_N512": 7680, b"FF_DMA_MIN_ROWS_WIDE": 2560, b"FF_SK_HYBRID": 1,
+                b"FF_SK_HYBRID_FIX": 10, b"FF_SK_HYBRID_MAXLEFT8": 4, b"FF_SK_HYBRID_MINU": 2, b"FF_SK_HYBRID_FORCE": 0,
+                b"FF_NO_PANEL": 0, b"FF_X3_SMALL_SPLIT": 0, b"FF_RK_SPLIT_OLD": 1, b"FF_RK_SPLIT_YOUNG": 1, b"FF_RK_PHASE": 0,
+                b"FF_RK_ROTATE": 1, b"FF_DEBUG_TIMING": 0}
+    assert hip_lib.ff_reset_tuning() == 0
+    for name, want in defaults.items():
+        assert hip_lib.ff_get_tuning(name, ctypes.byref(v)) == 0 and v.value == want, name
+    try:
+        assert hip_lib.ff_set_tuning(b"FF_DMA_MIN_ROWS", 123) == 0
+        assert hip_lib.ff_get_tuning(b"FF_DMA_MIN_ROWS", ctypes.byref(v)) == 0 and v.value == 123
+        assert hip_lib.ff_set_tuning(b"FF_NOT_A_KNOB", 1) == FF_ERR_ARG and b"FF_NOT_A_KNOB" in hip_lib.ff_last_error()
+        assert hip_lib.ff_get_tuning(b"FF_NOT_A_KNOB", ctypes.byref(v)) == FF_ERR_ARG
+        assert hip_lib.ff_set_tuning(b"FF_PINNED_COUNTERS", 0) == FF_ERR_ARG          # must stay inside the allocated slots
+        assert hip_lib.ff_set_tuning(None, 1) == FF_ERR_ARG
+    finally:
+        assert hip_lib.ff_reset_tuning() == 0
+    assert hip_lib.ff_get_tuning(b"FF_DMA_MIN_ROWS", ctypes.byref(v)) == 0 and v.value == 4096
+    # the sources read no environment variable anywhere else
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = [f for f in glob.glob(os.path.join(root, "faceformer_amd", "csrc", "*")) if "getenv" in open(f).read()]
+    assert [os.path.basename(f) for f in hits] == ["ff_rowops.hip"], hits

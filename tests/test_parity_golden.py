@@ -145,6 +145,31 @@ def test_golden_parity(hip_lib, name):
     _record_margin(name, "package default", stats)
 
 
+@pytest.mark.parametrize("name", golden_names(module_path=True))
+def test_golden_parity_of_postnorm_and_gelu_models_through_the_submodule_loop(hip_lib, name):
+    """Round 6: the reference hands `normalize_before` and `activation` to every layer (model.py:14-18,33-45); no config sets
+    them and the native engine implements pre-norm + relu only.  A model built with the other values decodes through
+    `_forward_eval_modules` -- the reference's loop over this package's HIP sub-modules -- and must meet the same bars against
+    goldens captured from the imported reference built with those arguments (post-norm + gelu, pre-norm + gelu, post-norm)."""
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    assert not model.engine_supported()
+    model._module_trace = []
+    with torch.no_grad():
+        res = model(batch_to(batch, "cuda"))
+    T = case["model"]["seq_len"]
+    out = dict(steps=len(model._module_trace), predict=res["predict"].reshape(-1, T), logits=torch.stack(model._module_trace),
+               memory=model._module_memory)
+    stats = compare_with_golden(case, z, out)
+    print(name, stats)
+    _record_margin(name, "HIP sub-module loop", stats)
+    if case["kind"] == "seq2seq":       # the single-sequence model also returns `embedding` and `pointer` (model.py:216-217)
+        assert tuple(res["embedding"].shape) == tuple(model._module_memory.shape)
+        ptr = res["pointer"][:, -1].cpu().numpy()
+        assert np.abs(ptr - z["pointer_last"]).max() < 2e-4 * max(1.0, np.abs(z["pointer_last"]).max())
+
+
 def _record_margin(name, form, stats):
     """FF_PARITY_MARGINS=<file>: one line per (golden, arithmetic form) with the worst |dlogit| / tol of the run -- kept
     under profiles/<round>/parity_margins.txt so that drift towards the bar is visible between rounds."""
@@ -546,6 +571,53 @@ def test_decode_steps_after_the_first_launch_no_layernorm(hip_lib):
                        env={k: v for k, v in dict(os.environ, FF_L0_FOLD="0", FF_POINTER_FOLD="0", FF_LAST_QKV_ONE_LAUNCH_ROWS="0").items()
                             if k != "FF_PARITY_MARGINS"})
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-1000:]
+
+
+@pytest.mark.parametrize("name", ["par_small_gain4", "seq_small_gain4", "par_small_ragged"])
+def test_launch_forms_flipped_in_process_through_the_tuning_table(hip_lib, name):
+    """Round 6: every A/B knob of the library is one int in ONE table (ff_set_tuning / ff_get_tuning), so a test can
+    flip a launch form per call instead of per child process; the two knobs that change the workspace layout are also decode
+    flags (FF_NO_L0_FOLD, FF_NO_POINTER_FOLD).  Each form must reproduce the golden; the LayerNorm launch count shows that the
+    form really changed; afterwards the defaults are back."""
+    import ctypes
+    from faceformer_amd.hip import lib as L
+    from faceformer_amd.hip import ops
+    case, z = load_golden(name)
+    sd, batch = case_weights_and_batch(case)
+    model = build_model(case, sd, "cuda")
+    b = batch_to(batch, "cuda")
+
+    def layernorm_launches():
+        ms, work, cnt = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_longlong * 7)()
+        torch.cuda.synchronize()
+        hip_lib.ff_profile_begin()
+        with torch.no_grad():
+            pred = model(dict(b))["predict"]
+        assert hip_lib.ff_profile_end(ms, work, cnt, 7) == 0
+        assert np.array_equal(pred.cpu().numpy(), z["predict"])
+        return int(cnt[2])
+    base = layernorm_launches()
+    assert ops.get_tuning("FF_L0_FOLD") == 1 and ops.get_tuning("FF_POINTER_FOLD") == 1
+    try:
+        assert ops.set_tuning("FF_L0_FOLD", 0) == 1
+        unfolded = layernorm_launches()
+        assert unfolded > base                                  # one LayerNorm launch per step and micro-batch again
+        ops.set_tuning("FF_L0_FOLD", 1)
+        ops.set_tuning("FF_POINTER_FOLD", 0)
+        ops.set_tuning("FF_LAST_QKV_ONE_LAUNCH_ROWS", 0)
+        assert layernorm_launches() == base
+        ops.reset_tuning()
+        flags0 = model.decode_flags
+        model.decode_flags = flags0 | L.FF_NO_L0_FOLD | L.FF_NO_POINTER_FOLD      # the same two forms, per call
+        assert layernorm_launches() == unfolded
+        model.decode_flags = flags0
+        ops.set_tuning("FF_PINNED_COUNTERS", 8)                 # the stop rule through drain + copy
+        assert layernorm_launches() == base
+    finally:
+        ops.reset_tuning()
+    assert layernorm_launches() == base
+    with pytest.raises(L.HipExtensionError):
+        ops.set_tuning("FF_NO_SUCH_KNOB", 1)
 
 
 def test_json_gather_over_rccl(hip_lib, tmp_path):
