@@ -170,19 +170,22 @@ def _committed_traffic(fname):
         return json.load(f)["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
 
 
-def x3_roofline(prof, wall_ms, with_traffic=False):
-    """`roofline` of the 3 x bf16 split projection kernel (the package default's dominant kernel) from one profiled pass:
-    algorithmic fp32 flops (2MNK) of its launches / their summed duration net of the event bracket, against the bf16 matrix
-    peak divided by the six bf16 products an fp32 product costs."""
+def x3_roofline(prof, wall_ms, with_traffic=False, kind="fp16x2"):
+    """`roofline` of the split projection kernel (the package default's dominant kernel) from one profiled pass: algorithmic
+    fp32 flops (2MNK) of its launches / their summed duration net of the event bracket, against the 16-bit matrix peak divided
+    by the partial products an fp32 product costs: six with three bf16 terms, three with two fp16 terms (round 6)."""
     ms, work, cnt, alg_bytes = prof
     nl = max(1, sum(cnt))
     bracket_us = max(0.0, (sum(ms) - wall_ms) / nl * 1e3)
     net = [max(0.0, ms[i] - cnt[i] * bracket_us * 1e-3) for i in range(len(ms))]
     i3 = CAT_NAMES.index("gemm_bf16x3_kernel")
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    nprod = 3.0 if kind == "fp16x2" else 6.0
+    peak = PEAK_BF16_MFMA_TFLOPS / nprod
     ach = work[i3] / (net[i3] * 1e-3) / 1e12 if net[i3] > 0 else 0.0
     return {
-        "kernel": "gemm_x3_kernel (ff_gemm_x3.hip): fp32-accurate product as six bf16 MFMA partial products per K slice",
+        "kernel": "gemm_x3_kernel (ff_gemm_x3.hip): fp32-accurate product as %d %s MFMA partial products per K slice"
+                  % (int(nprod), "fp16" if kind == "fp16x2" else "bf16"),
+        "split_kind": kind,
         "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)", "frac": ach / peak,
         "traffic": _committed_traffic("traffic_x3.json")[0] if with_traffic else None,
         "traffic_unit": "HBM bytes per launch", "traffic_source": _committed_traffic("traffic_x3.json")[1] if with_traffic else None,
@@ -192,9 +195,10 @@ def x3_roofline(prof, wall_ms, with_traffic=False):
         "event_bracket_us_per_launch": bracket_us,
         "kernel_time_ms_per_step": {CAT_NAMES[i]: net[i] for i in range(len(ms))},
         "kernel_launches_per_step": {CAT_NAMES[i]: cnt[i] for i in range(len(ms))},
-        "note": "peak = 2500 TF/s dense bf16 / 6 partial products; the loop is POWER-limited on this chip: the same binary reaches "
-                "245-272 TF/s-equivalent on zero-filled operands and 170-200 on random ones (profiles/r04/x3v2_*.txt); "
-                "effective_clock_ghz = shader clock measured under this configuration's passes (profiles/r05/effective_clock.md)",
+        "note": "peak = 2500 TF/s dense 16-bit MFMA / %d partial products; the six-product bf16 form is POWER-limited on this chip "
+                "(245-272 TF/s-equivalent on zero-filled operands, 170-200 on random ones: profiles/r04/x3v2_*.txt), the three-product "
+                "fp16 form runs 226-245 on random operands (profiles/r06/gemm_split_kinds.txt); effective_clock_ghz = shader clock "
+                "measured under this configuration's passes" % int(nprod),
     }
 
 
@@ -409,6 +413,8 @@ def main():
                     help="3 x bf16 projections (fp32-accurate, bf16 matrix cores) on launches with at least this many rows. "
                          "The HEADLINE is measured with 0 (every product on the f32 matrix cores, dtype f32); the package "
                          "default is measured as well and reported under 'bf16x3_projections'")
+    ap.add_argument("--split-kind", default="", choices=["", "bf16x3", "fp16x2"],
+                    help="how the split projections of the package-default line split an fp32 operand (default: the package's)")
     ap.add_argument("--no-fuse-ln", action="store_true", help="standalone LayerNorm launches (A/B of FF_FUSE_LAYERNORM)")
     ap.add_argument("--no-dedup", action="store_true", help="decode every padding-anchor row like the reference does")
     ap.add_argument("--sync-every", type=int, default=1, help="host stop-rule check period in steps (0 = never; package default 1)")
@@ -512,6 +518,8 @@ def main():
         model.chunk_seqs, model.num_streams = args.chunk_seqs, args.streams
         model.sync_every = args.sync_every
         model.x3_min_rows = args.x3_min_rows
+        if args.split_kind:
+            model.split_kind = args.split_kind
         if args.no_dedup:
             model.decode_flags = model.decode_flags & ~L.FF_DEDUP_PAD_ANCHORS
         if args.no_fuse_ln:
@@ -521,6 +529,8 @@ def main():
 
     def apply_knobs(mod):
         mod.ln_fuse_max_rows = args.ln_fuse_max_rows
+        if os.environ.get("FF_BENCH_LN_FIRST"):        # (A/B: rows normalised before the split product instead of in its epilogue)
+            mod.x3_ln_in_epilogue = False
 
     def steps_executed(pred):   # pred [N, F, T] or [N, T]
         p = pred.reshape(-1, pred.size(-1))
@@ -708,7 +718,8 @@ def main():
                 with torch.no_grad():
                     model(dict(batch))
             roof3 = x3_roofline(profile_once(lib, L, once3), 1e3 * dt3 / args.steps,
-                                with_traffic=(not cfgE and args.edges == 256 and W == 1))
+                                with_traffic=(not cfgE and args.edges == 256 and W == 1 and getattr(model, "split_kind", "") == "bf16x3"),
+                                kind=getattr(model, "split_kind", "bf16x3"))
             ghz3 = effective_clock(once3, dt3 / args.steps)
             roof3["effective_clock_ghz"] = ghz3
             roof3["frac_at_effective_clock"] = roof3["frac"] * NOMINAL_GHZ / ghz3 if ghz3 > 0 else None
@@ -717,10 +728,11 @@ def main():
         fence()
         result["bf16x3_projections"] = {
             "value": sel_per_step * args.steps / dt3, "unit": "edges/s", "ms_per_step": 1e3 * dt3 / args.steps,
-            "x3_min_rows": X3_MIN_ROWS_DEFAULT,
+            "x3_min_rows": X3_MIN_ROWS_DEFAULT, "split_kind": getattr(model, "split_kind", "bf16x3"),
             "note": "package default: decoder projections of launches with >= %d rows (q|k|v; linear1 from 7/4 x, the 512-column "
-                    "ones from 11/4 x that) as 3 x bf16 split products on the bf16 matrix cores with the LayerNorms folded in "
-                    "(ff_gemm_x3_ln), fp32-accurate; NOT the headline" % X3_MIN_ROWS_DEFAULT,
+                    "ones from 11/4 x that) as split products on the 16-bit matrix cores (split_kind fp16x2: two fp16 terms, three "
+                    "products; bf16x3: three bf16 terms, six products) with the LayerNorms folded in, fp32-accurate; NOT the headline"
+                    % X3_MIN_ROWS_DEFAULT,
             "path_roofline": path_roofline(falg, dt3 / args.steps)}
         if roof3 is not None:
             result["bf16x3_projections"]["roofline"] = roof3
@@ -881,7 +893,7 @@ def main():
             if not args.no_x3_line:
                 m2.x3_min_rows = X3_MIN_ROWS_DEFAULT
                 d3, _ = timed(st, fence, 1, K2)
-                r3 = x3_roofline(profile_once(lib, L, st), 1e3 * d3 / K2) if profiled(name) else None
+                r3 = x3_roofline(profile_once(lib, L, st), 1e3 * d3 / K2, kind=getattr(m2, "split_kind", "bf16x3")) if profiled(name) else None
                 m2.x3_min_rows = 0
                 ent["bf16x3_projections"] = {"value": sum(n2) * sd2 * K2 / d3, "unit": "edges/s", "ms_per_step": 1e3 * d3 / K2,
                                              "ms_per_wireframe": 1e3 * d3 / K2 / len(n2), "roofline": r3,

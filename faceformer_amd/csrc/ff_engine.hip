@@ -109,6 +109,7 @@ int check_model(const ff_model* m) {
                    m->num_dec_layers <= FF_MAX_LAYERS, "model: bad layer counts");
   FF_CHECK_ARG(m->in_dim > 0 && (m->in_dim & 3) == 0, "model: in_dim=%d must be a multiple of 4", m->in_dim);
   FF_CHECK_ARG(m->num_token > 0, "model: num_token");
+  FF_CHECK_ARG(m->split_kind == 0 || m->split_kind == 1, "model: split_kind=%d (0 = bf16 x 3 planes, 1 = fp16 x 2 planes)", m->split_kind);
   return FF_OK;
 }
 
@@ -127,17 +128,18 @@ int gemm(const float* A, int lda, const float* A2, int n_split, const float* W, 
 inline bool x3_wins(const ff_decode_params* prm, int M, int N, int K, int lda) {
   if (prm->x3_min_rows <= 0 || (K % 32) != 0 || K < 64 || (N & 3) != 0) return false;
   if ((size_t)M * (size_t)lda >= ((size_t)1 << 30)) return false;   // the split kernel's 32-bit byte offsets (x3_check_common): f32 family instead
-  const long need = (long)prm->x3_min_rows * (N >= 1536 ? 4 : (N >= 1024 ? 7 : 11)) / 4;
+  const long need = (long)prm->x3_min_rows * (N >= 1536 ? 4 : (N >= 1024 ? ff_knob(FF_K_X3_NEED_N1024) : ff_knob(FF_K_X3_NEED_N512))) / 4;
   return M >= need;
 }
 
 // The same product through the 3 x bf16 kernel when the weight's planes are bound and the launch is in the
 // range where it wins.
-int gemm_or_x3(const ff_decode_params* prm, const void* planes, const float* A, int lda, const float* A2, int n_split,
+int gemm_or_x3(const ff_model* m, const ff_decode_params* prm, const void* planes, const float* A, int lda, const float* A2, int n_split,
                const float* W, int ldw, const float* bias, const float* res, int ldr, float* C, int ldc, int M,
                int N, int K, int act, hipStream_t st) {
   if (planes && x3_wins(prm, M, N, K, lda) && (!A2 || (n_split % 128) == 0))
-    return ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
+    return m->split_kind == 1 ? ff_gemm_x2h(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st)
+                              : ff_gemm_x3(A, lda, A2, n_split, planes, bias, res, ldr, C, ldc, M, N, K, act, st);
   return gemm(A, lda, A2, n_split, W, ldw, bias, res, ldr, C, ldc, M, N, K, act, st);
 }
 
@@ -239,6 +241,9 @@ constexpr int FF_PINNED_SLOTS = 65536;   // host-mapped stop counters allocated 
 struct EngineKnobs {
   bool l0_fold, pointer_fold, dbg_timing;
   int one_launch_rows, pinned;
+  int kv_touch;              // experiment FF_KV_TOUCH (0 off)
+  hipStream_t touch_st;      // ... its side stream and fork event (set by ff_decode; null: off)
+  hipEvent_t touch_ev;
 };
 EngineKnobs engine_knobs(const ff_decode_params* p) {
   EngineKnobs k;
@@ -248,6 +253,8 @@ EngineKnobs engine_knobs(const ff_decode_params* p) {
   k.one_launch_rows = ff_knob(FF_K_LAST_QKV_ONE_LAUNCH_ROWS);
   const int pc = ff_knob(FF_K_PINNED_COUNTERS);
   k.pinned = pc > 0 && pc < FF_PINNED_SLOTS ? pc : FF_PINNED_SLOTS;
+  k.kv_touch = ff_knob(FF_K_KV_TOUCH);
+  k.touch_st = nullptr; k.touch_ev = nullptr;
   return k;
 }
 
@@ -366,7 +373,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKno
     d.row_table = table; d.ld_row_table = ldt; d.row_div = Bc; d.row_cols = tcols;
     d.ln_stats_out = st_out;
     if (planes && x3_wins(prm, M, N, K, lda) && (!st_in || K == 512) && (!table || (tcols & 3) == 0))
-      return ff_gemm_x3_ln(&d, planes, plane_rows, row0, st_in ? colsum : nullptr, st);
+      return m->split_kind == 1 ? ff_gemm_x2h_ln(&d, planes, plane_rows, row0, st_in ? colsum : nullptr, st)
+                                : ff_gemm_x3_ln(&d, planes, plane_rows, row0, st_in ? colsum : nullptr, st);
     return ff_gemm_f32_ln(&d, st);
   };
 
@@ -425,7 +433,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKno
         FF_RETURN_IF(gemm(buf.yq + newoff * E, E, nullptr, 0, w.self_attn.in_proj_w, E, w.self_attn.in_proj_b, nullptr, 0,
                           buf.qkv + newoff * 3 * E, 3 * E, Bc, E, E, 0, st));
       } else {
-        FF_RETURN_IF(gemm_or_x3(prm, w.in_proj_planes, buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E,
+        FF_RETURN_IF(gemm_or_x3(m, prm, w.in_proj_planes, buf.yq, E, buf.y, 2 * E, w.self_attn.in_proj_w, E,
                                 w.self_attn.in_proj_b, nullptr, 0, buf.qkv, 3 * E, R, 3 * E, E, 0, st));
       }
       QKV = buf.qkv;
@@ -453,10 +461,18 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKno
       FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
                            buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.self_out_planes, E, 0));
       // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
+      const bool touch = kn.kv_touch && kn.touch_st && ck.nw == 1 && S <= 288 && !last && t >= 8;
+      auto kv_touch = [&]() -> int {   // experiment: this layer's K | V towards the L2s that will read them, from the side stream
+        FF_CHECK_HIP(hipEventRecord(kn.touch_ev, st));
+        FF_CHECK_HIP(hipStreamWaitEvent(kn.touch_st, kn.touch_ev, 0));
+        return ff_kv_touch(bufs.kvc[l] + (size_t)ck.w0 * S * 2 * E, 2 * E, S, H, kn.touch_st);
+      };
+      if (touch && kn.kv_touch == 1) FF_RETURN_IF(kv_touch());
       FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
                            w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr, w.ln2_planes, E, 0, w.ln2_csum));
+      if (touch && kn.kv_touch == 2) FF_RETURN_IF(kv_touch());
     } else {
-      FF_RETURN_IF(gemm_or_x3(prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
+      FF_RETURN_IF(gemm_or_x3(m, prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
                               w.self_attn.out_b, xin + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
       // ---- cross attention: q = LN2(x) + qpos, k = memory + pos, v = memory (transformer.py:247-252);
       //      K/V come from the per-batch cache ----
@@ -466,7 +482,7 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKno
       else
         FF_RETURN_IF(ff_layernorm(buf.x, E, w.norm2_w, w.norm2_b, m->ln_eps, nullptr, 0, buf.yq, E, qpos, E, Bc, T,
                                   Rl, E, st));
-      FF_RETURN_IF(gemm_or_x3(prm, w.cross_q_planes, buf.yq + roff * E, E, nullptr, 0, w.cross_attn.in_proj_w, E,
+      FF_RETURN_IF(gemm_or_x3(m, prm, w.cross_q_planes, buf.yq + roff * E, E, nullptr, 0, w.cross_attn.in_proj_w, E,
                               w.cross_attn.in_proj_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, st));
     }
     {
@@ -494,14 +510,14 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKno
       FF_RETURN_IF(gemm_ln(buf.h + roff * FFd, FFd, w.lin2_w, FFd, w.lin2_b, buf.x + roff * E, E, buf.x + roff * E, E,
                            Rl, E, FFd, 0, nullptr, nullptr, 0, 0, stat, w.lin2_planes, E, 0));
     } else {
-      FF_RETURN_IF(gemm_or_x3(prm, w.cross_out_planes, buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E,
+      FF_RETURN_IF(gemm_or_x3(m, prm, w.cross_out_planes, buf.o + roff * E, E, nullptr, 0, w.cross_attn.out_w, E,
                               w.cross_attn.out_b, buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
       // ---- feed forward (transformer.py:253-255) ----
       FF_RETURN_IF(ff_layernorm(buf.x + roff * E, E, w.norm3_w, w.norm3_b, m->ln_eps, buf.y + roff * E, E, nullptr, 0,
                                 nullptr, 0, 1, 1, Rl, E, st));
-      FF_RETURN_IF(gemm_or_x3(prm, w.lin1_planes, buf.y + roff * E, E, nullptr, 0, w.lin1_w, E, w.lin1_b, nullptr, 0,
+      FF_RETURN_IF(gemm_or_x3(m, prm, w.lin1_planes, buf.y + roff * E, E, nullptr, 0, w.lin1_w, E, w.lin1_b, nullptr, 0,
                               buf.h + roff * FFd, FFd, Rl, FFd, E, 1, st));
-      FF_RETURN_IF(gemm_or_x3(prm, w.lin2_planes, buf.h + roff * FFd, FFd, nullptr, 0, w.lin2_w, FFd, w.lin2_b,
+      FF_RETURN_IF(gemm_or_x3(m, prm, w.lin2_planes, buf.h + roff * FFd, FFd, nullptr, 0, w.lin2_w, FFd, w.lin2_b,
                               buf.x + roff * E, E, buf.x + roff * E, E, Rl, E, FFd, 0, st));
     }
   }
@@ -538,6 +554,8 @@ struct StreamPool {
   hipStream_t side[FF_MAX_STREAMS];
   hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];
   hipEvent_t chk_ev[FF_MAX_STREAMS];      // stop-rule check: per-stream progress marks
+  hipStream_t touch_st;                     // experiment FF_KV_TOUCH: side stream + fork / join events
+  hipEvent_t touch_ev, touch_join;
   int* hpin;                                // host-mapped pinned counters [step][micro-batch], written by the pointer launches
   int* hpin_dev;                            // ... the device-visible address of the same memory
   int created;
@@ -567,6 +585,9 @@ int pool_get(int n, StreamPool** out) {
     FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.hpin), sizeof(int) * FF_PINNED_SLOTS,
                                hipHostMallocMapped | hipHostMallocCoherent));
     FF_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&pool.hpin_dev), pool.hpin, 0));
+    FF_CHECK_HIP(hipStreamCreateWithFlags(&pool.touch_st, hipStreamNonBlocking));
+    FF_CHECK_HIP(hipEventCreateWithFlags(&pool.touch_ev, hipEventDisableTiming));
+    FF_CHECK_HIP(hipEventCreateWithFlags(&pool.touch_join, hipEventDisableTiming));
     pool.events = true;
   }
   while (pool.created < n) {
@@ -697,7 +718,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   Bump bp(workspace, workspace_bytes);
   DecodeBuffers buf;
   const int nch = (int)chunks.size();
-  const EngineKnobs kn = engine_knobs(p);
+  EngineKnobs kn = engine_knobs(p);
   layout_decode(m, p, kn, (size_t)Btot, (size_t)max_bc, (size_t)nch, bp, &buf);
   if (!bp.ok) { ff_set_error("ff_decode: workspace too small (%zu needed, %zu given)", bp.off, workspace_bytes); return FF_ERR_WORKSPACE; }
   for (Chunk& c : chunks) {
@@ -723,6 +744,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_RETURN_IF(pool_get(forked ? ns : 0, &pool));   // (also owns the pinned counter buffer / events of the stop check)
   if (forked)
     for (int s = 0; s < ns; ++s) sts[s] = pool->side[s];
+  if (kn.kv_touch && !forked) { kn.touch_st = pool->touch_st; kn.touch_ev = pool->touch_ev; }
   auto sync_all = [&]() -> int {
     for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamSynchronize(sts[s]));
     return FF_OK;
@@ -872,6 +894,10 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks (%d of %d sequences decoded): %.2f ms; until GPU idle: "
                       "%.2f ms\n", enq, chunks.size(), Btot, N * F, host_ms, tot_ms);
     }
+    if (kn.touch_st) {   // the touch launches read the caller's workspace: the main stream ends behind them
+      FF_CHECK_HIP(hipEventRecord(pool->touch_join, kn.touch_st));
+      FF_CHECK_HIP(hipStreamWaitEvent(main_st, pool->touch_join, 0));
+    }
     if (forked) {  // join
       for (int s = 0; s < ns; ++s) {
         FF_CHECK_HIP(hipEventRecord(pool->join_ev[s], sts[s]));
@@ -883,6 +909,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   {
     const int rc = run();
     if (rc != FF_OK) {
+      if (kn.touch_st) (void)hipStreamSynchronize(kn.touch_st);
       for (int s = 0; s < ns; ++s) (void)hipStreamSynchronize(sts[s]);
       (void)hipStreamSynchronize(main_st);
       return rc;

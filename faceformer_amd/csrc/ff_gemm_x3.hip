@@ -62,6 +62,7 @@ struct X3Args {
   int lda, ldr, ldc;
   int M, N, K;
   int n_split, act;
+  int nt;                    // gemm_x3_kernel: terms per operand -- 3 (bf16 planes) or 2 (fp16 planes, ff_gemm_x2h)
   int tiles_m, tiles_n;
   long long plane_stride;  // elements between two planes of Wp
   int w_rows, w_row0;      // the planes describe a [w_rows, K] weight; the product uses rows [w_row0, w_row0 + N)
@@ -111,6 +112,24 @@ __global__ void split_weight_kernel(const float* __restrict__ W, int ldw, int N,
     o[at] = p1;
     o[plane + at] = p2;
     o[2 * plane + at] = p3;
+  }
+}
+
+// fp16 terms of the same layout ([plane][k / 16][row][k % 16], two planes): w1 = fp16(w), w2' = fp16((w - w1) 2^11)
+__global__ void split_weight_fp16_kernel(const float* __restrict__ W, int ldw, int N, int K, unsigned short* __restrict__ P) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const size_t n2 = (size_t)N * (K / 2);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / (K / 2), c = (i % (K / 2)) * 2;
+    const float x0 = W[row * ldw + c], x1 = W[row * ldw + c + 1];
+    const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+    const f16x2 l = __builtin_convertvector(f32x2{(x0 - (float)h[0]) * 2048.0f, (x1 - (float)h[1]) * 2048.0f}, f16x2);
+    unsigned* o = reinterpret_cast<unsigned*>(P);
+    const size_t plane = (size_t)N * K / 2;
+    const size_t at = ((c >> 4) * (size_t)N + row) * 8 + ((c & 15) >> 1);
+    o[at] = __builtin_bit_cast(unsigned, h);
+    o[plane + at] = __builtin_bit_cast(unsigned, l);
   }
 }
 
@@ -168,7 +187,7 @@ constexpr int X3_STAT_BYTES = 16384;   // MODE 1: one 4 KB patch per wave (32 ro
 // bits: |x| must stay below 65504, which the callers guarantee (LayerNorm output is bounded by sqrt(K); the engine checks the
 // norm bounds of the other operands when it binds the planes: faceformer_amd/hip/engine.py).
 template <int BM, int MODE, int NT>
-__global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3_kernel(X3Args g) {
+__global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3_kernel(X3Args g) {   // (MODE 3 with two terms at three blocks per CU: 368 B of scratch, 10 accesses inside the MFMA runs -- stays at two)
   constexpr int BN = X3_BN, BK = X3_BK;
   constexpr int WN = 128 / BM;              // waves along N: 1 or 2
   constexpr int NI = BN / WN / 32;          // 32-column accumulators per wave: 4 or 2
@@ -380,6 +399,10 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
         x1 = x3_fmul(x3_fsub(x1, mean_s), rstd_s);
       }
       if (NT == 2) {     // fp16 terms: x1 = fp16(x) (round to nearest), residual exact in fp32
+        if (MODE == 3) {   // RAW (un-normalised) rows: 2^-6 keeps |x| up to 4.2e6 inside fp16's range (undone, exactly, per tile)
+          x0 = x3_fmul(x0, 0.015625f);
+          x1 = x3_fmul(x1, 0.015625f);
+        }
         const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
         p1_[q] = __builtin_bit_cast(unsigned, h);
         r_[q][0] = x3_fsub(x0, (float)h[0]);
@@ -434,7 +457,8 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {   // (fp16 terms: the small products were accumulated at 2^11 times their weight)
-        acc[ni][e] += NT == 2 ? accs[ni][e] * (1.0f / 2048.0f) : accs[ni][e];
+        if (NT == 2 && MODE == 3) acc[ni][e] = acc[ni][e] * 64.0f + accs[ni][e] * (64.0f / 2048.0f);   // (... and the rows at 2^-6)
+        else acc[ni][e] += NT == 2 ? accs[ni][e] * (1.0f / 2048.0f) : accs[ni][e];
         accs[ni][e] = 0.f;
       }
     if (cp_kind == 1) {
@@ -1254,18 +1278,18 @@ int x3_acquire(hipStream_t st, X3Args* out) {
 // tuning / tests: force the launch shape (0 auto, 1 whole tiles, 2 unit ranges)
 int g_x3_force_shape = 0;
 
-template <int BM, int MODE>
+template <int BM, int MODE, int NT = 3>
 int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
   static std::atomic<bool> attr_set[16] = {};   // hipFuncSetAttribute is per device; host threads may race here (idempotent)
-  constexpr int bytes = 3 * (BM * 64 + 3 * X3_BN * 32) + (MODE == 1 ? X3_STAT_BYTES : 0);
+  constexpr int bytes = 3 * (BM * 64 + NT * X3_BN * 32) + (MODE == 1 ? X3_STAT_BYTES : 0);
   int dev = 0;
   FF_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<BM, MODE>),
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<BM, MODE, NT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((gemm_x3_kernel<BM, MODE>), dim3(grid), dim3(256), bytes, st, g);
+  hipLaunchKernelGGL((gemm_x3_kernel<BM, MODE, NT>), dim3(grid), dim3(256), bytes, st, g);
   FF_CHECK_LAUNCH();
   return FF_OK;
 }
@@ -1342,7 +1366,13 @@ int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
     return dma_f32_launch_mode<BM, 0>(g, (int)grid, st);
   }
   FFProfScope prof(FF_CAT_GEMM_X3, 2.0 * M * N * K, st);
-  ff_prof_add_bytes(FF_CAT_GEMM_X3, 4.0 * (double)M * K + 6.0 * (double)N * K + 4.0 * (double)M * N * (g.res ? 2 : 1));
+  ff_prof_add_bytes(FF_CAT_GEMM_X3, 4.0 * (double)M * K + 2.0 * (g.nt == 2 ? 2 : 3) * (double)N * K + 4.0 * (double)M * N * (g.res ? 2 : 1));
+  if (g.nt == 2) {
+    if (mode == 1) return x3_launch_mode<BM, 1, 2>(g, (int)grid, st);
+    if (mode == 2) return x3_launch_mode<BM, 2, 2>(g, (int)grid, st);
+    if (mode == 3) return x3_launch_mode<BM, 3, 2>(g, (int)grid, st);
+    return x3_launch_mode<BM, 0, 2>(g, (int)grid, st);
+  }
   if (mode == 1) return x3_launch_mode<BM, 1>(g, (int)grid, st);
   if (mode == 2) return x3_launch_mode<BM, 2>(g, (int)grid, st);
   if (mode == 3) return x3_launch_mode<BM, 3>(g, (int)grid, st);
@@ -1406,6 +1436,19 @@ extern "C" int ff_split_weight_bf16x3(const float* W, int ldw, int N, int K, voi
   return FF_OK;
 }
 
+extern "C" size_t ff_split_weight_fp16x2_bytes(int N, int K) { return (size_t)2 * N * K * sizeof(unsigned short); }
+
+extern "C" int ff_split_weight_fp16x2(const float* W, int ldw, int N, int K, void* planes, ff_stream_t stream) {
+  FF_CHECK_ARG(W && planes && N > 0 && K > 0 && (K & 15) == 0 && ldw >= K, "ff_split_weight_fp16x2: bad arguments (K %% 16)");
+  FF_CHECK_ARG(ff_aligned16(planes), "ff_split_weight_fp16x2: planes must be 16-byte aligned");
+  const size_t n2 = (size_t)N * (K / 2);
+  const int grid = (int)((n2 + 255) / 256 < 4096 ? (n2 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split_weight_fp16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
+                     static_cast<unsigned short*>(planes));
+  FF_CHECK_LAUNCH();
+  return FF_OK;
+}
+
 extern "C" int ff_x3_prepare_stream(hipStream_t st) {
   X3Args g;
   return x3_acquire(st, &g);
@@ -1428,15 +1471,17 @@ extern "C" int ff_set_x3_tuning(int shape) {
   return FF_OK;
 }
 
-extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
-                          const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
-                          int K, int act, ff_stream_t stream) {
+namespace {
+int gemm_split_plain(int nt, const char* who, const float* A, int lda, const float* A2, int n_split, const void* w_planes,
+                     const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
+                     int K, int act, ff_stream_t stream) {
   if (M == 0 || N == 0) return FF_OK;
-  FF_RETURN_IF(x3_check_common(A, lda, w_planes, bias, residual, ldr, C, ldc, M, N, K, act, "ff_gemm_x3"));
-  FF_CHECK_ARG(!A2 || ff_aligned16(A2), "ff_gemm_x3: A2 must be 16-byte aligned");
-  if (A2) FF_CHECK_ARG(n_split > 0 && n_split < N && (n_split % 128) == 0, "ff_gemm_x3: n_split must be a multiple of 128 inside (0,N)");
+  FF_RETURN_IF(x3_check_common(A, lda, w_planes, bias, residual, ldr, C, ldc, M, N, K, act, who));
+  FF_CHECK_ARG(!A2 || ff_aligned16(A2), "%s: A2 must be 16-byte aligned", who);
+  if (A2) FF_CHECK_ARG(n_split > 0 && n_split < N && (n_split % 128) == 0, "%s: n_split must be a multiple of 128 inside (0,N)", who);
   X3Args g;
   memset(&g, 0, sizeof(g));
+  g.nt = nt;
   g.A = A; g.A2 = A2; g.lda = lda;
   g.Wp = static_cast<const unsigned short*>(w_planes); g.bias = bias; g.res = residual; g.ldr = ldr;
   g.C = C; g.ldc = ldc;
@@ -1444,6 +1489,18 @@ extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split,
   g.plane_stride = (long long)N * K;
   g.w_rows = N; g.w_row0 = 0;
   return x3_launch(g, 0, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
+                          const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
+                          int K, int act, ff_stream_t stream) {
+  return gemm_split_plain(3, "ff_gemm_x3", A, lda, A2, n_split, w_planes, bias, residual, ldr, C, ldc, M, N, K, act, stream);
+}
+extern "C" int ff_gemm_x2h(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
+                           const float* bias, const float* residual, int ldr, float* C, int ldc, int M, int N,
+                           int K, int act, ff_stream_t stream) {
+  return gemm_split_plain(2, "ff_gemm_x2h", A, lda, A2, n_split, w_planes, bias, residual, ldr, C, ldc, M, N, K, act, stream);
 }
 
 // x3_ln_linear -- why the consumer's normalisation may move into the epilogue.  LN(x) W'^T = rstd (x W'^T - mean s), s = the row
@@ -1453,8 +1510,9 @@ extern "C" int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split,
 // |mean| / sigma is 0.06 (median) / 0.15 (maximum over 50 836 rows of a gain-4 decode) and the two forms are equally far from
 // fp64 (5.2e-7 vs 5.1e-7 relative); callers whose rows can have |mean| >> sigma pass w_colsum = NULL and get the
 // normalise-first form (MODE 1).
-extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
-                             ff_stream_t stream) {
+namespace {
+int gemm_split_ln(int nt, const ff_gemm_ln_desc* d, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
+                  ff_stream_t stream) {
   FF_CHECK_ARG(d != nullptr, "ff_gemm_x3_ln: null descriptor");
   const int M = d->M, N = d->N, K = d->K;
   if (M == 0 || N == 0) return FF_OK;
@@ -1471,6 +1529,7 @@ extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int
   FF_CHECK_ARG(!d->ln_stats_out || (N & 31) == 0, "ff_gemm_x3_ln: ln_stats_out needs N %% 32 == 0");
   X3Args g;
   memset(&g, 0, sizeof(g));
+  g.nt = nt;
   g.A = d->A; g.lda = d->lda;
   g.Wp = static_cast<const unsigned short*>(w_planes); g.bias = d->bias; g.res = d->residual; g.ldr = d->ldr;
   g.C = d->C; g.ldc = d->ldc;
@@ -1483,4 +1542,16 @@ extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int
   g.colsum = w_colsum;
   FF_CHECK_ARG(!w_colsum || (ff_aligned16(w_colsum) && (row0 & 3) == 0), "ff_gemm_x3_ln: w_colsum must be 16-byte aligned, row0 %% 4 == 0");
   return x3_launch(g, d->ln_stats_in ? (w_colsum ? 3 : 1) : (d->ln_stats_out ? 2 : 0), (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int ff_gemm_x3_ln(const ff_gemm_ln_desc* d, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
+                             ff_stream_t stream) {
+  return gemm_split_ln(3, d, w_planes, plane_rows, row0, w_colsum, stream);
+}
+// ... on fp16 planes (ff_split_weight_fp16x2).  w_colsum selects the epilogue form of the LayerNorm, which multiplies the RAW rows:
+// the caller must know them to be inside fp16's range (|x| < 65504); the normalise-first form (w_colsum = NULL) needs no such bound.
+extern "C" int ff_gemm_x2h_ln(const ff_gemm_ln_desc* d, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
+                              ff_stream_t stream) {
+  return gemm_split_ln(2, d, w_planes, plane_rows, row0, w_colsum, stream);
 }

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import lib as _L
-from .ops import _dev, _p, _stream, split_weight
+from .ops import SPLIT_KINDS, _dev, _p, _stream, split_weight
 
 import operator
 
@@ -30,8 +30,11 @@ class PathEngine:
     """
 
     def __init__(self, tensors, num_head, num_token=4, ln_eps=1e-5, bf16_split_planes=False, fold_layernorm=True,
-                 ln_in_epilogue=True):
+                 ln_in_epilogue=True, split_kind="bf16x3"):
         self._lib = _L.load()
+        if split_kind not in SPLIT_KINDS:
+            raise ValueError("split_kind must be one of %s" % sorted(SPLIT_KINDS))
+        self.split_kind = split_kind
         self._keep = {}
         self._bound_at = {}
         self._planes = {}
@@ -96,7 +99,7 @@ class PathEngine:
                         wt = wt[:E_]  # q rows only: k|v of the cross attention are projected once per batch
                     if wt.shape[1] % 32 or wt.shape[1] < 64:
                         continue      # the bf16-split kernel needs K % 32 == 0: this weight stays f32-only (null planes)
-                    pl = split_weight(wt)
+                    pl = split_weight(wt, split_kind)
                     self._planes[(i, field)] = pl
                     setattr(m.dec[i], field, pl.data_ptr())
         m.dec_norm_w, m.dec_norm_b = get("decoder.norm.weight"), get("decoder.norm.bias")
@@ -124,7 +127,7 @@ class PathEngine:
                         # folding (ff_gemm_x3_ln) instead of launching their LayerNorms
                         for field, cfield, key in (("ln1_planes", "ln1_csum", (i, 1)), ("ln2_planes", "ln2_csum", (i, 2)),
                                                    ("ln3_planes", "ln3_csum", (i, 3))):
-                            pl = split_weight(self._folded[key][0])
+                            pl = split_weight(self._folded[key][0], split_kind)
                             self._planes[(i, field)] = pl
                             setattr(lw, field, pl.data_ptr())
                             if ln_in_epilogue:
@@ -135,6 +138,9 @@ class PathEngine:
                 m.proj_fold_w, m.proj_fold_b, _ = self._fold(
                     ("proj",), tensors["project.weight"], tensors["project.bias"],
                     tensors["decoder.norm.weight"], tensors["decoder.norm.bias"], None, 0)
+        m.split_kind = SPLIT_KINDS[split_kind] if self._planes else 0
+        if self._planes and split_kind == "fp16x2":
+            self._check_fp16_range(tensors, n_dec, E)
         self.model = m
         self.E, self.H, self.num_token = E, num_head, num_token
         self.device = tensors["project.weight"].device
@@ -147,6 +153,41 @@ class PathEngine:
         # the stream-K exchange buffer of the launch stream is allocated here, not inside the first decode
         with torch.cuda.device(self.device):
             _L.check(self._lib.ff_gemm_prepare_stream(_stream()), "ff_gemm_prepare_stream")
+
+    def _check_fp16_range(self, tensors, n_dec, E):
+        """fp16 has five exponent bits: every operand of a "2 x fp16" product must stay below 65504 in magnitude.  Weights are
+        checked directly.  The activations are bounded a priori: LayerNorm-normalised rows by sqrt(E); the raw rows of the
+        epilogue form are fed at 2^-6 (< 4.2e6); the attention outputs by max |v| <= sqrt(E) ||Wv_n||_2 + |b_n| (a row of a
+        softmax-weighted mean of value rows; v = LN(.) Wv'^T + b or memory Wv^T + b, memory being LayerNorm output as well),
+        the feed-forward hidden rows by sqrt(E) ||W1'_n||_2 + |b1_n| (Cauchy-Schwarz, gamma / beta folded in).  A model
+        whose bounds do not fit is refused here -- loudly -- instead of overflowing inside a kernel."""
+        lim = 6.0e4
+        root = float(E) ** 0.5
+
+        def bound(W, b):
+            return float((W.double().norm(dim=1) * root + b.double().abs()).max())
+        worst = {"weights": max(float(t.float().abs().max()) for (_i, f), t in self._planes.items() if t.dim() == 4)}
+        for i in range(n_dec):
+            p = "decoder.layers.%d." % i
+            for name, key in (("self-attention values", (i, 1)), ("feed-forward hidden", (i, 3))):
+                if key in self._folded:
+                    Wf, bf, _ = self._folded[key]
+                    Wv = Wf[2 * E:] if key[1] == 1 else Wf
+                    bv = bf[2 * E:] if key[1] == 1 else bf
+                    worst[name] = max(worst.get(name, 0.0), bound(Wv, bv))
+            # memory = gamma * n + beta with ||n||_2 <= sqrt(E) (the encoder's final LayerNorm): v_n = n . (W_n * gamma) + W_n . beta + b_n
+            Wc, bc = tensors[p + "multihead_attn.in_proj_weight"][2 * E:], tensors[p + "multihead_attn.in_proj_bias"][2 * E:]
+            ge, be = tensors["encoder.norm.weight"], tensors["encoder.norm.bias"]
+            worst["cross-attention values"] = max(worst.get("cross-attention values", 0.0), bound(Wc * ge, Wc @ be + bc))
+            for nm in ("norm1", "norm2", "norm3"):     # un-folded steps: y = gamma * n + beta goes through the planes of the raw weight
+                g_, b_ = tensors[p + nm + ".weight"], tensors[p + nm + ".bias"]
+                worst["LayerNorm outputs"] = max(worst.get("LayerNorm outputs", 0.0), float(g_.abs().max()) * root + float(b_.abs().max()))
+        bad = {k: v for k, v in worst.items() if not v < lim}
+        if bad:
+            raise _L.HipExtensionError(
+                "split_kind='fp16x2': operand bounds outside fp16's range (%s); bind the model with split_kind='bf16x3'"
+                % ", ".join("%s <= %.3g" % kv for kv in sorted(bad.items())))
+        self.fp16_operand_bounds = worst
 
     def _fold(self, key, W, bias, gamma, beta, pos, pos_cols):
         """(Wf, bf, P) device pointers of ff_fold_layernorm_linear for one LayerNorm -> Linear pair."""

@@ -89,6 +89,7 @@ class Model(C.Structure):
         ("dec_norm_w", fptr), ("dec_norm_b", fptr),
         ("proj_w", fptr), ("proj_b", fptr),
         ("proj_fold_w", fptr), ("proj_fold_b", fptr),
+        ("split_kind", C.c_int),
     ]
 
 
@@ -136,6 +137,11 @@ SIGNATURES = {
     "ff_gemm_x3": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_int,
                              C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "ff_gemm_x3_ln": (C.c_int, [C.POINTER(GemmLnDesc), fptr, C.c_int, C.c_int, fptr, fptr]),
+    "ff_split_weight_fp16x2_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ff_split_weight_fp16x2": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, fptr]),
+    "ff_gemm_x2h": (C.c_int, [fptr, C.c_int, fptr, C.c_int, fptr, fptr, fptr, C.c_int, fptr, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "ff_gemm_x2h_ln": (C.c_int, [C.POINTER(GemmLnDesc), fptr, C.c_int, C.c_int, fptr, fptr]),
     "ff_set_x3_tuning": (C.c_int, [C.c_int]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),

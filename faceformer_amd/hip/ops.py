@@ -193,7 +193,9 @@ def linear_x3_ln(x, planes, bias=None, act=0, residual=None, stats_in=None, eps=
         d.ln_stats_out = _p(stats)
     if colsum is not None:
         _dev(colsum, "colsum")
-    _L.check(_L.load().ff_gemm_x3_ln(C.byref(d), planes.data_ptr(), plane_rows, row0, _p(colsum), _stream()), "ff_gemm_x3_ln")
+    lib = _L.load()
+    fn, who = (lib.ff_gemm_x2h_ln, "ff_gemm_x2h_ln") if planes.dtype == torch.float16 else (lib.ff_gemm_x3_ln, "ff_gemm_x3_ln")
+    _L.check(fn(C.byref(d), planes.data_ptr(), plane_rows, row0, _p(colsum), _stream()), who)
     return (out, stats) if want_stats else out
 
 
@@ -331,14 +333,24 @@ def set_gemm_tuning(min_units=2, two_per_cu_units=2048, fix_tenths=25, small_max
                                           int(small_max_rows)), "ff_set_gemm_tuning")
 
 
+SPLIT_KINDS = {"bf16x3": 0, "fp16x2": 1}     # ff_model.split_kind
+
+
 @_on_tensor_device
-def split_weight(weight):
-    """[N, K] fp32 matrix -> its three bf16 planes in the K-blocked layout [3, K/16, N, 16]
-    (planes_to_matrix(planes) == weight up to 2^-25 relative)."""
+def split_weight(weight, kind="bf16x3"):
+    """[N, K] fp32 matrix -> its split planes in the K-blocked layout [terms, K/16, N, 16]: three bf16 planes ("bf16x3",
+    planes_to_matrix(planes) == weight up to 2^-25 relative) or two fp16 planes ("fp16x2": w1 = fp16(w), w2' = fp16((w - w1) 2^11),
+    22 mantissa bits; |w| must be < 65504)."""
     weight, ldw = _rows(weight, "weight")
     N, K = weight.shape
     if K % 16:
         raise ValueError("split_weight: K must be a multiple of 16")
+    if kind == "fp16x2":
+        planes = torch.empty((2, K // 16, N, 16), device=weight.device, dtype=torch.float16)
+        _L.check(_L.load().ff_split_weight_fp16x2(_p(weight), ldw, N, K, planes.data_ptr(), _stream()), "ff_split_weight_fp16x2")
+        return planes
+    if kind != "bf16x3":
+        raise ValueError("split_weight: kind must be 'bf16x3' or 'fp16x2'")
     planes = torch.empty((3, K // 16, N, 16), device=weight.device, dtype=torch.bfloat16)
     _L.check(_L.load().ff_split_weight_bf16x3(_p(weight), ldw, N, K, planes.data_ptr(), _stream()),
              "ff_split_weight_bf16x3")
@@ -346,14 +358,18 @@ def split_weight(weight):
 
 
 def planes_to_matrix(planes):
-    """Inverse of split_weight (fp64 sum of the three terms), [rows, K]."""
+    """Inverse of split_weight (fp64 sum of the terms), [rows, K]."""
     kb, rows = planes.size(1), planes.size(2)
-    return planes.double().sum(0).permute(1, 0, 2).reshape(rows, kb * 16)
+    p = planes.double()
+    total = p[0] + p[1] / 2048.0 if planes.dtype == torch.float16 else p.sum(0)
+    return total.permute(1, 0, 2).reshape(rows, kb * 16)
 
 
 def _check_planes(p, what):
-    if p.dtype != torch.bfloat16 or p.dim() != 4 or p.size(0) != 3 or p.size(3) != 16 or not p.is_contiguous():
-        raise ValueError("linear_x3: %s must be a contiguous [3, K/16, rows, 16] bf16 tensor (split_weight)" % what)
+    ok = (p.dtype == torch.bfloat16 and p.size(0) == 3) or (p.dtype == torch.float16 and p.size(0) == 2)
+    if not ok or p.dim() != 4 or p.size(3) != 16 or not p.is_contiguous():
+        raise ValueError("linear_x3: %s must be a contiguous [3, K/16, rows, 16] bf16 or [2, K/16, rows, 16] fp16 tensor "
+                         "(split_weight)" % what)
 
 
 @_on_tensor_device
@@ -377,6 +393,8 @@ def linear_x3(x, planes, bias=None, act=0, residual=None, x2=None, n_split=0, ou
         residual, ldr = _rows(residual, "residual")
     if bias is not None:
         _dev(bias, "bias")
-    _L.check(_L.load().ff_gemm_x3(_p(x), lda, _p(x2), n_split, planes.data_ptr(), _p(bias), _p(residual), ldr,
-                                  _p(out), ldc, M, N, K, act, _stream()), "ff_gemm_x3")
+    lib = _L.load()
+    fn, who = (lib.ff_gemm_x2h, "ff_gemm_x2h") if planes.dtype == torch.float16 else (lib.ff_gemm_x3, "ff_gemm_x3")
+    _L.check(fn(_p(x), lda, _p(x2), n_split, planes.data_ptr(), _p(bias), _p(residual), ldr,
+                _p(out), ldc, M, N, K, act, _stream()), who)
     return out

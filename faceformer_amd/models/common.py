@@ -12,6 +12,7 @@ from ..transformer import (HipLinear, TransformerDecoder, TransformerDecoderLaye
 from ..utils import min_value_of_dtype
 
 
+SPLIT_KIND_DEFAULT = "fp16x2"   # round 6 (profiles/r06/split_kinds_ab.txt: config B 50.9 -> 45.4 ms, C128 256 k -> 302 k edges/s, margins unchanged)
 X3_MIN_ROWS_DEFAULT = 1024   # package default of SurfaceFormerBase.x3_min_rows (bench.py reports this form beside the f32 headline)
 
 
@@ -67,6 +68,9 @@ class SurfaceFormerBase(nn.Module):
         # split product.  Error factor (1 + |mean| / sigma) of the row -- 0.06 median, 0.15 maximum on this model's LayerNorm
         # inputs; False = rows normalised before the product (ff_gemm_x3.hip: x3_ln_linear).  Read when the engine is bound.
         self.x3_ln_in_epilogue = True
+        # how those projections split an fp32 operand: "bf16x3" (three bf16 terms, six products) or "fp16x2" (two fp16 terms, three
+        # products: half the matrix-core work; the engine checks at bind time that the model's operand bounds fit fp16's range)
+        self.split_kind = SPLIT_KIND_DEFAULT
         self._engine_obj = None
 
     def _reset_parameters(self):
@@ -187,7 +191,8 @@ class SurfaceFormerBase(nn.Module):
         self._check_supported()
         eng = self._engine_obj
         if eng is None or not eng.pointers_current() or eng.has_planes != (self.x3_min_rows > 0) or \
-                eng.ln_in_epilogue != bool(getattr(self, "x3_ln_in_epilogue", True)):
+                eng.ln_in_epilogue != bool(getattr(self, "x3_ln_in_epilogue", True)) or \
+                eng.split_kind != getattr(self, "split_kind", SPLIT_KIND_DEFAULT):
             tensors = {k: v for k, v in self.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             dev = tensors["project.weight"].device
             if dev.type != "cuda":
@@ -197,7 +202,8 @@ class SurfaceFormerBase(nn.Module):
                     ".cuda()." % dev)
             eng = PathEngine(tensors, self.num_head, self.num_token, self.encoder.norm.eps,
                              bf16_split_planes=self.x3_min_rows > 0, fold_layernorm=True,
-                             ln_in_epilogue=getattr(self, "x3_ln_in_epilogue", True))
+                             ln_in_epilogue=getattr(self, "x3_ln_in_epilogue", True),
+                             split_kind=getattr(self, "split_kind", SPLIT_KIND_DEFAULT))
             self._engine_obj = eng
         return eng
 

@@ -191,6 +191,23 @@ int ff_gemm_x3(const float* A, int lda, const float* A2, int n_split, const void
 int ff_gemm_x3_ln(const ff_gemm_ln_desc* desc, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
                   ff_stream_t stream);
 
+/* "2 x fp16" (round 6): the same products on the fp16 matrix cores with HALF the partial products.  x = x1 + x2, x1 = fp16(x),
+ * x2' = fp16((x - x1) 2^11) (the second term is kept at 2^11 times its value: the magnitude of the first, outside fp16's
+ * subnormals): 22 mantissa bits per operand, THREE products x1 y1 + (x1 y2' + x2' y1) 2^-11 (v_mfma_f32_32x32x16_f16; x1 y1 in
+ * its own accumulator).  What is dropped (x2 y2, the last two bits of each operand) stays below the rounding error an fp32
+ * dot product of that length accumulates anyway: against fp64 the result is as close as ff_gemm_f32's (op tests compare the three;
+ * emulation: profiles/r06/fp16_split_error_table.txt).  fp16 has five exponent bits: every |a| must be < 65504 (weights: checked
+ * by the caller when it makes the planes).  LayerNorm-normalised rows are bounded by sqrt(K); the epilogue form (w_colsum) feeds
+ * the RAW rows at 2^-6 (|x| < 4.2e6, exact scaling).  Planes: ff_split_weight_fp16x2, [2][K/16][N][16] fp16,
+ * ff_split_weight_fp16x2_bytes(N, K) bytes.  Arguments, restrictions and replaced call sites as ff_gemm_x3 / ff_gemm_x3_ln. */
+size_t ff_split_weight_fp16x2_bytes(int N, int K);
+int ff_split_weight_fp16x2(const float* W, int ldw, int N, int K, void* planes, ff_stream_t stream);
+int ff_gemm_x2h(const float* A, int lda, const float* A2, int n_split, const void* w_planes,
+                const float* bias, const float* residual, int ldr, float* C, int ldc,
+                int M, int N, int K, int act, ff_stream_t stream);
+int ff_gemm_x2h_ln(const ff_gemm_ln_desc* desc, const void* w_planes, int plane_rows, int row0, const float* w_colsum,
+                   ff_stream_t stream);
+
 /* Launch shape of the 3 x bf16 kernel (process-wide; tests and tools/): 0 = the default -- whole tiles, and when the tile
  * count is not a multiple of the CU count the remaining tiles cut into 2 / 4 / 8 K-pieces, one piece per CU, summed by the
  * block that holds the tile's last piece in ascending piece order --, 1 = whole tiles only, 2 = equal K-unit ranges per
@@ -362,6 +379,8 @@ typedef struct ff_model {
   const float *dec_norm_w, *dec_norm_b;
   const float *proj_w, *proj_b;        /* project [E, E], [E] */
   const float *proj_fold_w, *proj_fold_b; /* optional: decoder.norm folded into project (ff_fold_layernorm_linear) */
+  int split_kind;          /* what the `*_planes` of the decoder layers hold: 0 = three bf16 planes (ff_split_weight_bf16x3, six
+                              products per fp32 product), 1 = two fp16 planes (ff_split_weight_fp16x2, three products; round 6) */
 } ff_model;
 
 /* Encoder (a1-a4 of SURVEY.md 8a): embedding MLP + token rows, 6 pre-norm layers, final LayerNorm.

@@ -258,7 +258,28 @@ def test_gemm_small_rows_kernel_batched(ops):
     assert rel_err(out, a.double() @ w.double().transpose(1, 2)) < 3e-6
 
 
-# ---- GEMM on the bf16 matrix cores (3 x bf16 split) ---------------------------------------------------
+# ---- GEMM on the bf16 / fp16 matrix cores (3 x bf16 split; round 6: 2 x fp16 split, half the products) ------------
+@pytest.fixture(params=["bf16x3", "fp16x2"])
+def split_kind(request):
+    """Both split forms run every product test below: three bf16 terms (six products) and two fp16 terms (three products)."""
+    return request.param
+
+
+def test_split_weight_fp16x2_carries_22_bits(ops):
+    """w = w1 + w2' 2^-11 with w1 = fp16(w), w2' = fp16((w - w1) 2^11): 22 mantissa bits wherever w1 is a normal fp16 number
+    (|w| >= 6.1e-5), an ABSOLUTE error of at most 2^-36 below that; never worse than 2^-21 relative from 1e-4 to 6e4."""
+    w = rnd(200, 512, seed=3) * torch.logspace(-4, 4, 512)
+    w = w.clamp(-6.0e4, 6.0e4)
+    planes = ops.split_weight(w.cuda(), "fp16x2")
+    assert planes.dtype == torch.float16 and tuple(planes.shape) == (2, 32, 200, 16)
+    back = ops.planes_to_matrix(planes).cpu()
+    err = (back - w.double()).abs()
+    assert float((err / w.double().abs().clamp_min(6.2e-5)).max()) < 2.0 ** -21
+    tiny = rnd(64, 64, seed=4) * 1e-6
+    back = ops.planes_to_matrix(ops.split_weight(tiny.cuda(), "fp16x2")).cpu()
+    assert float((back - tiny.double()).abs().max()) <= 2.0 ** -35
+
+
 def test_split_weight_is_exact(ops):
     """The three bf16 planes must reproduce the fp32 weight to 2^-25 relative (exact split)."""
     w = rnd(200, 512, seed=3) * torch.logspace(-6, 3, 512)  # nine decades of magnitudes
@@ -270,11 +291,11 @@ def test_split_weight_is_exact(ops):
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024),
                                    (4100, 1024, 512), (64, 260, 512), (130, 96, 64), (2304, 512, 512),
                                    (9216, 1536, 512)])
-def test_gemm_x3_matches_fp64_like_fp32(ops, M, N, K):
+def test_gemm_x3_matches_fp64_like_fp32(ops, split_kind, M, N, K):
     """3 x bf16 product vs fp64: bias, ReLU and aliased residual; its error must not exceed the f32-MFMA
     kernel's by more than a small factor (both are 'fp32 dot product' accurate)."""
     a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
-    planes = ops.split_weight(w.cuda())
+    planes = ops.split_weight(w.cuda(), split_kind)
     ref0 = a.double() @ w.double().t() + bias.double()
     out = ops.linear_x3(a.cuda(), planes, bias.cuda())
     e_x3 = rel_err(out, ref0)
@@ -300,11 +321,11 @@ def x3_tuning(request, ops):
                                    (2304, 512, 512), (5000, 1024, 512), (9216, 1536, 512), (4608, 512, 1024),
                                    # more than half a round of tiles left over: K-pieces beyond one per CU (no-wait exchange)
                                    (6400, 512, 512), (6400, 1536, 512), (6400, 512, 1024)])
-def test_gemm_x3_every_tile_and_launch_shape(ops, x3_tuning, M, N, K):
+def test_gemm_x3_every_tile_and_launch_shape(ops, split_kind, x3_tuning, M, N, K):
     """Whole tiles and equal K-unit ranges (cut tiles exchanged between blocks): same result up to the summation order,
     deterministic, ragged edges in M and N."""
     a, w, bias, res = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.1), rnd(N, seed=13), rnd(M, N, seed=14)
-    planes = ops.split_weight(w.cuda())
+    planes = ops.split_weight(w.cuda(), split_kind)
     ref = torch.relu(a.double() @ w.double().t() + bias.double()) + res.double()
     x = res.cuda()
     ops.linear_x3(a.cuda(), planes, bias.cuda(), act=1, residual=x, out=x)
@@ -321,14 +342,14 @@ def test_gemm_x3_every_tile_and_launch_shape(ops, x3_tuning, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(37, 512, 512), (300, 512, 1024), (1300, 512, 512), (5000, 512, 512), (640, 128, 256),
                                    (9216, 512, 1024), (6400, 512, 512), (6656, 512, 1024)])
-def test_gemm_x3_emits_layernorm_segment_statistics(hip_lib, ops, x3_tuning, M, N, K):
+def test_gemm_x3_emits_layernorm_segment_statistics(hip_lib, ops, split_kind, x3_tuning, M, N, K):
     """ff_gemm_x3_ln, producer side: C = A W^T + b + residual plus (mean, M2) per row and 32-column segment of the stored C."""
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).cuda()
     W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     b = torch.randn(N, generator=g).cuda()
     res = (3.0 + 2.0 * torch.randn(M, N, generator=g)).cuda()          # non-zero mean: the cancellation trap
-    out, stats = ops.linear_x3_ln(A, ops.split_weight(W), b, residual=res, want_stats=True)
+    out, stats = ops.linear_x3_ln(A, ops.split_weight(W, split_kind), b, residual=res, want_stats=True)
     ref = A.double() @ W.double().t() + b.double() + res.double()
     assert (out.double() - ref).abs().max() < 2e-5 * ref.abs().max()
     want = _seg_stats(out.double())                                    # statistics of what was actually stored
@@ -340,7 +361,7 @@ def test_gemm_x3_emits_layernorm_segment_statistics(hip_lib, ops, x3_tuning, M, 
 @pytest.mark.parametrize("in_epilogue", [False, True], ids=["normalise_first", "normalise_in_epilogue"])
 @pytest.mark.parametrize("M,N,div", [(37, 1536, 5), (300, 512, 7), (1300, 1536, 64), (5000, 1024, 256), (9216, 1536, 256),
                                      (4352, 512, 256), (6400, 1536, 256), (6400, 512, 256)])
-def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, x3_tuning, M, N, div, in_epilogue):
+def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, split_kind, x3_tuning, M, N, div, in_epilogue):
     """ff_gemm_x3_ln, consumer side: act((LN(x) + pos[row // div]) W^T + b) from raw x, its segment statistics, the planes of
     the folded weight, the folded bias and the pos W^T table -- against the unfused arithmetic in float64; rows normalised
     before the product, and the plain product with rstd (x W'^T - mean colsum(W')) in the epilogue (rows with |mean| / sigma
@@ -358,7 +379,7 @@ def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops,
     Wf, bf, P = ops.fold_layernorm_linear(Wd, b.cuda(), gamma.cuda(), beta.cuda(), pos.cuda(), pos_cols)
     stats = _seg_stats(xd.double()).float().contiguous()
     colsum = Wf.double().sum(dim=1).float().contiguous() if in_epilogue else None
-    out = ops.linear_x3_ln(xd, ops.split_weight(Wf), bf, act=1, stats_in=stats, row_table=P, row_div=div, row_cols=pos_cols,
+    out = ops.linear_x3_ln(xd, ops.split_weight(Wf, split_kind), bf, act=1, stats_in=stats, row_table=P, row_div=div, row_cols=pos_cols,
                            colsum=colsum)
     x64 = x.double()
     ln = torch.nn.functional.layer_norm(x64, (K,), gamma.double(), beta.double(), 1e-5)
@@ -373,6 +394,47 @@ def test_gemm_x3_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops,
     assert (out - out32).abs().max() < 3e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("scale_a,scale_w", [(1.0, 0.05), (900.0, 0.22), (1.0, 1e-4), (40.0, 0.05), (1.2e4, 0.05), (1e-3, 0.05)])
+def test_gemm_x2h_error_is_fp32_class_over_operand_scales(ops, scale_a, scale_w):
+    """The 2 x fp16 product against fp64 at the operand scales of profiles/r06/fp16_split_error_table.txt (LayerNorm output x
+    xavier weight, gain-4 residual stream, tiny weights, ReLU hidden rows, rows close to fp16's range, small rows): the error
+    relative to |A| |W|^T stays within 1.5x the f32-MFMA kernel's -- an fp32 dot product's -- everywhere."""
+    M, N, K = 512, 512, 512
+    a = rnd(M, K, seed=21) * scale_a
+    if scale_a == 40.0:
+        a = torch.relu(a)
+    w = (torch.rand(N, K, generator=torch.Generator().manual_seed(22)) * 2 - 1) * scale_w
+    ref = a.double() @ w.double().t()
+    den = a.double().abs() @ w.double().abs().t()
+    got = ops.linear_x3(a.cuda(), ops.split_weight(w.cuda(), "fp16x2"), None).cpu().double()
+    f32 = ops.linear(a.cuda(), w.cuda(), None).cpu().double()
+    e_h, e_f = ((got - ref).abs() / den).max(), ((f32 - ref).abs() / den).max()
+    r_h, r_f = (((got - ref) / den) ** 2).mean().sqrt(), (((f32 - ref) / den) ** 2).mean().sqrt()
+    assert torch.isfinite(got).all()
+    assert e_h < 1.5 * e_f + 2.0 ** -24 and r_h < 1.5 * r_f + 2.0 ** -26, (float(e_h), float(e_f), float(r_h), float(r_f))
+
+
+def test_gemm_x2h_epilogue_form_takes_raw_rows_beyond_fp16_range(hip_lib, ops):
+    """The LayerNorm-in-the-epilogue form multiplies the RAW rows; the fp16 kernel feeds them at 2^-6 (exact), so rows of
+    magnitude 2e5 -- far outside fp16's 65504 -- come out finite and as accurate as the normalise-first form."""
+    M, N, K = 300, 512, 512
+    g = torch.Generator().manual_seed(5)
+    x = (2.0e5 * torch.randn(M, K, generator=g))
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    xd = x.cuda()
+    Wf, bf, _ = ops.fold_layernorm_linear(W.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), None, 0)
+    stats = _seg_stats(xd.double()).float().contiguous()
+    colsum = Wf.double().sum(dim=1).float().contiguous()
+    planes = ops.split_weight(Wf, "fp16x2")
+    ref = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ W.double().t() + b.double()
+    for cs in (colsum, None):
+        out = ops.linear_x3_ln(xd, planes, bf, stats_in=stats, colsum=cs).cpu().double()
+        assert torch.isfinite(out).all()
+        assert (out - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max())
+
+
 def test_gemm_x3_ln_argument_validation(hip_lib, ops):
     from faceformer_amd.hip import lib as L
     x = torch.randn(64, 256).cuda()
@@ -385,20 +447,20 @@ def test_gemm_x3_ln_argument_validation(hip_lib, ops):
         ops.set_x3_tuning(3)
 
 
-def test_gemm_x3_split_a(ops):
+def test_gemm_x3_split_a(ops, split_kind):
     M, E = 300, 512
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
-    out = ops.linear_x3(yq.cuda(), ops.split_weight(w.cuda()), b.cuda(), x2=y.cuda(), n_split=2 * E)
+    out = ops.linear_x3(yq.cuda(), ops.split_weight(w.cuda(), split_kind), b.cuda(), x2=y.cuda(), n_split=2 * E)
     ref = torch.cat([yq.double() @ w[: 2 * E].double().t(), y.double() @ w[2 * E:].double().t()], 1) + b.double()
     assert rel_err(out, ref) < 3e-6
 
 
-def test_gemm_x3_identity_layout(ops):
+def test_gemm_x3_identity_layout(ops, split_kind):
     K = 64
     eye = torch.eye(K)
     w = rnd(96, K, seed=9)
-    out = ops.linear_x3(eye.cuda(), ops.split_weight(w.cuda()), None)
-    assert float((out.cpu() - w.t()).abs().max()) < 1e-7
+    out = ops.linear_x3(eye.cuda(), ops.split_weight(w.cuda(), split_kind), None)
+    assert float((out.cpu() - w.t()).abs().max()) < (1e-7 if split_kind == "bf16x3" else 2e-6)   # (24 / 22 bits of |w| <= 4.5)
 
 
 # ---- attention --------------------------------------------------------------------------------------

@@ -214,28 +214,32 @@ def test_golden_parity_on_the_f32_matrix_cores_only(hip_lib, name):
     _record_margin(name, "f32 MFMA only, LN folded always", st)
 
 
+@pytest.mark.parametrize("kind", ["bf16x3", "fp16x2"])
 @pytest.mark.parametrize("min_rows", [1, 300])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows):
-    """The same bars with the decoder projections evaluated as 3 x bf16 split products on the bf16 matrix cores (every step:
-    min_rows=1; only the longer prefixes: 300) -- with the LayerNorms folded into them (ff_gemm_x3_ln: the E = 512 goldens)
-    and, second pass, with standalone LayerNorm launches in front of the plain split products."""
+def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows, kind):
+    """The same bars with the decoder projections evaluated as split products on the 16-bit matrix cores -- three bf16 terms / six
+    products, and (round 6) two fp16 terms / three products -- on every step (min_rows=1) or only the longer prefixes (300):
+    with the LayerNorms folded into them (ff_gemm_x3_ln / ff_gemm_x2h_ln: the E = 512 goldens) and, second and third pass, with
+    the rows normalised before the product and with standalone LayerNorm launches in front of the plain split products."""
     case, z = load_golden(name)
     sd, batch = case_weights_and_batch(case)
     model = build_model(case, sd, "cuda")
     model.x3_min_rows = min_rows
+    model.split_kind = kind
     out = run_traced(model, case, batch_to(batch, "cuda"))
+    assert model.engine().split_kind == kind
     stats = compare_with_golden(case, z, out)
     print(name, min_rows, stats)
-    _record_margin(name, "bf16x3 from %d rows" % min_rows, stats)
+    _record_margin(name, "%s from %d rows" % (kind, min_rows), stats)
     model.x3_ln_in_epilogue = False     # rows normalised before the product (the engine re-binds)
     stats = compare_with_golden(case, z, run_traced(model, case, batch_to(batch, "cuda")))
-    _record_margin(name, "bf16x3 from %d rows, LN before product" % min_rows, stats)
+    _record_margin(name, "%s from %d rows, LN before product" % (kind, min_rows), stats)
     model.x3_ln_in_epilogue = True
     from faceformer_amd.hip import lib as L
     model.decode_flags = model.decode_flags & ~L.FF_FUSE_LAYERNORM
     stats = compare_with_golden(case, z, run_traced(model, case, batch_to(batch, "cuda")))
-    _record_margin(name, "bf16x3 from %d rows, standalone LN" % min_rows, stats)
+    _record_margin(name, "%s from %d rows, standalone LN" % (kind, min_rows), stats)
 
 
 @pytest.mark.parametrize("name", ["par_small_gain4", "par_small_ragged", "par_small_earlybreak",
