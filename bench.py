@@ -529,8 +529,8 @@ def main():
 
     def apply_knobs(mod):
         mod.ln_fuse_max_rows = args.ln_fuse_max_rows
-        if os.environ.get("FF_BENCH_LN_FIRST"):        # (A/B: rows normalised before the split product instead of in its epilogue)
-            mod.x3_ln_in_epilogue = False
+        if os.environ.get("FF_BENCH_LN_EPILOGUE"):     # (A/B: "1" = the split products normalise in their epilogue, "0" = rows first)
+            mod.x3_ln_in_epilogue = os.environ["FF_BENCH_LN_EPILOGUE"] == "1"
 
     def steps_executed(pred):   # pred [N, F, T] or [N, T]
         p = pred.reshape(-1, pred.size(-1))

@@ -88,8 +88,6 @@ enum FFKnob {
   FF_K_X3_SMALL_SPLIT,            // split kernel: K-pieces on idle CUs below one tile per CU
   FF_K_RK_SPLIT_OLD, FF_K_RK_SPLIT_YOUNG, FF_K_RK_PHASE, FF_K_RK_ROTATE,   // K/V-resident attention probes
   FF_K_X3_NEED_N1024, FF_K_X3_NEED_N512,   // split products: rows needed by the 1024- / 512-column projections, in quarters of x3_min_rows
-  FF_K_KV_TOUCH,                  // experiment: pre-touch the cross-attention K | V of a one-wireframe micro-batch from a side stream
-                                  // (1: beside the cross-q projection, 2: beside the attention launch itself; 0 = off)
   FF_K_COUNT
 };
 int ff_knob(int id);
@@ -110,7 +108,6 @@ int ff_pointer_argmax_sync(const float* p, int ldp, const float* memory, int S, 
                            int ldnext, int* count_ge, int ge_bound, int* count_eq, int eq_value,
                            const ff_pointer_sync* sync, ff_stream_t stream);
 
-int ff_kv_touch(const float* kv, int ld, int S, int H, hipStream_t st);   // (ff_rowops.hip: experiment, knob FF_KV_TOUCH)
 // out[c, r] = in[r, c] for an [rows, cols] fp32 matrix (ff_rowops.hip; the engine's per-call transposes)
 int ff_transpose(const float* in, int ld_in, int rows, int cols, float* out, int ld_out, hipStream_t st);
 

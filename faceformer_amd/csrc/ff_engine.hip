@@ -241,9 +241,6 @@ constexpr int FF_PINNED_SLOTS = 65536;   // host-mapped stop counters allocated 
 struct EngineKnobs {
   bool l0_fold, pointer_fold, dbg_timing;
   int one_launch_rows, pinned;
-  int kv_touch;              // experiment FF_KV_TOUCH (0 off)
-  hipStream_t touch_st;      // ... its side stream and fork event (set by ff_decode; null: off)
-  hipEvent_t touch_ev;
 };
 EngineKnobs engine_knobs(const ff_decode_params* p) {
   EngineKnobs k;
@@ -253,8 +250,6 @@ EngineKnobs engine_knobs(const ff_decode_params* p) {
   k.one_launch_rows = ff_knob(FF_K_LAST_QKV_ONE_LAUNCH_ROWS);
   const int pc = ff_knob(FF_K_PINNED_COUNTERS);
   k.pinned = pc > 0 && pc < FF_PINNED_SLOTS ? pc : FF_PINNED_SLOTS;
-  k.kv_touch = ff_knob(FF_K_KV_TOUCH);
-  k.touch_st = nullptr; k.touch_ev = nullptr;
   return k;
 }
 
@@ -461,16 +456,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKno
       FF_RETURN_IF(gemm_ln(buf.o + roff * E, E, w.self_attn.out_w, E, w.self_attn.out_b, xin + roff * E, E,
                            buf.x + roff * E, E, Rl, E, E, 0, nullptr, nullptr, 0, 0, stat, w.self_out_planes, E, 0));
       // ---- cross attention: q = LN2(x) + qpos (transformer.py:247-252) ----
-      const bool touch = kn.kv_touch && kn.touch_st && ck.nw == 1 && S <= 288 && !last && t >= 8;
-      auto kv_touch = [&]() -> int {   // experiment: this layer's K | V towards the L2s that will read them, from the side stream
-        FF_CHECK_HIP(hipEventRecord(kn.touch_ev, st));
-        FF_CHECK_HIP(hipStreamWaitEvent(kn.touch_st, kn.touch_ev, 0));
-        return ff_kv_touch(bufs.kvc[l] + (size_t)ck.w0 * S * 2 * E, 2 * E, S, H, kn.touch_st);
-      };
-      if (touch && kn.kv_touch == 1) FF_RETURN_IF(kv_touch());
       FF_RETURN_IF(gemm_ln(buf.x + roff * E, E, w.ln2_w, E, w.ln2_b, nullptr, 0, qc + roff * E, E, Rl, E, E, 0, stat,
                            w.ln2_pos + (last ? (size_t)(t - 1) * E : 0), E, E, nullptr, w.ln2_planes, E, 0, w.ln2_csum));
-      if (touch && kn.kv_touch == 2) FF_RETURN_IF(kv_touch());
     } else {
       FF_RETURN_IF(gemm_or_x3(m, prm, w.self_out_planes, buf.o + roff * E, E, nullptr, 0, w.self_attn.out_w, E,
                               w.self_attn.out_b, xin + roff * E, E, buf.x + roff * E, E, Rl, E, E, 0, st));
@@ -554,8 +541,6 @@ struct StreamPool {
   hipStream_t side[FF_MAX_STREAMS];
   hipEvent_t fork_ev, join_ev[FF_MAX_STREAMS];
   hipEvent_t chk_ev[FF_MAX_STREAMS];      // stop-rule check: per-stream progress marks
-  hipStream_t touch_st;                     // experiment FF_KV_TOUCH: side stream + fork / join events
-  hipEvent_t touch_ev, touch_join;
   int* hpin;                                // host-mapped pinned counters [step][micro-batch], written by the pointer launches
   int* hpin_dev;                            // ... the device-visible address of the same memory
   int created;
@@ -585,9 +570,6 @@ int pool_get(int n, StreamPool** out) {
     FF_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&pool.hpin), sizeof(int) * FF_PINNED_SLOTS,
                                hipHostMallocMapped | hipHostMallocCoherent));
     FF_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&pool.hpin_dev), pool.hpin, 0));
-    FF_CHECK_HIP(hipStreamCreateWithFlags(&pool.touch_st, hipStreamNonBlocking));
-    FF_CHECK_HIP(hipEventCreateWithFlags(&pool.touch_ev, hipEventDisableTiming));
-    FF_CHECK_HIP(hipEventCreateWithFlags(&pool.touch_join, hipEventDisableTiming));
     pool.events = true;
   }
   while (pool.created < n) {
@@ -718,7 +700,7 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   Bump bp(workspace, workspace_bytes);
   DecodeBuffers buf;
   const int nch = (int)chunks.size();
-  EngineKnobs kn = engine_knobs(p);
+  const EngineKnobs kn = engine_knobs(p);
   layout_decode(m, p, kn, (size_t)Btot, (size_t)max_bc, (size_t)nch, bp, &buf);
   if (!bp.ok) { ff_set_error("ff_decode: workspace too small (%zu needed, %zu given)", bp.off, workspace_bytes); return FF_ERR_WORKSPACE; }
   for (Chunk& c : chunks) {
@@ -744,7 +726,6 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   FF_RETURN_IF(pool_get(forked ? ns : 0, &pool));   // (also owns the pinned counter buffer / events of the stop check)
   if (forked)
     for (int s = 0; s < ns; ++s) sts[s] = pool->side[s];
-  if (kn.kv_touch && !forked) { kn.touch_st = pool->touch_st; kn.touch_ev = pool->touch_ev; }
   auto sync_all = [&]() -> int {
     for (int s = 0; s < ns; ++s) FF_CHECK_HIP(hipStreamSynchronize(sts[s]));
     return FF_OK;
@@ -894,10 +875,6 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       fprintf(stderr, "[ff_decode] host enqueue of %d steps x %zu chunks (%d of %d sequences decoded): %.2f ms; until GPU idle: "
                       "%.2f ms\n", enq, chunks.size(), Btot, N * F, host_ms, tot_ms);
     }
-    if (kn.touch_st) {   // the touch launches read the caller's workspace: the main stream ends behind them
-      FF_CHECK_HIP(hipEventRecord(pool->touch_join, kn.touch_st));
-      FF_CHECK_HIP(hipStreamWaitEvent(main_st, pool->touch_join, 0));
-    }
     if (forked) {  // join
       for (int s = 0; s < ns; ++s) {
         FF_CHECK_HIP(hipEventRecord(pool->join_ev[s], sts[s]));
@@ -909,7 +886,6 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
   {
     const int rc = run();
     if (rc != FF_OK) {
-      if (kn.touch_st) (void)hipStreamSynchronize(kn.touch_st);
       for (int s = 0; s < ns; ++s) (void)hipStreamSynchronize(sts[s]);
       (void)hipStreamSynchronize(main_st);
       return rc;

@@ -45,7 +45,6 @@ const KnobDef g_knob_defs[FF_K_COUNT] = {
     {"FF_NO_PANEL", 0, true}, {"FF_X3_SMALL_SPLIT", 0, false},
     {"FF_RK_SPLIT_OLD", 1, false}, {"FF_RK_SPLIT_YOUNG", 1, false}, {"FF_RK_PHASE", 0, false}, {"FF_RK_ROTATE", 1, false},
     {"FF_X3_NEED_N1024", 7, false}, {"FF_X3_NEED_N512", 11, false},
-    {"FF_KV_TOUCH", 0, false},
 };
 std::atomic<int> g_knobs[FF_K_COUNT];
 std::once_flag g_knobs_once;
@@ -347,26 +346,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   __syncthreads();
   for (int i = ty; i < 32; i += 8)
     if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * ld_out + r0 + tx] = tile[tx][i];
-}
-
-// ---- experiment (knob FF_KV_TOUCH): pull the K | V head slices of ONE wireframe's cross-attention cache into the L2 of the XCD whose
-// attention blocks will read them (workgroup b of a launch lands on XCD b % 8; the K/V-resident kernel puts head h on XCD h when a
-// micro-batch holds one wireframe).  Lines of 128 bytes: 2 of K and 2 of V per key row and head; loaded and dropped.
-__global__ __launch_bounds__(256) void kv_touch_kernel(const float* __restrict__ kv, int ld, int S, int H) {
-  const int h = blockIdx.x % H, part = blockIdx.x / H, parts = gridDim.x / H;
-  const int lines = S * 4;
-  for (int i = part * 256 + threadIdx.x; i < lines; i += parts * 256) {
-    const int row = i >> 2, which = i & 3;
-    const float* p = kv + (size_t)row * ld + (which >> 1) * (H * FF_HEAD_DIM) + h * FF_HEAD_DIM + (which & 1) * 32;
-    float v;
-    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  }
-}
-int ff_kv_touch(const float* kv, int ld, int S, int H, hipStream_t st) {
-  FF_CHECK_ARG(kv && S > 0 && H > 0 && ld >= 2 * H * FF_HEAD_DIM, "ff_kv_touch: bad arguments");
-  hipLaunchKernelGGL(kv_touch_kernel, dim3(H * 4), dim3(256), 0, st, kv, ld, S, H);
-  FF_CHECK_LAUNCH();
-  return FF_OK;
 }
 
 int ff_transpose(const float* in, int ld_in, int rows, int cols, float* out, int ld_out, hipStream_t st) {

@@ -67,7 +67,10 @@ class SurfaceFormerBase(nn.Module):
         # ... their LayerNorm applied in the consumer's EPILOGUE (rstd (x W'^T - mean colsum(W'))): the K loop then is the plain
         # split product.  Error factor (1 + |mean| / sigma) of the row -- 0.06 median, 0.15 maximum on this model's LayerNorm
         # inputs; False = rows normalised before the product (ff_gemm_x3.hip: x3_ln_linear).  Read when the engine is bound.
-        self.x3_ln_in_epilogue = True
+        # None = by split kind: True for the bf16 terms (+5-13 % there), False for the fp16 terms (config B 44.3-44.8 vs 44.9 ms, C128 313 k vs
+        # 309 k edges/s with the rows normalised first: profiles/r06/fp16x2_ln_form_ab.txt -- and normalised rows are bounded by sqrt(E),
+        # so nothing un-normalised ever meets fp16's range).
+        self.x3_ln_in_epilogue = None
         # how those projections split an fp32 operand: "bf16x3" (three bf16 terms, six products) or "fp16x2" (two fp16 terms, three
         # products: half the matrix-core work; the engine checks at bind time that the model's operand bounds fit fp16's range)
         self.split_kind = SPLIT_KIND_DEFAULT
@@ -186,12 +189,16 @@ class SurfaceFormerBase(nn.Module):
             inputs["predict"] = predict
         return inputs
 
+    def _ln_in_epilogue(self):
+        v = getattr(self, "x3_ln_in_epilogue", None)
+        return (getattr(self, "split_kind", SPLIT_KIND_DEFAULT) == "bf16x3") if v is None else bool(v)
+
     def engine(self):
         """PathEngine bound to this module's parameters (rebuilt when they moved, e.g. after .to())."""
         self._check_supported()
         eng = self._engine_obj
         if eng is None or not eng.pointers_current() or eng.has_planes != (self.x3_min_rows > 0) or \
-                eng.ln_in_epilogue != bool(getattr(self, "x3_ln_in_epilogue", True)) or \
+                eng.ln_in_epilogue != self._ln_in_epilogue() or \
                 eng.split_kind != getattr(self, "split_kind", SPLIT_KIND_DEFAULT):
             tensors = {k: v for k, v in self.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             dev = tensors["project.weight"].device
@@ -202,7 +209,7 @@ class SurfaceFormerBase(nn.Module):
                     ".cuda()." % dev)
             eng = PathEngine(tensors, self.num_head, self.num_token, self.encoder.norm.eps,
                              bf16_split_planes=self.x3_min_rows > 0, fold_layernorm=True,
-                             ln_in_epilogue=getattr(self, "x3_ln_in_epilogue", True),
+                             ln_in_epilogue=self._ln_in_epilogue(),
                              split_kind=getattr(self, "split_kind", SPLIT_KIND_DEFAULT))
             self._engine_obj = eng
         return eng

@@ -227,6 +227,8 @@ def test_golden_parity_with_bf16_split_projections(hip_lib, name, min_rows, kind
     model = build_model(case, sd, "cuda")
     model.x3_min_rows = min_rows
     model.split_kind = kind
+    assert model.x3_ln_in_epilogue is None and model._ln_in_epilogue() == (kind == "bf16x3")   # the default form goes by the kind
+    model.x3_ln_in_epilogue = True      # first pass: LayerNorm in the epilogue of the split product
     out = run_traced(model, case, batch_to(batch, "cuda"))
     assert model.engine().split_kind == kind
     stats = compare_with_golden(case, z, out)

@@ -10,7 +10,7 @@ echo "# config B, split products (fp16x2) from x3_min_rows rows on; ms per wiref
 for r in 1024 512 768 1024 1280; do echo "x3_min_rows $r : $(runx --x3-min-rows $r)"; done
 for n in "7 11" "6 9" "5 8" "5 7" "4 6" "6 11" "7 9"; do set -- $n; echo "min_rows 1024, need N1024 $1/4 N512 $2/4 : $(FF_X3_NEED_N1024=$1 FF_X3_NEED_N512=$2 runx --x3-min-rows 1024)"; done
 for n in "6 9" "5 8" "4 6"; do set -- $n; echo "min_rows 768,  need N1024 $1/4 N512 $2/4 : $(FF_X3_NEED_N1024=$1 FF_X3_NEED_N512=$2 runx --x3-min-rows 768)"; done
-echo "LayerNorm first (MODE 1), min_rows 1024 : $(FF_BENCH_LN_FIRST=1 runx --x3-min-rows 1024)  / in the epilogue: $(runx --x3-min-rows 1024)"
+echo "LayerNorm first (MODE 1), min_rows 1024 : $(FF_BENCH_LN_EPILOGUE=0 runx --x3-min-rows 1024)  / in the epilogue: $(runx --x3-min-rows 1024)"
 echo "bf16x3 for reference, min_rows 1024 : $(runx --x3-min-rows 1024 --split-kind bf16x3)"
 } > $O/fp16x2_thresholds.txt 2>&1
 cat $O/fp16x2_thresholds.txt
