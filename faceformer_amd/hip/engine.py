@@ -85,23 +85,6 @@ class PathEngine:
         m.enc_norm_w, m.enc_norm_b = get("encoder.norm.weight"), get("encoder.norm.bias")
         for i in range(n_dec):
             layer(m.dec[i], "decoder.layers.%d" % i, True)
-            if bf16_split_planes:
-                # three exact bf16 planes per weight (+1.5x their bytes), split once here: lets ff_decode run
-                # q|k|v, linear1 and linear2 of the large steps on the bf16 matrix cores (x3_min_rows);
-                # re-bind after in-place weight updates
-                E_ = E
-                for field, name in (("in_proj_planes", "self_attn.in_proj_weight"), ("lin1_planes", "linear1.weight"),
-                                    ("lin2_planes", "linear2.weight"), ("self_out_planes", "self_attn.out_proj.weight"),
-                                    ("cross_q_planes", "multihead_attn.in_proj_weight"),
-                                    ("cross_out_planes", "multihead_attn.out_proj.weight")):
-                    wt = tensors["decoder.layers.%d.%s" % (i, name)]
-                    if field == "cross_q_planes":
-                        wt = wt[:E_]  # q rows only: k|v of the cross attention are projected once per batch
-                    if wt.shape[1] % 32 or wt.shape[1] < 64:
-                        continue      # the bf16-split kernel needs K % 32 == 0: this weight stays f32-only (null planes)
-                    pl = split_weight(wt, split_kind)
-                    self._planes[(i, field)] = pl
-                    setattr(m.dec[i], field, pl.data_ptr())
         m.dec_norm_w, m.dec_norm_b = get("decoder.norm.weight"), get("decoder.norm.bias")
         m.proj_w, m.proj_b = get("project.weight"), get("project.bias")
         if fold_layernorm and E % 64 == 0 and E >= 128 and m.FF % 64 == 0 and m.FF >= 128:
@@ -122,25 +105,25 @@ class PathEngine:
                     lw.ln3_w, lw.ln3_b, _ = self._fold(
                         (i, 3), tensors[p + "linear1.weight"], tensors[p + "linear1.bias"],
                         tensors[p + "norm3.weight"], tensors[p + "norm3.bias"], None, 0)
-                    if bf16_split_planes and E % 32 == 0:
-                        # planes of the FOLDED weights: the steps that take the 3 x bf16 projections keep the LayerNorm
-                        # folding (ff_gemm_x3_ln) instead of launching their LayerNorms
-                        for field, cfield, key in (("ln1_planes", "ln1_csum", (i, 1)), ("ln2_planes", "ln2_csum", (i, 2)),
-                                                   ("ln3_planes", "ln3_csum", (i, 3))):
-                            pl = split_weight(self._folded[key][0], split_kind)
-                            self._planes[(i, field)] = pl
-                            setattr(lw, field, pl.data_ptr())
-                            if ln_in_epilogue:
-                                # row sums of the folded weight (fp64 sum, rounded once): LN(x) W'^T = rstd (x W'^T - mean s)
-                                cs = self._folded[key][0].double().sum(dim=1).float().contiguous()
-                                self._planes[(i, cfield)] = cs
-                                setattr(lw, cfield, cs.data_ptr())
                 m.proj_fold_w, m.proj_fold_b, _ = self._fold(
                     ("proj",), tensors["project.weight"], tensors["project.bias"],
                     tensors["decoder.norm.weight"], tensors["decoder.norm.bias"], None, 0)
-        m.split_kind = SPLIT_KINDS[split_kind] if self._planes else 0
-        if self._planes and split_kind == "fp16x2":
-            self._check_fp16_range(tensors, n_dec, E)
+        # Split planes (x3_min_rows > 0): of the raw weights (steps that launch their LayerNorms) and of the LayerNorm-folded ones.
+        # A model whose operand bounds leave fp16's range gets the bf16 terms instead of the fp16 ones (with a warning): the
+        # range of bf16 is fp32's.  `requested_kind` is what the caller asked for, `split_kind` what was bound.
+        self.requested_kind = split_kind
+        if bf16_split_planes:
+            self._make_planes(m, tensors, n_dec, E, split_kind, ln_in_epilogue)
+            if split_kind == "fp16x2":
+                bad = self._check_fp16_range(tensors, n_dec, E)
+                if bad:
+                    import warnings
+                    warnings.warn("faceformer_amd: split_kind='fp16x2' needs every operand of the split products inside fp16's range; "
+                                  "this model's bounds are not (%s) -- binding the bf16x3 planes instead" % bad)
+                    self.split_kind = "bf16x3"
+                    self._planes = {}
+                    self._make_planes(m, tensors, n_dec, E, "bf16x3", ln_in_epilogue)
+        m.split_kind = SPLIT_KINDS[self.split_kind] if self._planes else 0
         self.model = m
         self.E, self.H, self.num_token = E, num_head, num_token
         self.device = tensors["project.weight"].device
@@ -154,13 +137,47 @@ class PathEngine:
         with torch.cuda.device(self.device):
             _L.check(self._lib.ff_gemm_prepare_stream(_stream()), "ff_gemm_prepare_stream")
 
+    def _make_planes(self, m, tensors, n_dec, E, kind, ln_in_epilogue):
+        """Split planes of the decoder projections: three exact bf16 planes per weight (+1.5x their bytes) or two fp16 planes
+        (+1x), split once here -- ff_decode then runs the large steps' projections on the 16-bit matrix cores (x3_min_rows);
+        re-bound after in-place weight updates (pointers_current)."""
+        for i in range(n_dec):
+            for field, name in (("in_proj_planes", "self_attn.in_proj_weight"), ("lin1_planes", "linear1.weight"),
+                                ("lin2_planes", "linear2.weight"), ("self_out_planes", "self_attn.out_proj.weight"),
+                                ("cross_q_planes", "multihead_attn.in_proj_weight"),
+                                ("cross_out_planes", "multihead_attn.out_proj.weight")):
+                wt = tensors["decoder.layers.%d.%s" % (i, name)]
+                if field == "cross_q_planes":
+                    wt = wt[:E]       # q rows only: k|v of the cross attention are projected once per batch
+                if wt.shape[1] % 32 or wt.shape[1] < 64:
+                    setattr(m.dec[i], field, None)
+                    continue          # the split kernel needs K % 32 == 0: this weight stays f32-only (null planes)
+                pl = split_weight(wt, kind)
+                self._planes[(i, field)] = pl
+                setattr(m.dec[i], field, pl.data_ptr())
+            if E % 32 == 0:
+                # planes of the FOLDED weights: the steps that take the split projections keep the LayerNorm folding
+                # (ff_gemm_x3_ln / ff_gemm_x2h_ln) instead of launching their LayerNorms
+                for field, cfield, key in (("ln1_planes", "ln1_csum", (i, 1)), ("ln2_planes", "ln2_csum", (i, 2)),
+                                           ("ln3_planes", "ln3_csum", (i, 3))):
+                    if key not in self._folded:
+                        continue
+                    pl = split_weight(self._folded[key][0], kind)
+                    self._planes[(i, field)] = pl
+                    setattr(m.dec[i], field, pl.data_ptr())
+                    if ln_in_epilogue:
+                        # row sums of the folded weight (fp64 sum, rounded once): LN(x) W'^T = rstd (x W'^T - mean s)
+                        cs = self._folded[key][0].double().sum(dim=1).float().contiguous()
+                        self._planes[(i, cfield)] = cs
+                        setattr(m.dec[i], cfield, cs.data_ptr())
+
     def _check_fp16_range(self, tensors, n_dec, E):
         """fp16 has five exponent bits: every operand of a "2 x fp16" product must stay below 65504 in magnitude.  Weights are
         checked directly.  The activations are bounded a priori: LayerNorm-normalised rows by sqrt(E); the raw rows of the
         epilogue form are fed at 2^-6 (< 4.2e6); the attention outputs by max |v| <= sqrt(E) ||Wv_n||_2 + |b_n| (a row of a
         softmax-weighted mean of value rows; v = LN(.) Wv'^T + b or memory Wv^T + b, memory being LayerNorm output as well),
         the feed-forward hidden rows by sqrt(E) ||W1'_n||_2 + |b1_n| (Cauchy-Schwarz, gamma / beta folded in).  A model
-        whose bounds do not fit is refused here -- loudly -- instead of overflowing inside a kernel."""
+        whose bounds do not fit gets the bf16 terms instead (the caller warns).  Returns "" or the offending bounds."""
         lim = 6.0e4
         root = float(E) ** 0.5
 
@@ -182,12 +199,9 @@ class PathEngine:
             for nm in ("norm1", "norm2", "norm3"):     # un-folded steps: y = gamma * n + beta goes through the planes of the raw weight
                 g_, b_ = tensors[p + nm + ".weight"], tensors[p + nm + ".bias"]
                 worst["LayerNorm outputs"] = max(worst.get("LayerNorm outputs", 0.0), float(g_.abs().max()) * root + float(b_.abs().max()))
-        bad = {k: v for k, v in worst.items() if not v < lim}
-        if bad:
-            raise _L.HipExtensionError(
-                "split_kind='fp16x2': operand bounds outside fp16's range (%s); bind the model with split_kind='bf16x3'"
-                % ", ".join("%s <= %.3g" % kv for kv in sorted(bad.items())))
         self.fp16_operand_bounds = worst
+        bad = {k: v for k, v in worst.items() if not v < lim}
+        return ", ".join("%s <= %.3g" % kv for kv in sorted(bad.items()))
 
     def _fold(self, key, W, bias, gamma, beta, pos, pos_cols):
         """(Wf, bf, P) device pointers of ff_fold_layernorm_linear for one LayerNorm -> Linear pair."""

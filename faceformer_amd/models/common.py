@@ -199,7 +199,7 @@ class SurfaceFormerBase(nn.Module):
         eng = self._engine_obj
         if eng is None or not eng.pointers_current() or eng.has_planes != (self.x3_min_rows > 0) or \
                 eng.ln_in_epilogue != self._ln_in_epilogue() or \
-                eng.split_kind != getattr(self, "split_kind", SPLIT_KIND_DEFAULT):
+                eng.requested_kind != getattr(self, "split_kind", SPLIT_KIND_DEFAULT):
             tensors = {k: v for k, v in self.state_dict(keep_vars=True).items() if v.dtype == torch.float32}
             dev = tensors["project.weight"].device
             if dev.type != "cuda":

@@ -626,6 +626,42 @@ def test_launch_forms_flipped_in_process_through_the_tuning_table(hip_lib, name)
         ops.set_tuning("FF_NO_SUCH_KNOB", 1)
 
 
+def test_model_outside_fp16_range_falls_back_to_the_bf16_terms(hip_lib):
+    """Round 6: the package default splits an fp32 operand into two fp16 terms, and fp16 has five exponent bits.  When the planes
+    are bound the engine bounds every operand of those products (LayerNorm rows by sqrt(E), attention outputs and feed-forward
+    hidden rows by sqrt(E) ||W'_n||_2 + |b_n|, the weights themselves); a model whose bounds do not fit -- here: linear1 of one
+    layer scaled by 3e4 -- is bound with the bf16 terms instead, with a warning, and decodes exactly like a model that asked for
+    them.  The goldens' own weights are inside the range (no warning: the other tests run with warnings as they come)."""
+    import warnings
+    case, z = load_golden("par_small_gain4")
+    sd, batch = case_weights_and_batch(case)
+    sd = dict(sd)
+    sd["decoder.layers.0.linear1.weight"] = sd["decoder.layers.0.linear1.weight"] * 3.0e4
+    preds = {}
+    for kind in ("fp16x2", "bf16x3"):
+        model = build_model(case, sd, "cuda")
+        model.x3_min_rows, model.split_kind = 1, kind
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                preds[kind] = model(batch_to(batch, "cuda"))["predict"].cpu().numpy()
+        eng = model.engine()
+        assert eng.split_kind == "bf16x3" and eng.requested_kind == kind
+        assert (len([x for x in w if "fp16" in str(x.message)]) == 1) == (kind == "fp16x2")
+        with torch.no_grad():                     # the fallback is bound once, not on every call
+            model(batch_to(batch, "cuda"))
+        assert model.engine() is eng
+    assert np.array_equal(preds["fp16x2"], preds["bf16x3"])
+    ok = build_model(case, case_weights_and_batch(case)[0], "cuda")
+    ok.x3_min_rows, ok.split_kind = 1, "fp16x2"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            ok(batch_to(batch, "cuda"))
+    assert ok.engine().split_kind == "fp16x2" and not [x for x in w if "fp16" in str(x.message)]
+    assert max(ok.engine().fp16_operand_bounds.values()) < 6.0e4
+
+
 def test_json_gather_over_rccl(hip_lib, tmp_path):
     """The north-star's 'RCCL all-gather of predicted face-loop JSON': decode_to_face_json on the nccl backend
     (world size 1 on this box; the gloo tests cover world sizes 2 and 3) incl. the co-edge post-processing
