@@ -161,6 +161,46 @@ def gemm_roofline(prof, wall_ms, empty_us, traffic=None, traffic_src=None):
     return roof, extra
 
 
+def live_traffic(timeout_s=150):
+    """HBM bytes per launch of the f32 GEMM family, MEASURED IN THIS RUN: two child passes of the same workload under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, no trace domains mixed in -- MI355X_MICROARCH.md's recipe),
+    summed over the family's dispatches: (2 x FETCH_SIZE + WRITE_SIZE) KB / dispatches (FETCH_SIZE under-reports wide coalesced
+    reads by 2x on gfx950).  Returns (bytes per launch, source text) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "1",
+                   "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-x3-line", "--no-other-configs", "--no-live-traffic"]
+            try:
+                cp = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp",
+                                    env=dict(os.environ, TMPDIR="/tmp"))
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s: no result within %d s" % (counter, timeout_s)
+            dbs = [os.path.join(r, f) for r, _d, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if cp.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, cp.returncode)
+            try:
+                rows = sqlite3.connect(dbs[0]).execute(
+                    "select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+            except sqlite3.Error as e:
+                return None, "rocpd database of the %s pass: %s" % (counter, e)
+            vals = [float(v) for k, v in rows if "gemm_" in k and "x3" not in k]
+            if not vals:
+                return None, "no GEMM dispatches in the %s pass" % counter
+            sums[counter] = (sum(vals), len(vals))
+    f = sums["FETCH_SIZE"][0] / sums["FETCH_SIZE"][1]
+    w = sums["WRITE_SIZE"][0] / sums["WRITE_SIZE"][1]
+    return (2.0 * f + w) * 1024.0, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate child passes of the "
+                                    "same workload, %d GEMM dispatches, (2 x FETCH_SIZE + WRITE_SIZE) KB per dispatch" % sums["FETCH_SIZE"][1])
+
+
 def _committed_traffic(fname):
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", fname)))
@@ -246,6 +286,8 @@ def compact_line(result):
     if result.get("roofline"):
         r = _pick(result["roofline"], ROOF_KEYS)
         r["kernel"] = _cut(r.get("kernel"), 80)
+        src = result["roofline"].get("traffic_source") or ""
+        r["traffic_measured"] = "this run (rocprofv3 --pmc, 2 child passes)" if src.startswith("measured in this run") else _cut(src, 90)
         out["roofline"] = r
     if "kernel_time_ms_per_step" in result:
         out["kernel_time_ms_per_step"] = result["kernel_time_ms_per_step"]
@@ -266,17 +308,18 @@ def compact_line(result):
         if rf.get("frac") is not None:
             b["kernel_frac"] = rf["frac"]
         return b
-    x3 = result.get("bf16x3_projections")
+    x3 = result.get("package_default")
     if x3:
-        out["bf16x3_projections"] = brief(x3)
+        out["package_default"] = brief(x3)
+        out["package_default"]["split_kind"] = x3.get("split_kind")
         if (x3.get("roofline") or {}).get("effective_clock_ghz") is not None:
-            out["bf16x3_projections"]["effective_clock_ghz"] = x3["roofline"]["effective_clock_ghz"]
+            out["package_default"]["effective_clock_ghz"] = x3["roofline"]["effective_clock_ghz"]
     if result.get("other_configs"):
         oc = {}
         for name, e in result["other_configs"].items():
             oc[name] = brief(e)
-            if e.get("bf16x3_projections"):
-                oc[name]["bf16x3"] = _pick(e["bf16x3_projections"], ("value", "ms_per_step"))
+            if e.get("package_default"):
+                oc[name]["default"] = _pick(e["package_default"], ("value", "ms_per_step"))
         out["other_configs"] = oc
     for k in ("rehearsal", "rccl_ranks", "collective_backend", "rccl_version", "wireframes_per_s", "bench_seconds"):
         if k in result:
@@ -290,7 +333,7 @@ def compact_line(result):
     out = _sig(out)
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= LINE_LIMIT:    # never let the driver's record go unparsed again: shed the optional blocks
-        for k in ("other_configs", "kernel_time_ms_per_step", "bf16x3_projections", "path_roofline"):
+        for k in ("other_configs", "kernel_time_ms_per_step", "package_default", "path_roofline"):
             out.pop(k, None)
             line = json.dumps(out, separators=(",", ":"))
             if len(line) < LINE_LIMIT:
@@ -412,7 +455,7 @@ def main():
     ap.add_argument("--x3-min-rows", type=int, default=0,
                     help="3 x bf16 projections (fp32-accurate, bf16 matrix cores) on launches with at least this many rows. "
                          "The HEADLINE is measured with 0 (every product on the f32 matrix cores, dtype f32); the package "
-                         "default is measured as well and reported under 'bf16x3_projections'")
+                         "default is measured as well and reported under 'package_default'")
     ap.add_argument("--split-kind", default="", choices=["", "bf16x3", "fp16x2"],
                     help="how the split projections of the package-default line split an fp32 operand (default: the package's)")
     ap.add_argument("--no-fuse-ln", action="store_true", help="standalone LayerNorm launches (A/B of FF_FUSE_LAYERNORM)")
@@ -425,6 +468,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-x3-line", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC passes instead of two rocprofv3 --pmc child passes of this run")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C128 / E32 / D / A lines of the N = 1 run")
     ap.add_argument("--other-steps", type=int, default=1, help="timed passes of each `other_configs` entry")
     ap.add_argument("--other-list", default="C128,E32,D,A64",
@@ -718,7 +763,7 @@ def main():
                 with torch.no_grad():
                     model(dict(batch))
             roof3 = x3_roofline(profile_once(lib, L, once3), 1e3 * dt3 / args.steps,
-                                with_traffic=(not cfgE and args.edges == 256 and W == 1 and getattr(model, "split_kind", "") == "bf16x3"),
+                                with_traffic=(not cfgE and args.edges == 256 and W == 1),
                                 kind=getattr(model, "split_kind", "bf16x3"))
             ghz3 = effective_clock(once3, dt3 / args.steps)
             roof3["effective_clock_ghz"] = ghz3
@@ -726,7 +771,7 @@ def main():
         model.x3_min_rows = 0
         step()      # (re-binds the engine without the bf16 planes for the profiling leg below)
         fence()
-        result["bf16x3_projections"] = {
+        result["package_default"] = {
             "value": sel_per_step * args.steps / dt3, "unit": "edges/s", "ms_per_step": 1e3 * dt3 / args.steps,
             "x3_min_rows": X3_MIN_ROWS_DEFAULT, "split_kind": getattr(model, "split_kind", "bf16x3"),
             "note": "package default: decoder projections of launches with >= %d rows (q|k|v; linear1 from 7/4 x, the 512-column "
@@ -735,7 +780,7 @@ def main():
                     % X3_MIN_ROWS_DEFAULT,
             "path_roofline": path_roofline(falg, dt3 / args.steps)}
         if roof3 is not None:
-            result["bf16x3_projections"]["roofline"] = roof3
+            result["package_default"]["roofline"] = roof3
 
     if rank == 0 and not args.no_roofline:
         def once():
@@ -748,10 +793,16 @@ def main():
         traffic, traffic_src = None, None
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
-        if cands and not cfgE and args.edges == 256 and W == 1:
-            with open(cands[-1]) as f:
-                tj = json.load(f)
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+        if not cfgE and args.edges == 256 and W == 1:
+            why = "--no-live-traffic"
+            if not args.no_live_traffic and not multi:
+                traffic, traffic_src = live_traffic()
+                why = traffic_src if traffic is None else None
+            if traffic is None and cands:      # the committed PMC passes of the same command (labelled as such)
+                with open(cands[-1]) as f:
+                    tj = json.load(f)
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_src = "%s (committed passes; live measurement: %s)" % (os.path.relpath(cands[-1], ROOT), why)
         result["roofline"], extra = gemm_roofline(prof, 1e3 * dt / args.steps, bracket_us, traffic, traffic_src)
         result.update(extra)
         ghz = effective_clock(once, dt / args.steps)
@@ -895,7 +946,7 @@ def main():
                 d3, _ = timed(st, fence, 1, K2)
                 r3 = x3_roofline(profile_once(lib, L, st), 1e3 * d3 / K2, kind=getattr(m2, "split_kind", "bf16x3")) if profiled(name) else None
                 m2.x3_min_rows = 0
-                ent["bf16x3_projections"] = {"value": sum(n2) * sd2 * K2 / d3, "unit": "edges/s", "ms_per_step": 1e3 * d3 / K2,
+                ent["package_default"] = {"value": sum(n2) * sd2 * K2 / d3, "unit": "edges/s", "ms_per_step": 1e3 * d3 / K2,
                                              "ms_per_wireframe": 1e3 * d3 / K2 / len(n2), "roofline": r3,
                                              "path_roofline": path_roofline(sum(alg_flops_per_wireframe(n, T2) for n in n2), d3 / K2),
                                              "note": "package default (x3_min_rows = %d), fp32-accurate; not the headline form" % X3_MIN_ROWS_DEFAULT}

@@ -182,7 +182,7 @@ class PathEngine:
         root = float(E) ** 0.5
 
         def bound(W, b):
-            return float((W.double().norm(dim=1) * root + b.double().abs()).max())
+            return float((W.detach().double().norm(dim=1) * root + b.detach().double().abs()).max())
         worst = {"weights": max(float(t.float().abs().max()) for (_i, f), t in self._planes.items() if t.dim() == 4)}
         for i in range(n_dec):
             p = "decoder.layers.%d." % i
@@ -195,10 +195,12 @@ class PathEngine:
             # memory = gamma * n + beta with ||n||_2 <= sqrt(E) (the encoder's final LayerNorm): v_n = n . (W_n * gamma) + W_n . beta + b_n
             Wc, bc = tensors[p + "multihead_attn.in_proj_weight"][2 * E:], tensors[p + "multihead_attn.in_proj_bias"][2 * E:]
             ge, be = tensors["encoder.norm.weight"], tensors["encoder.norm.bias"]
-            worst["cross-attention values"] = max(worst.get("cross-attention values", 0.0), bound(Wc * ge, Wc @ be + bc))
+            with torch.no_grad():
+                worst["cross-attention values"] = max(worst.get("cross-attention values", 0.0), bound(Wc * ge, Wc @ be + bc))
             for nm in ("norm1", "norm2", "norm3"):     # un-folded steps: y = gamma * n + beta goes through the planes of the raw weight
                 g_, b_ = tensors[p + nm + ".weight"], tensors[p + nm + ".bias"]
-                worst["LayerNorm outputs"] = max(worst.get("LayerNorm outputs", 0.0), float(g_.abs().max()) * root + float(b_.abs().max()))
+                worst["LayerNorm outputs"] = max(worst.get("LayerNorm outputs", 0.0),
+                                                 float(g_.detach().abs().max()) * root + float(b_.detach().abs().max()))
         self.fp16_operand_bounds = worst
         bad = {k: v for k, v in worst.items() if not v < lim}
         return ", ".join("%s <= %.3g" % kv for kv in sorted(bad.items()))

@@ -69,7 +69,7 @@ def test_compact_line_of_the_round_4_record_is_parsable_and_small():
     assert abs(d["roofline"]["traffic"] / full["roofline"]["traffic"] - 1) < 1e-5
     assert abs(d["cpu_baseline"]["value"] - full["cpu_baseline"]["value"]) < 1e-2 and len(d["cpu_baseline"]["sample"]) <= 160
     assert set(d["other_configs"]) == set(full["other_configs"])
-    assert all(set(v) <= {"value", "ms_per_step", "frac", "kernel_frac", "bf16x3"} for v in d["other_configs"].values())
+    assert all(set(v) <= {"value", "ms_per_step", "frac", "kernel_frac", "bf16x3", "default"} for v in d["other_configs"].values())
     assert "workload" in d["config"] and "model" not in d["config"]
 
 

@@ -9,7 +9,7 @@ EXTRA="$*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-x3-line --no-other-configs $EXTRA"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-x3-line --no-other-configs --no-live-traffic $EXTRA"
 echo "command: $CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats -d /tmp/prof_trace -o t -- $CMD > $OUT/trace.log 2>&1
 python tools/rocpd_stats.py /tmp/prof_trace/t_results.db $OUT/kernel_stats.md > /dev/null

@@ -146,7 +146,7 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|")
     for fill in ("random", "zeros"):
         for M, K, N in ((16384, 512, 1536), (9216, 1024, 512)):   # (launches of >= 60 us: the Python loop stays ahead of the GPU;
-            # the config-B-sized launches are probed in situ by bench.py: bf16x3_projections.roofline.effective_clock_ghz)
+            # the config-B-sized launches are probed in situ by bench.py: package_default.roofline.effective_clock_ghz)
             a = torch.randn(M, K, device=dev)
             w = torch.randn(N, K, device=dev) * 0.05
             b = torch.randn(N, device=dev)

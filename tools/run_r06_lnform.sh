@@ -5,8 +5,8 @@ O=gpurun_out/r06e; mkdir -p $O
 show() { python - "$1" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-x=d.get("bf16x3_projections",{})
-print("  B split %.2f ms %.0f edges/s" % (x.get("ms_per_step",-1), x.get("value",-1)), {k:(v.get("bf16x3") or {}).get("value") for k,v in (d.get("other_configs") or {}).items()})
+x=d.get("package_default", d.get("bf16x3_projections", {}))
+print("  B split %.2f ms %.0f edges/s" % (x.get("ms_per_step",-1), x.get("value",-1)), {k:(v.get("default") or v.get("bf16x3") or {}).get("value") for k,v in (d.get("other_configs") or {}).items()})
 PY
 }
 {

@@ -13,7 +13,7 @@ for kind in bf16x3 fp16x2 bf16x3 fp16x2; do
   python - $O/bench_$kind.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-x=d.get("bf16x3_projections",{})
+x=d.get("package_default", d.get("bf16x3_projections", {}))
 print("B f32 %.2f ms | B split %.2f ms %.0f edges/s" % (d["ms_per_step"], x.get("ms_per_step",-1), x.get("value",-1)))
 for k,v in (d.get("other_configs") or {}).items():
     print(k, v)
