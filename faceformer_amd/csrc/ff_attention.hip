@@ -743,6 +743,11 @@ extern "C" int ff_attention(const ff_attn_desc* desc, ff_stream_t stream) {
   // (the pair's K/V load is a fixed cost of every block: it pays from ~2 query tiles per CU on -- measured: config B
   //  from t = 8, never for the single-sequence decode, whose 8 pairs have at most 9 query tiles each)
   const bool resident_ok = d.nk <= RK_KEYS && d.nk > 0 && !d.causal;   // (cross-attention and encoder: no causal mask in that kernel)
+  // 2 x fp16 kernel (round 6): the caller split K | V into fp16 planes (ff_attention_split_kv) -- same launches as the K/V-resident
+  // kernel, an item at 24 half-length MFMAs instead of 65
+  if (d.kv_planes && ff_attention_x2h_ok(d) &&
+      (g_attention_algo == 4 || (g_attention_algo == 0 && ff_knob(FF_K_X2H_ATTN) && qt32 >= 4 && gh * qt32 >= 512)))
+    return ff_attention_x2h_launch(d, d.kv_planes, (long long)ff_attention_planes_stride(), st);
   if (g_attention_algo == 3 ? resident_ok : (g_attention_algo == 0 && resident_ok && qt32 >= 4 && gh * qt32 >= 512)) {
     static std::atomic<bool> attr_done[16] = {};   // idempotent per-device attribute; host threads may race here
     int dev = 0;

@@ -88,9 +88,15 @@ enum FFKnob {
   FF_K_X3_SMALL_SPLIT,            // split kernel: K-pieces on idle CUs below one tile per CU
   FF_K_RK_SPLIT_OLD, FF_K_RK_SPLIT_YOUNG, FF_K_RK_PHASE, FF_K_RK_ROTATE,   // K/V-resident attention probes
   FF_K_X3_NEED_N1024, FF_K_X3_NEED_N512,   // split products: rows needed by the 1024- / 512-column projections, in quarters of x3_min_rows
+  FF_K_X2H_ATTN,                  // 1: cross-attention launches whose descriptor carries fp16 planes take the 2 x fp16 kernel
   FF_K_COUNT
 };
 int ff_knob(int id);
+
+// 2 x fp16 cross-attention (ff_attention_x2h.hip)
+size_t ff_attention_planes_stride();
+bool ff_attention_x2h_ok(const ff_attn_desc& d);
+int ff_attention_x2h_launch(const ff_attn_desc& d, const void* planes, long long plane_stride, hipStream_t st);
 
 // ff_pointer_argmax with the decode engine's stop-rule hand-over (ff_pointer.hip)
 struct ff_pointer_sync {

@@ -151,6 +151,7 @@ struct Scratch {
 
 struct DecodeBuffers {
   float *mem_pos, *kvc[FF_MAX_LAYERS];
+  unsigned char* kvp[FF_MAX_LAYERS];   // fp16 planes of the cross-attention K | V (2 x fp16 attention kernel) or null
   float *x0_all, *qkv0_all;
   float* x0stat_all;   // [Btot, E/32, 2] LayerNorm segment statistics of the NEWEST x0 rows (written by the pointer launches)
   float *projT, *pg_all, *pc_all;   // folded project + pointer GEMM of one-wireframe micro-batches (see pointer_fold): the transposed
@@ -240,6 +241,7 @@ int plan_streams(const ff_decode_params* p) {
 constexpr int FF_PINNED_SLOTS = 65536;   // host-mapped stop counters allocated per device (knob FF_PINNED_COUNTERS: how many a decode may use)
 struct EngineKnobs {
   bool l0_fold, pointer_fold, dbg_timing;
+  bool x2h_attn;             // cross-attention K | V also as fp16 planes (FF_X2H_ATTN, with the fp16 split products in use)
   int one_launch_rows, pinned;
 };
 EngineKnobs engine_knobs(const ff_decode_params* p) {
@@ -247,6 +249,7 @@ EngineKnobs engine_knobs(const ff_decode_params* p) {
   k.l0_fold = ff_knob(FF_K_L0_FOLD) != 0 && !(p->flags & FF_NO_L0_FOLD);
   k.pointer_fold = ff_knob(FF_K_POINTER_FOLD) != 0 && !(p->flags & FF_NO_POINTER_FOLD);
   k.dbg_timing = ff_knob(FF_K_DEBUG_TIMING) != 0;
+  k.x2h_attn = ff_knob(FF_K_X2H_ATTN) != 0;
   k.one_launch_rows = ff_knob(FF_K_LAST_QKV_ONE_LAUNCH_ROWS);
   const int pc = ff_knob(FF_K_PINNED_COUNTERS);
   k.pinned = pc > 0 && pc < FF_PINNED_SLOTS ? pc : FF_PINNED_SLOTS;
@@ -265,6 +268,11 @@ size_t layout_decode(const ff_model* m, const ff_decode_params* p, const EngineK
   memset(&b, 0, sizeof(b));
   b.mem_pos = bp.take<float>((size_t)p->N * S * E);
   for (int l = 0; l < m->num_dec_layers; ++l) b.kvc[l] = bp.take<float>((size_t)p->N * S * 2 * E);
+  // the package default's cross-attention runs on the fp16 matrix cores as well (ff_attention_x2h.hip): K | V of every (wireframe,
+  // head) pair split once per batch into fp16 planes, 145 KB per pair and layer (key sets of at most 288 rows)
+  const bool planes = kn.x2h_attn && m->split_kind == 1 && p->x3_min_rows > 0 && S <= 288 && m->dec[0].in_proj_planes != nullptr;
+  for (int l = 0; l < m->num_dec_layers; ++l)
+    b.kvp[l] = planes ? bp.take<unsigned char>(ff_attention_planes_bytes(p->N, m->H)) : nullptr;
   b.x0_all = bp.take<float>((size_t)T * Btot * E);
   b.tok_all = bp.take<int>((size_t)T * Btot);
   b.qkv0_all = (p->flags & FF_REUSE_LAYER0_QKV) ? bp.take<float>((size_t)T * Btot * 3 * E) : nullptr;
@@ -486,6 +494,8 @@ int decoder_pass(const ff_model* m, const ff_decode_params* prm, const EngineKno
       d.kv_len = kv_len + ck.w0;
       d.key_mask = mask + (size_t)ck.w0 * S; d.mask_stride = S;
       d.scale = 0.125f;
+      if (bufs.kvp[l] && x3_wins(prm, R, 3 * E, E, E))   // (the steps whose projections take the split products)
+        d.kv_planes = bufs.kvp[l] + (size_t)ck.w0 * H * (ff_attention_planes_bytes(1, H) / H);
       FF_RETURN_IF(ff_attention(&d, st));
     }
     if (fuse) {
@@ -743,6 +753,8 @@ extern "C" int ff_decode(const ff_model* m, const ff_decode_params* p, const flo
       const ff_mha_weights& c = m->dec[l].cross_attn;
       FF_RETURN_IF(gemm(buf.mem_pos, E, memory, E, c.in_proj_w + (size_t)E * E, E, c.in_proj_b + E, nullptr, 0,
                         buf.kvc[l], 2 * E, RS, 2 * E, E, 0, main_st));
+      if (buf.kvp[l])
+        FF_RETURN_IF(ff_attention_split_kv(buf.kvc[l], buf.kvc[l] + E, 2 * E, 2 * E, N, m->H, S, S, 1, buf.kvp[l], main_st));
     }
     // cnt_ge | cnt_eq | arrive | seen are consecutive in the workspace (layout_decode): ONE fill
     FF_CHECK_HIP(hipMemsetAsync(buf.cnt_ge, 0, (size_t)(reinterpret_cast<char*>(buf.seen + Btot) - reinterpret_cast<char*>(buf.cnt_ge)),

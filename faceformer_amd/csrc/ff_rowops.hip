@@ -44,7 +44,7 @@ const KnobDef g_knob_defs[FF_K_COUNT] = {
     {"FF_SK_HYBRID_MINU", 2, false}, {"FF_SK_HYBRID_FORCE", 0, false},
     {"FF_NO_PANEL", 0, true}, {"FF_X3_SMALL_SPLIT", 0, false},
     {"FF_RK_SPLIT_OLD", 1, false}, {"FF_RK_SPLIT_YOUNG", 1, false}, {"FF_RK_PHASE", 0, false}, {"FF_RK_ROTATE", 1, false},
-    {"FF_X3_NEED_N1024", 7, false}, {"FF_X3_NEED_N512", 11, false},
+    {"FF_X3_NEED_N1024", 7, false}, {"FF_X3_NEED_N512", 11, false}, {"FF_X2H_ATTN", 1, false},
 };
 std::atomic<int> g_knobs[FF_K_COUNT];
 std::once_flag g_knobs_once;

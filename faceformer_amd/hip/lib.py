@@ -39,6 +39,7 @@ class AttnDesc(C.Structure):
         ("key_mask", fptr), ("mask_stride", C.c_int),
         ("causal", C.c_int),
         ("scale", C.c_float),
+        ("kv_planes", fptr),
     ]
 
 
@@ -145,6 +146,8 @@ SIGNATURES = {
     "ff_set_x3_tuning": (C.c_int, [C.c_int]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),
+    "ff_attention_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ff_attention_split_kv": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr]),
     "ff_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "ff_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "ff_reset_tuning": (C.c_int, []),

@@ -223,12 +223,30 @@ def fold_layernorm_linear(weight, bias, gamma, beta, pos=None, pos_cols=0):
 
 
 @_on_tensor_device
+def split_kv(k, v, num_groups, num_heads, nk, k_group_stride, k_stride):
+    """fp16 planes of K | V for the 2 x fp16 attention kernel (ff_attention_split_kv): a uint8 tensor of
+    ff_attention_planes_bytes(num_groups, num_heads) bytes; 1 <= nk <= 288."""
+    _dev(k, "k"), _dev(v, "v")
+    lib = _L.load()
+    planes = torch.empty(int(lib.ff_attention_planes_bytes(num_groups, num_heads)), device=k.device, dtype=torch.uint8)
+    _L.check(lib.ff_attention_split_kv(_p(k), _p(v), k.stride(0), v.stride(0), num_groups, num_heads, nk, k_group_stride, k_stride,
+                                       planes.data_ptr(), _stream()), "ff_attention_split_kv")
+    return planes
+
+
+_attn_algo = 0      # what set_attention_algo() last set: 4 makes attention() split K | V itself (tests of the 2 x fp16 kernel)
+
+
+@_on_tensor_device
 def attention(q, k, v, num_groups, num_heads, nq, nk, q_group_stride, q_inner, q_outer_stride,
               k_group_stride, k_stride, kv_len=None, key_mask=None, causal=False, scale=0.125,
-              out=None):
+              out=None, kv_planes=None):
     """Raw descriptor-level attention (see ff_attn_desc).  q/k/v/out are 2-D row tensors (views
-    into wider buffers are fine: the leading dimension is taken from stride(0))."""
+    into wider buffers are fine: the leading dimension is taken from stride(0)).  kv_planes: split_kv(k, v, ...) of the same
+    K | V -- eligible launches then run on the fp16 matrix cores."""
     _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
+    if kv_planes is None and _attn_algo == 4 and 0 < nk <= 288 and not causal:
+        kv_planes = split_kv(k, v, num_groups, num_heads, nk, k_group_stride, k_stride)
     if out is None:
         out = torch.empty((q.size(0), num_heads * _L.FF_HEAD_DIM), device=q.device, dtype=torch.float32)
     d = _L.AttnDesc()
@@ -245,6 +263,7 @@ def attention(q, k, v, num_groups, num_heads, nq, nk, q_group_stride, q_inner, q
     d.kv_len, d.key_mask = _p(kv_len), _p(key_mask)
     d.causal = 1 if causal else 0
     d.scale = scale
+    d.kv_planes = _p(kv_planes)
     _L.check(_L.load().ff_attention(C.byref(d), _stream()), "ff_attention")
     return out
 
@@ -300,7 +319,10 @@ def gather_rows(memory, tok, seqs_per_group=1):
 
 
 def set_attention_algo(algo):
-    """0 automatic, 1 block-shared LDS staging, 2 wave-independent; returns the previous value."""
+    """0 automatic, 1 block-shared LDS staging, 2 wave-independent, 3 K/V-resident, 4 the 2 x fp16 kernel (attention() then splits
+    K | V itself when the caller gives no planes); returns the previous value."""
+    global _attn_algo
+    _attn_algo = int(algo)
     return _L.load().ff_set_attention_algo(int(algo))
 
 

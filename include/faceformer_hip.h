@@ -255,12 +255,24 @@ typedef struct ff_attn_desc {
   const unsigned char* key_mask; int mask_stride; /* [num_groups, mask_stride] or NULL; 1 = masked */
   int causal;
   float scale;            /* 1/sqrt(64) = 0.125 on the path */
+  const void* kv_planes;  /* optional (round 6): the fp16 planes of k / v made by ff_attention_split_kv for exactly these groups, heads
+                             and nk -- launches that qualify (nk <= 288, no causal mask, enough query tiles) then run on the fp16 matrix
+                             cores with fp32 accuracy ("2 x fp16": ff_attention_x2h.hip); NULL: the f32 kernels */
 } ff_attn_desc;
+
+/* K | V of every (group, head) pair -> two fp16 planes each, in the layout the 2 x fp16 attention kernel copies into LDS
+ * (ff_attention_planes_bytes(num_groups, num_heads) bytes: 148 480 per pair).  k / v / ldk / ldv / nk / k_group_stride / k_stride as in
+ * ff_attn_desc; 1 <= nk <= 288.  Made once per batch and layer by ff_decode (cross-attention keys are the encoder memory:
+ * reference transformer.py:248-250); every |k|, |v| must be below 65504 (fp16's range). */
+size_t ff_attention_planes_bytes(int num_groups, int num_heads);
+int ff_attention_split_kv(const float* k, const float* v, int ldk, int ldv, int num_groups, int num_heads, int nk,
+                          int k_group_stride, int k_stride, void* planes, ff_stream_t stream);
 
 int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
 /* Kernel selection for ff_attention (tuning / tests): 0 automatic, 1 block-shared LDS staging,
  * 2 wave-independent with in-block key splitting, 3 K/V-resident (key sets of at most 288 rows without a causal mask;
- * other launches fall back to the automatic choice between 1 and 2).  Returns the previous value.
+ * other launches fall back to the automatic choice between 1 and 2), 4 the 2 x fp16 kernel whenever the descriptor carries planes
+ * and the launch is inside its limits (automatic: from the K/V-resident kernel's threshold on).  Returns the previous value.
  * The K/V-resident kernel parks partial (max, sum, O) records in the stream's scratch area (the one ff_gemm_prepare_stream
  * allocates: 24 MB per (device, stream), shared with the projection kernels of that stream in stream order). */
 int ff_set_attention_algo(int algo);

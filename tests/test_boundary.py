@@ -238,7 +238,7 @@ def test_tuning_table_is_one_settable_struct(hip_lib):
                 b"FF_DMA_MIN_ROWS": 4096, b"FF_DMA_MIN_ROWS_N512": 7680, b"FF_DMA_MIN_ROWS_WIDE": 2560, b"FF_SK_HYBRID": 1,
                 b"FF_SK_HYBRID_FIX": 10, b"FF_SK_HYBRID_MAXLEFT8": 4, b"FF_SK_HYBRID_MINU": 2, b"FF_SK_HYBRID_FORCE": 0,
                 b"FF_NO_PANEL": 0, b"FF_X3_SMALL_SPLIT": 0, b"FF_RK_SPLIT_OLD": 1, b"FF_RK_SPLIT_YOUNG": 1, b"FF_RK_PHASE": 0,
-                b"FF_RK_ROTATE": 1, b"FF_DEBUG_TIMING": 0, b"FF_X3_NEED_N1024": 7, b"FF_X3_NEED_N512": 11}
+                b"FF_RK_ROTATE": 1, b"FF_DEBUG_TIMING": 0, b"FF_X3_NEED_N1024": 7, b"FF_X3_NEED_N512": 11, b"FF_X2H_ATTN": 1}
     assert hip_lib.ff_reset_tuning() == 0
     for name, want in defaults.items():
         assert hip_lib.ff_get_tuning(name, ctypes.byref(v)) == 0 and v.value == want, name

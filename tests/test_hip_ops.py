@@ -10,7 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["attn-auto", "attn-lds", "attn-wave", "attn-resident"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["attn-auto", "attn-lds", "attn-wave", "attn-resident", "attn-x2h"])
 def attn_algo(ops, request):
     old = ops.set_attention_algo(request.param)
     yield request.param

@@ -6,7 +6,7 @@ name=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p build_ub/all_$name
 objs=""
-for src in ff_rowops ff_gemm ff_gemm_x3 ff_attention ff_pointer ff_engine; do
+for src in ff_rowops ff_gemm ff_gemm_x3 ff_attention ff_attention_x2h ff_pointer ff_engine; do
   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Ifaceformer_amd/csrc -Wall -Wno-unused-function "$@" \
         -c faceformer_amd/csrc/$src.hip -o build_ub/all_$name/$src.o &
   objs="$objs build_ub/all_$name/$src.o"

@@ -158,8 +158,12 @@ def main():
             pa, pw, pb, po, pp = a.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), planes.data_ptr()
             # (prebuilt arguments, straight ctypes calls: a few microseconds of host time per launch, so that the 26-us launches
             # of the config-B-sized shape stay GPU-bound)
-            run_case("gemm_x3_kernel %dx%d->%d %s" % (M, K, N, fill),
+            run_case("gemm_x3_kernel (3 x bf16) %dx%d->%d %s" % (M, K, N, fill),
                      lambda: lib.ff_gemm_x3(pa, K, None, 0, pp, pb, None, 0, po, N, M, N, K, 0, st), 2.0 * M * N * K, PEAK_X3)
+            planes2 = ops.split_weight(w, "fp16x2")       # round 6: two fp16 terms, three products (the package default)
+            pp2 = planes2.data_ptr()
+            run_case("gemm_x3_kernel (2 x fp16) %dx%d->%d %s" % (M, K, N, fill),
+                     lambda: lib.ff_gemm_x2h(pa, K, None, 0, pp2, pb, None, 0, po, N, M, N, K, 0, st), 2.0 * M * N * K, 2.0 * PEAK_X3)
             if True:
                 run_case("gemm_dma_f32_kernel %dx%d->%d %s" % (M, K, N, fill),
                          lambda: lib.ff_gemm_f32(pa, K, None, 0, pw, K, pb, None, 0, po, N, M, N, K, 0, 11, st), 2.0 * M * N * K, PEAK_F32)
