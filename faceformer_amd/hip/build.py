@@ -17,7 +17,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(HERE, "libfaceformer_hip.so")
 BUILD_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
-SOURCES = ["ff_rowops.hip", "ff_gemm.hip", "ff_gemm_x3.hip", "ff_attention.hip", "ff_attention_x2h.hip", "ff_pointer.hip", "ff_engine.hip"]
+SOURCES = ["ff_rowops.hip", "ff_gemm.hip", "ff_gemm_x3.hip", "ff_attention.hip", "ff_attention_x2h.hip", "ff_attention_general.hip", "ff_pointer.hip", "ff_engine.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function"]
 

@@ -17,7 +17,7 @@ FF_FUSE_LAYERNORM = 32
 FF_STOP_EACH_EOS = 512
 FF_NO_L0_FOLD = 1024
 FF_NO_POINTER_FOLD = 2048
-FF_ABI_VERSION = 102   # include/faceformer_hip.h: the struct layouts below are this version's
+FF_ABI_VERSION = 103   # include/faceformer_hip.h: the struct layouts below are this version's
 
 fptr = C.c_void_p  # device pointers travel as integers
 
@@ -40,6 +40,26 @@ class AttnDesc(C.Structure):
         ("causal", C.c_int),
         ("scale", C.c_float),
         ("kv_planes", fptr),
+    ]
+
+
+class AttnGeneralDesc(C.Structure):
+    _fields_ = [
+        ("q", fptr), ("k", fptr), ("v", fptr), ("o", fptr),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
+        ("num_groups", C.c_int), ("num_heads", C.c_int), ("head_dim", C.c_int),
+        ("nq", C.c_int),
+        ("q_group_stride", C.c_int), ("q_inner", C.c_int), ("q_outer_stride", C.c_int),
+        ("nk", C.c_int),
+        ("k_group_stride", C.c_int), ("k_stride", C.c_int),
+        ("kv_len", fptr),
+        ("key_mask", fptr), ("mask_stride", C.c_int),
+        ("causal", C.c_int),
+        ("attn_bias", fptr),
+        ("attn_mask", fptr),
+        ("attn_ld", C.c_int),
+        ("attn_batch_stride", C.c_longlong),
+        ("scale", C.c_float),
     ]
 
 
@@ -145,6 +165,7 @@ SIGNATURES = {
     "ff_gemm_x2h_ln": (C.c_int, [C.POINTER(GemmLnDesc), fptr, C.c_int, C.c_int, fptr, fptr]),
     "ff_set_x3_tuning": (C.c_int, [C.c_int]),
     "ff_attention": (C.c_int, [C.POINTER(AttnDesc), fptr]),
+    "ff_attention_general": (C.c_int, [C.POINTER(AttnGeneralDesc), fptr]),
     "ff_set_attention_algo": (C.c_int, [C.c_int]),
     "ff_attention_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ff_attention_split_kv": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr]),

@@ -269,6 +269,57 @@ def attention(q, k, v, num_groups, num_heads, nq, nk, q_group_stride, q_inner, q
 
 
 @_on_tensor_device
+def attention_general(q, k, v, num_groups, num_heads, head_dim, nq, nk, q_group_stride, q_inner, q_outer_stride,
+                      k_group_stride, k_stride, kv_len=None, key_mask=None, causal=False, attn_bias=None, attn_mask=None,
+                      scale=None, out=None):
+    """ff_attention_general: any head width, torch's `attn_mask` forms.  attn_bias: fp32 [nq, nk] or [num_groups*num_heads, nq, nk]
+    (added to the scores); attn_mask: uint8 / bool of the same shapes (non-zero = key removed).  A query without keys -> NaN (torch)."""
+    _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
+    if out is None:
+        out = torch.empty((q.size(0), num_heads * head_dim), device=q.device, dtype=torch.float32)
+    d = _L.AttnGeneralDesc()
+    d.q, d.k, d.v, d.o = _p(q), _p(k), _p(v), _p(out)
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.num_groups, d.num_heads, d.head_dim, d.nq, d.nk = num_groups, num_heads, head_dim, nq, nk
+    d.q_group_stride, d.q_inner, d.q_outer_stride = q_group_stride, q_inner, q_outer_stride
+    d.k_group_stride, d.k_stride = k_group_stride, k_stride
+    if kv_len is not None:
+        _dev(kv_len, "kv_len", torch.int32)
+    if key_mask is not None:
+        _dev(key_mask, "key_mask", torch.uint8)
+        d.mask_stride = key_mask.stride(0)
+    d.kv_len, d.key_mask = _p(kv_len), _p(key_mask)
+    d.causal = 1 if causal else 0
+    keep = []
+    for name, m, dt in (("attn_bias", attn_bias, torch.float32), ("attn_mask", attn_mask, torch.uint8)):
+        if m is None:
+            continue
+        if m.dtype == torch.bool and dt == torch.uint8:
+            m = m.to(torch.uint8)
+        _dev(m, name, dt)
+        if m.dim() == 2:
+            want = (nq, nk)
+        elif m.dim() == 3:
+            want = (num_groups * num_heads, nq, nk)
+        else:
+            raise ValueError("%s must be 2-D [nq, nk] or 3-D [num_groups*num_heads, nq, nk]" % name)
+        if tuple(m.shape) != want:
+            raise ValueError("%s must have shape %s, got %s" % (name, want, tuple(m.shape)))
+        m = m.contiguous()
+        keep.append(m)
+        ld, bs = nk, (nq * nk if m.dim() == 3 else 0)
+        if (d.attn_bias or d.attn_mask) and (d.attn_ld != ld or d.attn_batch_stride != bs):
+            # both given with different batching: expand the shared one (rare; keeps the descriptor to one addressing)
+            raise ValueError("attn_bias and attn_mask must both be 2-D or both 3-D")
+        d.attn_ld, d.attn_batch_stride = ld, bs
+        setattr(d, name, m.data_ptr())
+    d.scale = float(head_dim) ** -0.5 if scale is None else scale
+    _L.check(_L.load().ff_attention_general(C.byref(d), _stream()), "ff_attention_general")
+    del keep
+    return out
+
+
+@_on_tensor_device
 def pointer_argmax(p, memory, mask=None, kv_len=None, extra_mask=None, seqs_per_group=1,
                    want_logits=False, want_rows=False, counters=None, ge_bound=0, eq_value=0):
     """select_next: returns dict(next, best, second, [logits], [rows])."""

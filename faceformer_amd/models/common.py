@@ -113,9 +113,11 @@ class SurfaceFormerBase(nn.Module):
     # ---- native engine binding --------------------------------------------------------------------
     def engine_supported(self):
         """The native engine (ff_encode / ff_decode) implements what every reference config uses: pre-norm layers with relu
-        feed-forward blocks.  The other constructor arguments of the reference (model.py:14-18: `normalize_before=False`,
-        `activation="gelu"`) decode through `_forward_eval_modules`."""
-        return bool(self.normalize_before) and self.activation_name == "relu"
+        feed-forward blocks and 64-wide attention heads (num_model / num_head = 512 / 8).  The other constructor arguments of
+        the reference (model.py:14-18: `normalize_before=False`, `activation="gelu"`, any head width) decode through
+        `_forward_eval_modules`."""
+        return bool(self.normalize_before) and self.activation_name == "relu" and \
+            self.num_model == self.num_head * _L.FF_HEAD_DIM
 
     def _check_supported(self):
         if not self.normalize_before:
@@ -123,9 +125,12 @@ class SurfaceFormerBase(nn.Module):
                                       "(normalize_before=True, what every reference config uses)")
         if self.activation_name != "relu":
             raise NotImplementedError("the native decode engine implements relu feed-forward layers")
+        if self.num_model != self.num_head * _L.FF_HEAD_DIM:
+            raise NotImplementedError("the native decode engine implements %d-wide attention heads (num_model / num_head = 512 / 8 in "
+                                      "every reference config); other widths decode through the sub-module loop" % _L.FF_HEAD_DIM)
 
     def _forward_eval_modules(self, inputs, parallel):
-        """Greedy decode of a model the native engine does not implement (post-norm layers, gelu), driven from Python over
+        """Greedy decode of a model the native engine does not implement (post-norm layers, gelu, head widths other than 64), driven from Python over
         this package's HIP sub-modules: `encoder` / `decoder` / `project` run ff_layernorm / ff_gemm_f32 / ff_attention /
         ff_gelu, the pointer head is ff_pointer_argmax.  Same semantics as the reference's loops (model_para.py:181-241,
         model.py:169-219): whole prefix re-decoded every step, `finfo.min` mask fill, lowest index on ties, the parallel

@@ -7,7 +7,10 @@ arithmetic is NOT torch's: every forward below runs on libfaceformer_hip.so --
 
     LayerNorm (+pos add)      -> ff_layernorm      (one wavefront per row)
     q/k/v, out-proj, FFN      -> ff_gemm_f32       (v_mfma_f32_32x32x2_f32, fused bias/ReLU/residual)
-    softmax(qk^T)v            -> ff_attention      (LDS-staged K/V tiles, online softmax, f32 MFMA)
+    softmax(qk^T)v            -> ff_attention      (LDS-staged K/V tiles, online softmax, f32 MFMA; 64-wide heads,
+                                                    key padding / causal masks: every reference config)
+                                 ff_attention_general (any num_model / num_head, torch's general `attn_mask` forms:
+                                                    src_mask, non-causal / float tgt_mask, memory_mask)
 
 Tensors are sequence-first (len x batch x E) like the reference; a contiguous sequence-first tensor
 IS the position-major row matrix the kernels want (row = position * batch + b), so no transposes
@@ -65,16 +68,29 @@ def _mask_u8(mask, name, shape):
     return mask.to(torch.uint8).contiguous()
 
 
-def _is_causal(mask, n):
-    """True iff `mask` is the square 'subsequent' mask (reference model.py:71-73)."""
+def _attn_mask_forms(mask, name, lq, lk, batch_heads):
+    """torch's `attn_mask` (nn.MultiheadAttention: 2-D [L, S] or 3-D [N*H, L, S]; boolean = True removes the key, floating =
+    added to the scores) -> (causal, attn_bias, attn_mask) for the kernels.  The square 'subsequent' boolean mask (reference
+    model.py:71-73) is recognised and runs as the MFMA kernels' causal rule; every other form goes to ff_attention_general."""
     if mask is None:
-        return False
-    if mask.dtype != torch.bool or tuple(mask.shape) != (n, n):
-        raise NotImplementedError("tgt_mask: only the boolean causal mask is supported")
-    want = torch.triu(torch.ones(n, n, dtype=torch.bool, device=mask.device), diagonal=1)
-    if not torch.equal(mask, want):
-        raise NotImplementedError("tgt_mask: only the boolean causal mask is supported")
-    return True
+        return False, None, None
+    if mask.dim() == 2:
+        want = (lq, lk)
+    elif mask.dim() == 3:
+        want = (batch_heads, lq, lk)
+    else:
+        raise ValueError("%s must be 2-D [L, S] or 3-D [N*num_heads, L, S], got %s" % (name, tuple(mask.shape)))
+    if tuple(mask.shape) != want:
+        raise ValueError("%s must have shape %s, got %s" % (name, want, tuple(mask.shape)))
+    if mask.dtype in (torch.bool, torch.uint8):
+        m = mask.to(torch.bool)
+        if m.dim() == 2 and lq == lk and torch.equal(
+                m, torch.triu(torch.ones(lq, lq, dtype=torch.bool, device=m.device), diagonal=1)):
+            return True, None, None
+        return False, None, m.to(torch.uint8).contiguous()
+    if mask.is_floating_point():
+        return False, mask.to(torch.float32).contiguous(), None
+    raise TypeError("%s must be a boolean or floating-point tensor, got %s" % (name, mask.dtype))
 
 
 class MultiheadAttention(nn.Module):
@@ -100,15 +116,22 @@ class MultiheadAttention(nn.Module):
 
     def _check(self):
         _eval_only(self)
-        if self.head_dim != FF_HEAD_DIM:
-            raise HipExtensionError(
-                "num_model / num_head = %d / %d gives attention heads of width %d: the HIP attention kernels are written for "
-                "head width %d (every reference config: 512 / 8)" % (self.embed_dim, self.num_heads, self.head_dim, FF_HEAD_DIM))
+
+    def _two_inputs(self, xa, xb, w, b, n_split):
+        """columns [0, n_split) from `xa`, the rest from `xb`, one launch -- the kernel switches its A operand at a 64-column tile
+        boundary, so widths that are not a multiple of 64 (num_model 96, ...) take two launches into one output buffer."""
+        if xa is xb:
+            return ops.linear(xa, w, b)
+        if n_split % 64 == 0:
+            return ops.linear(xa, w, b, x2=xb, n_split=n_split)
+        out = torch.empty((xa.size(0), w.size(0)), device=xa.device, dtype=torch.float32)
+        ops.linear(xa, w[:n_split], b[:n_split], out=out[:, :n_split])
+        ops.linear(xb, w[n_split:], b[n_split:], out=out[:, n_split:])
+        return out
 
     def project_self(self, yq, y):
         """q|k from `yq`, v from `y` in one launch -> [rows, 3E]."""
-        E = self.embed_dim
-        return ops.linear(yq, self.in_proj_weight, self.in_proj_bias, x2=y, n_split=2 * E)
+        return self._two_inputs(yq, y, self.in_proj_weight, self.in_proj_bias, 2 * self.embed_dim)
 
     def project_q(self, yq):
         E = self.embed_dim
@@ -117,14 +140,22 @@ class MultiheadAttention(nn.Module):
     def project_kv(self, kin, vin):
         """k from `kin`, v from `vin` -> [rows, 2E]."""
         E = self.embed_dim
-        return ops.linear(kin, self.in_proj_weight[E:], self.in_proj_bias[E:], x2=vin, n_split=E)
+        return self._two_inputs(kin, vin, self.in_proj_weight[E:], self.in_proj_bias[E:], E)
 
-    def attend(self, q, k, v, lq, lk, batch, key_padding_mask=None, causal=False):
-        """q: [lq*batch, >=E] rows (position-major), k/v: [lk*batch, ...]; returns [lq*batch, E]."""
+    def attend(self, q, k, v, lq, lk, batch, key_padding_mask=None, causal=False, attn_bias=None, attn_mask=None):
+        """q: [lq*batch, >=E] rows (position-major), k/v: [lk*batch, ...]; returns [lq*batch, E].  64-wide heads with a key
+        padding mask and / or the causal rule run on the MFMA kernels (ff_attention); any other head width and torch's general
+        `attn_mask` forms (attn_bias additive, attn_mask boolean: _attn_mask_forms) run on ff_attention_general."""
         kv_len = None
         if key_padding_mask is not None:
             idx = torch.arange(1, lk + 1, device=q.device, dtype=torch.int32)
             kv_len = ((key_padding_mask == 0).to(torch.int32) * idx).amax(dim=1).to(torch.int32)
+        if self.head_dim != FF_HEAD_DIM or attn_bias is not None or attn_mask is not None:
+            return ops.attention_general(q, k, v, num_groups=batch, num_heads=self.num_heads, head_dim=self.head_dim, nq=lq, nk=lk,
+                                         q_group_stride=1, q_inner=1, q_outer_stride=batch,
+                                         k_group_stride=1, k_stride=batch, kv_len=kv_len, key_mask=key_padding_mask,
+                                         causal=causal, attn_bias=attn_bias, attn_mask=attn_mask,
+                                         scale=float(self.head_dim) ** -0.5)
         return ops.attention(q, k, v, num_groups=batch, num_heads=self.num_heads, nq=lq, nk=lk,
                              q_group_stride=1, q_inner=1, q_outer_stride=batch,
                              k_group_stride=1, k_stride=batch, kv_len=kv_len,
@@ -138,8 +169,8 @@ class MultiheadAttention(nn.Module):
         q = self.project_q(_rows(query))
         kv = self.project_kv(_rows(key), _rows(value))
         kpm = _mask_u8(key_padding_mask, "key_padding_mask", (batch, lk))
-        causal = _is_causal(attn_mask, lq) if attn_mask is not None else False
-        o = self.attend(q, kv[:, :E], kv[:, E:], lq, lk, batch, kpm, causal)
+        causal, bias, amask = _attn_mask_forms(attn_mask, "attn_mask", lq, lk, batch * self.num_heads)
+        o = self.attend(q, kv[:, :E], kv[:, E:], lq, lk, batch, kpm, causal, bias, amask)
         out = ops.linear(o, self.out_proj.weight, self.out_proj.bias)
         return out.view(lq, batch, E), None
 
@@ -218,28 +249,27 @@ class TransformerEncoderLayer(nn.Module):
 
     def _prep(self, src, src_mask, src_key_padding_mask, pos):
         self.self_attn._check()
-        if src_mask is not None:
-            raise NotImplementedError("src_mask is not used on the decode path and not supported")
         S, N, E = src.shape
         kpm = _mask_u8(src_key_padding_mask, "src_key_padding_mask", (N, S))
-        return S, N, E, kpm, _pos_table(pos, S, N)
+        smask = _attn_mask_forms(src_mask, "src_mask", S, S, N * self.self_attn.num_heads)
+        return S, N, E, kpm, smask, _pos_table(pos, S, N)
 
     def forward_pre(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
-        S, N, E, kpm, (table, div, mod) = self._prep(src, src_mask, src_key_padding_mask, pos)
+        S, N, E, kpm, smask, (table, div, mod) = self._prep(src, src_mask, src_key_padding_mask, pos)
         x = _rows(src)
         y, yq = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, table, div, mod)
         qkv = self.self_attn.project_self(yq if yq is not None else y, y)
-        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], S, S, N, kpm)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], S, S, N, kpm, *smask)
         x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
         y, _ = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self._ffn(y, x).view(S, N, E)
 
     def forward_post(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
-        S, N, E, kpm, (table, div, mod) = self._prep(src, src_mask, src_key_padding_mask, pos)
+        S, N, E, kpm, smask, (table, div, mod) = self._prep(src, src_mask, src_key_padding_mask, pos)
         x = _rows(src)
         xq = ops.add_pos(x, table, div, mod) if table is not None else x
         qkv = self.self_attn.project_self(xq, x)
-        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], S, S, N, kpm)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], S, S, N, kpm, *smask)
         x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
         x, _ = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self._ffn(x, x)
@@ -279,13 +309,12 @@ class TransformerDecoderLayer(nn.Module):
 
     def _prep(self, tgt, memory, tgt_mask, memory_mask, tgt_kpm, mem_kpm, pos, query_pos):
         self.self_attn._check()
-        if memory_mask is not None:
-            raise NotImplementedError("memory_mask is not used on the decode path and not supported")
         t, B, E = tgt.shape
         S = memory.size(0)
         if memory.size(1) != B:
             raise ValueError("memory batch %d != tgt batch %d" % (memory.size(1), B))
-        return (t, B, E, S, _is_causal(tgt_mask, t) if tgt_mask is not None else False,
+        return (t, B, E, S, _attn_mask_forms(tgt_mask, "tgt_mask", t, t, B * self.self_attn.num_heads),
+                _attn_mask_forms(memory_mask, "memory_mask", t, S, B * self.multihead_attn.num_heads),
                 _mask_u8(tgt_kpm, "tgt_key_padding_mask", (B, t)),
                 _mask_u8(mem_kpm, "memory_key_padding_mask", (B, S)),
                 _pos_table(pos, S, B), _pos_table(query_pos, t, B))
@@ -298,34 +327,34 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward_pre(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                     memory_key_padding_mask=None, pos=None, query_pos=None):
-        t, B, E, S, causal, tkpm, mkpm, ptab, (qtab, qdiv, qmod) = self._prep(
+        t, B, E, S, tmask, mmask, tkpm, mkpm, ptab, (qtab, qdiv, qmod) = self._prep(
             tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos, query_pos)
         x = _rows(tgt)
         y, yq = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, qtab, qdiv, qmod)
         qkv = self.self_attn.project_self(yq if yq is not None else y, y)
-        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], t, t, B, tkpm, causal)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], t, t, B, tkpm, *tmask)
         x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
         y, yq = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, qtab, qdiv, qmod)
         q = self.multihead_attn.project_q(yq if yq is not None else y)
         kv = self._cross_kv(memory, ptab)
-        o = self.multihead_attn.attend(q, kv[:, :E], kv[:, E:], t, S, B, mkpm)
+        o = self.multihead_attn.attend(q, kv[:, :E], kv[:, E:], t, S, B, mkpm, *mmask)
         x = ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, residual=x)
         y, _ = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         return self._ffn(y, x).view(t, B, E)
 
     def forward_post(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                      memory_key_padding_mask=None, pos=None, query_pos=None):
-        t, B, E, S, causal, tkpm, mkpm, ptab, (qtab, qdiv, qmod) = self._prep(
+        t, B, E, S, tmask, mmask, tkpm, mkpm, ptab, (qtab, qdiv, qmod) = self._prep(
             tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos, query_pos)
         x = _rows(tgt)
         xq = ops.add_pos(x, qtab, qdiv, qmod) if qtab is not None else x
         qkv = self.self_attn.project_self(xq, x)
-        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], t, t, B, tkpm, causal)
+        o = self.self_attn.attend(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], t, t, B, tkpm, *tmask)
         x = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, residual=x)
         x, xq = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, qtab, qdiv, qmod)
         q = self.multihead_attn.project_q(xq if xq is not None else x)
         kv = self._cross_kv(memory, ptab)
-        o = self.multihead_attn.attend(q, kv[:, :E], kv[:, E:], t, S, B, mkpm)
+        o = self.multihead_attn.attend(q, kv[:, :E], kv[:, E:], t, S, B, mkpm, *mmask)
         x = ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, residual=x)
         x, _ = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x = self._ffn(x, x)

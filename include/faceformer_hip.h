@@ -35,13 +35,13 @@ enum ff_status {
   FF_ERR_NO_DEVICE = -4
 };
 
-#define FF_HEAD_DIM 64   /* attention head width supported by the kernels (reference: 512 / 8) */
+#define FF_HEAD_DIM 64   /* attention head width of the MFMA kernels (reference: 512 / 8); other widths: ff_attention_general */
 #define FF_MAX_LAYERS 16
 
-/* Library version (major*10000 + minor*100 + patch).  101: the struct layouts of this header (round 5: ff_decode_params lost
+/* Library version (major*10000 + minor*100 + patch).  103: ff_attention_general / ff_attn_general_desc added (round 6).  101: the struct layouts of this header (round 5: ff_decode_params lost
  * chain_max_rows / flow_min_rows, FF_STOP_EACH_EOS added; round 4: ff_layer_weights grew by the ln*_planes / ln*_csum
  * pointers).  A caller built against another header must refuse to run: hip/lib.py asserts equality with FF_ABI_VERSION. */
-#define FF_ABI_VERSION 102
+#define FF_ABI_VERSION 103
 int ff_version(void);
 /* Thread-local text of the last error returned by this library ("" if none). */
 const char* ff_last_error(void);
@@ -276,6 +276,38 @@ int ff_attention(const ff_attn_desc* desc, ff_stream_t stream);
  * The K/V-resident kernel parks partial (max, sum, O) records in the stream's scratch area (the one ff_gemm_prepare_stream
  * allocates: 24 MB per (device, stream), shared with the projection kernels of that stream in stream order). */
 int ff_set_attention_algo(int algo);
+
+/* ---------------------------------------------------------------------------------------------
+ * General attention core (round 6): the part of nn.MultiheadAttention's surface the 64-wide MFMA kernels above do not take --
+ * ANY head width (reference transformer.py:131,191-192 pass num_model / num_head through; every reference config gives 64) and
+ * torch's `attn_mask` in its general forms: the `mask` / `src_mask` of the encoder (transformer.py:70-73,164-176), a `tgt_mask`
+ * that is not the causal triangle and the `memory_mask` of the decoder (transformer.py:95-101,235-256).  Same row addressing,
+ * kv_len / key_mask / causal meaning as ff_attn_desc; head h reads columns [h*head_dim, (h+1)*head_dim).
+ *   attn_bias : additive fp32 mask, element (query i, key j) at attn_bias[b*attn_batch_stride + i*attn_ld + j] with
+ *               b = group*num_heads + head (torch's [N*H, L, S] order); attn_batch_stride 0 = one [nq, nk] matrix for all
+ *   attn_mask : boolean mask (1 = the key is removed), same addressing (in bytes); either, both or neither may be given
+ * Arithmetic of torch's explicit-weights path (what the reference calls): q*scale first, scores, + bias, -inf for removed keys,
+ * softmax, P V.  A query with no key left yields NaN like torch (ff_attention yields 0).  One wavefront per (group, head, query)
+ * on the VALU: a correctness surface for module users, not the decode path's kernel.  head_dim + nk <= ~10 000 floats (LDS).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ff_attn_general_desc {
+  const float* q; const float* k; const float* v; float* o;
+  int ldq, ldk, ldv, ldo;
+  int num_groups, num_heads, head_dim;
+  int nq;
+  int q_group_stride, q_inner, q_outer_stride;
+  int nk;
+  int k_group_stride, k_stride;
+  const int* kv_len;
+  const unsigned char* key_mask; int mask_stride;
+  int causal;
+  const float* attn_bias;
+  const unsigned char* attn_mask;
+  int attn_ld;
+  long long attn_batch_stride;
+  float scale;            /* head_dim ** -0.5 for nn.MultiheadAttention */
+} ff_attn_general_desc;
+int ff_attention_general(const ff_attn_general_desc* desc, ff_stream_t stream);
 
 /* Tuning knobs (round 6): every A/B switch of the library is one int in one table.  `name` is the environment
  * variable that initialises the knob when the library is first used (FF_L0_FOLD, FF_POINTER_FOLD, FF_LAST_QKV_ONE_LAUNCH_ROWS,

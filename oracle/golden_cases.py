@@ -2,13 +2,15 @@
 them from the imported reference, and by the tests, which regenerate inputs/weights from the same
 recipes).  Every case is fully described by seeds + sizes; no tensor data lives here.
 
-model: E=num_model, H=num_head (head dim is always 64 here, like the reference's 512/8),
+model: E=num_model, H=num_head (head dim 64 like the reference's 512/8, except the `*_h32` / `*_h128` cases),
        FF=num_feedforward, enc/dec = layer counts, L=num_lines, seq_len = max_face_length (parallel)
        or label_seq_length (seq2seq).
 """
 
 SMALL = dict(E=128, H=2, FF=256, enc=2, dec=2)
 FULL = dict(E=512, H=8, FF=1024, enc=6, dec=6)
+SMALL_H32 = dict(E=128, H=4, FF=256, enc=2, dec=2)     # num_model / num_head = 32-wide heads (transformer.py:131,191-192 take any)
+SMALL_H128 = dict(E=128, H=1, FF=256, enc=2, dec=2)    # ... one 128-wide head
 
 
 def _m(base, L, seq_len):
@@ -79,6 +81,10 @@ CASES = [
          recipe="gain4", wseed=1, n_edges=[20, 13], seeds=[1, 2]),
     dict(name="seq_small_postnorm", kind="seq2seq", model=_mc(SMALL, 24, 30, normalize_before=False),
          recipe="gain4", wseed=0, n_edges=[20, 13], seeds=[1, 2]),
+    # head widths other than 64 (num_model / num_head of the constructor: the reference's layers take any, every config gives 64):
+    # ff_attention_general under the sub-module loop
+    dict(name="par_small_h32", kind="parallel", model=_m(SMALL_H32, 24, 9), recipe="gain4", wseed=2, n_edges=[20, 13], seeds=[1, 2]),
+    dict(name="seq_small_h128", kind="seq2seq", model=_m(SMALL_H128, 24, 30), recipe="gain4", wseed=17, n_edges=[20, 13], seeds=[1, 2]),
     # configs/seq2seq.yml sizes (config A): L=110, T=259, one 64-edge wireframe
     dict(name="seq_full_A64_gain4", kind="seq2seq", model=_m(FULL, 110, 259), recipe="gain4",
          wseed=0, n_edges=[64], seeds=[3], slow=True),

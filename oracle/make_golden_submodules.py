@@ -44,6 +44,24 @@ CASES = {
     "enc_pre_gelu": dict(kind="encoder", pre=True, layers=2, S=10, B=3, kpm=True, seed=14, act="gelu"),
     "dec_post_gelu": dict(kind="decoder", pre=False, layers=1, t=4, B=3, S=9, causal=False, tgt_kpm=False,
                           mem_kpm=True, intermediate=False, seed=15, act="gelu"),
+    # round 6 -- head widths other than 64 (transformer.py:131,191-192 hand num_model / num_head to nn.MultiheadAttention as they
+    # come) and torch's general attn_mask forms (transformer.py:70-73 `mask` -> src_mask; :95-101 tgt_mask / memory_mask): boolean
+    # or additive float, one [L, S] matrix or one per (batch, head).  All of these run on ff_attention_general.
+    "enc_pre_h32": dict(kind="encoder", pre=True, layers=2, S=13, B=3, kpm=True, seed=16, H=4),
+    "dec_pre_h128_causal": dict(kind="decoder", pre=True, layers=2, t=7, B=4, S=11, causal=True, tgt_kpm=True, mem_kpm=True,
+                                intermediate=False, seed=17, H=1),
+    "dec_post_h16": dict(kind="decoder", pre=False, layers=1, t=5, B=3, S=70, causal=False, tgt_kpm=False, mem_kpm=True,
+                         intermediate=False, seed=18, H=8),
+    "dec_pre_h48": dict(kind="decoder", pre=True, layers=1, t=4, B=2, S=9, causal=False, tgt_kpm=False, mem_kpm=True,
+                        intermediate=False, seed=19, H=2, E=96, FF=192),
+    "enc_pre_srcmask_float": dict(kind="encoder", pre=True, layers=2, S=12, B=3, kpm=True, seed=20, src_mask="float"),
+    "enc_post_srcmask_bool3d": dict(kind="encoder", pre=False, layers=1, S=9, B=2, kpm=False, seed=21, src_mask="bool3d"),
+    "dec_pre_tgtmask_band": dict(kind="decoder", pre=True, layers=2, t=8, B=3, S=10, causal=False, tgt_kpm=False, mem_kpm=True,
+                                 intermediate=False, seed=22, tgt_mask="band"),
+    "dec_pre_memmask_float": dict(kind="decoder", pre=True, layers=2, t=6, B=3, S=12, causal=True, tgt_kpm=False, mem_kpm=True,
+                                  intermediate=False, seed=23, memory_mask="float"),
+    "dec_post_memmask_bool_tgt_float3d": dict(kind="decoder", pre=False, layers=1, t=5, B=2, S=8, causal=False, tgt_kpm=True,
+                                              mem_kpm=False, intermediate=False, seed=24, memory_mask="bool", tgt_mask="float3d"),
     # DETR-style wrapper that neither model class instantiates (transformer.py:18-59)
     "transformer_post": dict(kind="transformer", pre=False, enc=1, dec=2, N=2, Hh=3, Ww=4, Q=5, intermediate=True,
                              seed=8),
@@ -67,15 +85,37 @@ def _import_reference():
     return ref_tr, ref_emb, ref_models
 
 
+def _general_mask(name, kind, lq, lk, batch_heads, seed):
+    """torch attn_mask forms: "float" additive [lq, lk]; "float3d" additive [batch*heads, lq, lk]; "bool" / "bool3d" removal masks
+    that keep key 0 of every query (a query without keys is NaN in torch: not a comparison case); "band": |i - j| > 2 removed."""
+    from faceformer_amd.synth import make_named_tensor as T
+    if kind == "band":
+        i = torch.arange(lq)[:, None]
+        j = torch.arange(lk)[None, :]
+        return (i - j).abs() > 2
+    shape = (batch_heads, lq, lk) if kind.endswith("3d") else (lq, lk)
+    x = T(name, shape, seed, 2.0)
+    if kind.startswith("float"):
+        return x
+    m = x > 0.6
+    m[..., 0] = False
+    return m
+
+
 def make_inputs(name, c):
     """Seeded inputs of a case (the test regenerates them with this function's twin in the test file)."""
     from faceformer_amd.synth import make_named_tensor as T
     s = c["seed"]
+    E, H = c.get("E", globals()["E"]), c.get("H", globals()["H"])
     if c["kind"] == "decoder":
         d = dict(tgt=T(name + ".tgt", (c["t"], c["B"], E), s), memory=T(name + ".memory", (c["S"], c["B"], E), s),
                  pos=T(name + ".pos", (c["S"], 1, E), s, 0.5), query_pos=T(name + ".qpos", (c["t"], 1, E), s, 0.5))
         if c["causal"]:
             d["tgt_mask"] = torch.triu(torch.ones(c["t"], c["t"], dtype=torch.bool), diagonal=1)
+        if c.get("tgt_mask"):
+            d["tgt_mask"] = _general_mask(name + ".tgt_mask", c["tgt_mask"], c["t"], c["t"], c["B"] * H, s)
+        if c.get("memory_mask"):
+            d["memory_mask"] = _general_mask(name + ".memory_mask", c["memory_mask"], c["t"], c["S"], c["B"] * H, s)
         if c["tgt_kpm"]:   # trailing positions padded, never position 0 (a causal row must keep one key)
             keep = 2 + (torch.arange(c["B"]) * 3) % (c["t"] - 1)
             d["tgt_key_padding_mask"] = torch.arange(c["t"])[None, :] >= keep[:, None]
@@ -85,8 +125,11 @@ def make_inputs(name, c):
         return d
     if c["kind"] == "encoder":
         d = dict(src=T(name + ".src", (c["S"], c["B"], E), s), pos=T(name + ".pos", (c["S"], 1, E), s, 0.5))
-        keep = 4 + (torch.arange(c["B"]) * 4) % (c["S"] - 3)
-        d["src_key_padding_mask"] = torch.arange(c["S"])[None, :] >= keep[:, None]
+        if c["kpm"]:
+            keep = 4 + (torch.arange(c["B"]) * 4) % (c["S"] - 3)
+            d["src_key_padding_mask"] = torch.arange(c["S"])[None, :] >= keep[:, None]
+        if c.get("src_mask"):
+            d["src_mask"] = _general_mask(name + ".src_mask", c["src_mask"], c["S"], c["S"], c["B"] * H, s)
         return d
     if c["kind"] == "transformer":
         hw = c["Hh"] * c["Ww"]
@@ -111,6 +154,7 @@ def make_inputs(name, c):
 def build(name, c, tr, emb, models, token):
     """The module under test, constructed through the PUBLIC constructors (works for the reference's modules and
     for faceformer_amd's: same signatures)."""
+    E, H, FF = c.get("E", globals()["E"]), c.get("H", globals()["H"]), c.get("FF", globals()["FF"])
     if c["kind"] == "decoder":
         layer = tr.TransformerDecoderLayer(E, H, FF, 0.1, c.get("act", "relu"), c["pre"])
         return tr.TransformerDecoder(layer, c["layers"], torch.nn.LayerNorm(E), return_intermediate=c["intermediate"])
@@ -140,10 +184,10 @@ def load_weights(module, name, c):
 
 def call(module, c, inp):
     if c["kind"] == "decoder":
-        kw = {k: inp[k] for k in ("tgt_mask", "tgt_key_padding_mask", "memory_key_padding_mask") if k in inp}
+        kw = {k: inp[k] for k in ("tgt_mask", "memory_mask", "tgt_key_padding_mask", "memory_key_padding_mask") if k in inp}
         return module(inp["tgt"], inp["memory"], pos=inp["pos"], query_pos=inp["query_pos"], **kw)
     if c["kind"] == "encoder":
-        return module(inp["src"], src_key_padding_mask=inp["src_key_padding_mask"], pos=inp["pos"])
+        return module(inp["src"], mask=inp.get("src_mask"), src_key_padding_mask=inp.get("src_key_padding_mask"), pos=inp["pos"])
     if c["kind"] == "transformer":
         hs, mem = module(inp["src"], inp["mask"], inp["query_embed"], inp["pos_embed"])
         return hs, mem
@@ -157,15 +201,17 @@ def call(module, c, inp):
 def restate(name, c, sd, inp):
     """The same call through oracle/refpath.py's functional restatements (pinned here, bit for bit)."""
     from oracle import refpath as R
+    H = c.get("H", globals()["H"])
     if c["kind"] == "decoder":
         return R.decoder_stack(sd, "", inp["tgt"], inp["memory"], H, c["layers"], normalize_before=c["pre"],
                                final_norm=True, return_intermediate=c["intermediate"], tgt_mask=inp.get("tgt_mask"),
                                tgt_key_padding_mask=inp.get("tgt_key_padding_mask"),
                                memory_key_padding_mask=inp.get("memory_key_padding_mask"), pos=inp["pos"],
-                               query_pos=inp["query_pos"], activation=c.get("act", "relu"))
+                               query_pos=inp["query_pos"], activation=c.get("act", "relu"), memory_mask=inp.get("memory_mask"))
     if c["kind"] == "encoder":
         return R.encoder_stack(sd, "", inp["src"], H, c["layers"], normalize_before=c["pre"], final_norm=c["pre"],
-                               src_key_padding_mask=inp["src_key_padding_mask"], pos=inp["pos"], activation=c.get("act", "relu"))
+                               src_key_padding_mask=inp.get("src_key_padding_mask"), pos=inp["pos"], activation=c.get("act", "relu"),
+                               src_mask=inp.get("src_mask"))
     if c["kind"] == "select_next":
         return R.select_next(inp["embedding"], inp["pointer"], inp["input_mask"])[0]
     return None

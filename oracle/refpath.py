@@ -69,11 +69,11 @@ def embed_edges(sd, coord, num_token):
     return torch.cat((token_embed, h), dim=1)
 
 
-def encoder_layer(sd, p, src, key_padding_mask, pos, num_head, act=F.relu):
+def encoder_layer(sd, p, src, key_padding_mask, pos, num_head, act=F.relu, src_mask=None):
     """reference transformer.py:164-176 (forward_pre)."""
     y = _ln(src, sd, p + ".norm1")
     q = k = y + pos
-    src = src + _mha(q, k, y, sd, p + ".self_attn", num_head, key_padding_mask)
+    src = src + _mha(q, k, y, sd, p + ".self_attn", num_head, key_padding_mask, src_mask)
     y = _ln(src, sd, p + ".norm2")
     y = F.linear(act(F.linear(y, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
@@ -103,11 +103,11 @@ def decoder_layer(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, n
     return tgt + y
 
 
-def encoder_layer_post(sd, p, src, key_padding_mask, pos, num_head, act=F.relu):
+def encoder_layer_post(sd, p, src, key_padding_mask, pos, num_head, act=F.relu, src_mask=None):
     """reference transformer.py:148-162 (forward_post; unused by the reference's configs, part of the module
     surface)."""
     q = k = src if pos is None else src + pos
-    src = src + _mha(q, k, src, sd, p + ".self_attn", num_head, key_padding_mask)
+    src = src + _mha(q, k, src, sd, p + ".self_attn", num_head, key_padding_mask, src_mask)
     src = _ln(src, sd, p + ".norm1")
     y = F.linear(act(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
@@ -115,13 +115,13 @@ def encoder_layer_post(sd, p, src, key_padding_mask, pos, num_head, act=F.relu):
 
 
 def decoder_layer_post(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, num_head, tgt_mask=None,
-                       tgt_key_padding_mask=None, act=F.relu):
+                       tgt_key_padding_mask=None, act=F.relu, memory_mask=None):
     """reference transformer.py:211-233 (forward_post)."""
     q = k = tgt if query_pos is None else tgt + query_pos
     tgt = tgt + _mha(q, k, tgt, sd, p + ".self_attn", num_head, tgt_key_padding_mask, tgt_mask)
     tgt = _ln(tgt, sd, p + ".norm1")
     tgt = tgt + _mha(tgt if query_pos is None else tgt + query_pos, memory if pos is None else memory + pos, memory,
-                     sd, p + ".multihead_attn", num_head, memory_key_padding_mask)
+                     sd, p + ".multihead_attn", num_head, memory_key_padding_mask, memory_mask)
     tgt = _ln(tgt, sd, p + ".norm2")
     y = F.linear(act(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
@@ -129,7 +129,7 @@ def decoder_layer_post(sd, p, tgt, memory, memory_key_padding_mask, pos, query_p
 
 
 def decoder_layer_pre_kpm(sd, p, tgt, memory, memory_key_padding_mask, pos, query_pos, num_head, tgt_mask=None,
-                          tgt_key_padding_mask=None, act=F.relu):
+                          tgt_key_padding_mask=None, act=F.relu, memory_mask=None):
     """reference transformer.py:235-256 with EVERY keyword of the layer (the eval loop passes no tgt masks; the
     teacher-forced caller model_para.py:162-163 passes tgt_mask and tgt_key_padding_mask)."""
     y = _ln(tgt, sd, p + ".norm1")
@@ -137,7 +137,7 @@ def decoder_layer_pre_kpm(sd, p, tgt, memory, memory_key_padding_mask, pos, quer
     tgt = tgt + _mha(q, k, y, sd, p + ".self_attn", num_head, tgt_key_padding_mask, tgt_mask)
     y = _ln(tgt, sd, p + ".norm2")
     tgt = tgt + _mha(y if query_pos is None else y + query_pos, memory if pos is None else memory + pos, memory, sd,
-                     p + ".multihead_attn", num_head, memory_key_padding_mask)
+                     p + ".multihead_attn", num_head, memory_key_padding_mask, memory_mask)
     y = _ln(tgt, sd, p + ".norm3")
     y = F.linear(act(F.linear(y, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
@@ -155,14 +155,14 @@ def _activation(name):
 
 def decoder_stack(sd, prefix, tgt, memory, num_head, num_layers, normalize_before=True, final_norm=True,
                   return_intermediate=False, tgt_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None,
-                  pos=None, query_pos=None, activation="relu"):
+                  pos=None, query_pos=None, activation="relu", memory_mask=None):
     """reference transformer.py:95-124 over a state_dict with keys `<prefix>layers.<i>.*`, `<prefix>norm.*`: both
     layer forms and the `return_intermediate` stack."""
     layer = decoder_layer_pre_kpm if normalize_before else decoder_layer_post
     out, inter = tgt, []
     for i in range(num_layers):
         out = layer(sd, "%slayers.%d" % (prefix, i), out, memory, memory_key_padding_mask, pos, query_pos, num_head,
-                    tgt_mask, tgt_key_padding_mask, _activation(activation))
+                    tgt_mask, tgt_key_padding_mask, _activation(activation), memory_mask)
         if return_intermediate:
             inter.append(_ln(out, sd, prefix + "norm"))
     if final_norm:
@@ -173,15 +173,15 @@ def decoder_stack(sd, prefix, tgt, memory, num_head, num_layers, normalize_befor
 
 
 def encoder_stack(sd, prefix, src, num_head, num_layers, normalize_before=True, final_norm=True,
-                  src_key_padding_mask=None, pos=None, activation="relu"):
+                  src_key_padding_mask=None, pos=None, activation="relu", src_mask=None):
     """reference transformer.py:70-83 with either layer form."""
     out = src
     for i in range(num_layers):
         p = "%slayers.%d" % (prefix, i)
         if normalize_before:
-            out = encoder_layer(sd, p, out, src_key_padding_mask, 0 if pos is None else pos, num_head, _activation(activation))
+            out = encoder_layer(sd, p, out, src_key_padding_mask, 0 if pos is None else pos, num_head, _activation(activation), src_mask)
         else:
-            out = encoder_layer_post(sd, p, out, src_key_padding_mask, pos, num_head, _activation(activation))
+            out = encoder_layer_post(sd, p, out, src_key_padding_mask, pos, num_head, _activation(activation), src_mask)
     return _ln(out, sd, prefix + "norm") if final_norm else out
 
 

@@ -53,10 +53,10 @@ def load_golden(name):
 
 
 def is_module_path(case):
-    """Constructor arguments the native engine does not implement (post-norm layers, gelu): `forward_eval` then runs the
-    reference's loop on the HIP sub-modules (models/common.py: _forward_eval_modules)."""
+    """Constructor arguments the native engine does not implement (post-norm layers, gelu, head widths other than 64):
+    `forward_eval` then runs the reference's loop on the HIP sub-modules (models/common.py: _forward_eval_modules)."""
     m = case["model"]
-    return (not m.get("normalize_before", True)) or m.get("activation", "relu") != "relu"
+    return (not m.get("normalize_before", True)) or m.get("activation", "relu") != "relu" or m["E"] != 64 * m["H"]
 
 
 def golden_names(include_slow=True, module_path=False):

@@ -178,9 +178,10 @@ def test_struct_layouts_match_the_header(hip_lib):
 #include <stdio.h>
 #include "faceformer_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ff_attn_desc), sizeof(ff_mha_weights), sizeof(ff_layer_weights),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ff_attn_desc), sizeof(ff_mha_weights), sizeof(ff_layer_weights),
          sizeof(ff_model), sizeof(ff_decode_params), offsetof(ff_model, dec), sizeof(ff_gemm_ln_desc),
-         offsetof(ff_gemm_ln_desc, ln_stats_out));
+         offsetof(ff_gemm_ln_desc, ln_stats_out), sizeof(ff_attn_general_desc), offsetof(ff_attn_general_desc, attn_batch_stride),
+         offsetof(ff_attn_general_desc, scale));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -190,7 +191,8 @@ int main(void) {
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     got = [ctypes.sizeof(lib.AttnDesc), ctypes.sizeof(lib.MhaWeights), ctypes.sizeof(lib.LayerWeights),
            ctypes.sizeof(lib.Model), ctypes.sizeof(lib.DecodeParams), lib.Model.dec.offset,
-           ctypes.sizeof(lib.GemmLnDesc), lib.GemmLnDesc.ln_stats_out.offset]
+           ctypes.sizeof(lib.GemmLnDesc), lib.GemmLnDesc.ln_stats_out.offset, ctypes.sizeof(lib.AttnGeneralDesc),
+           lib.AttnGeneralDesc.attn_batch_stride.offset, lib.AttnGeneralDesc.scale.offset]
     assert [int(x) for x in out] == got
 
 
@@ -215,6 +217,12 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device(hip_lib):
     d.num_groups, d.num_heads, d.nq, d.nk = 1, 1, 4, 4
     assert hip_lib.ff_attention(ctypes.byref(d), None) == FF_ERR_ARG
     assert hip_lib.ff_attention(None, None) == FF_ERR_ARG
+    ga = lib.AttnGeneralDesc()
+    ga.num_groups, ga.num_heads, ga.head_dim, ga.nq, ga.nk = 1, 1, 0, 4, 4
+    assert hip_lib.ff_attention_general(ctypes.byref(ga), None) == FF_ERR_ARG and b"head_dim" in hip_lib.ff_last_error()
+    ga.head_dim = 32
+    assert hip_lib.ff_attention_general(ctypes.byref(ga), None) == FF_ERR_ARG and b"null tensor" in hip_lib.ff_last_error()
+    assert hip_lib.ff_attention_general(None, None) == FF_ERR_ARG
     # the bf16-split product: K must be a multiple of 32 and at least 64
     assert hip_lib.ff_gemm_x3(p, 48, None, 0, p, None, None, 0, p, 8, 2, 2, 48, 0, None) == FF_ERR_ARG
     assert b"K" in hip_lib.ff_last_error()

@@ -50,16 +50,94 @@ def test_gelu_rows_match_fp64_erf_form(hip_lib, ops, rows, E, ld):
     assert torch.equal(buf[:, E:], before[:, E:])
 
 
-def test_head_width_other_than_64_is_a_clear_error(hip_lib, ops):
-    """num_model / num_head != 64 (a constructor choice of the boundary, reference transformer.py:132): the module says what it
-    supports instead of failing inside a kernel."""
+def test_head_width_other_than_64_runs_on_the_general_kernel(hip_lib, ops):
+    """num_model / num_head != 64 (a constructor choice of the boundary, reference transformer.py:131-132): the layer runs on
+    ff_attention_general (round 6; it was a clear error before) and matches torch's nn.MultiheadAttention arithmetic in fp64."""
+    from faceformer_amd.transformer import MultiheadAttention
+    for E, H in ((128, 4), (128, 1), (96, 2), (64, 8)):       # heads of 32 / 128 / 48 / 8
+        mha = MultiheadAttention(E, H).eval()
+        ref = torch.nn.MultiheadAttention(E, H).double().eval()
+        ref.load_state_dict({k: v.double() for k, v in mha.state_dict().items()})
+        q, kk = rnd(6, 3, E, seed=E + H), rnd(11, 3, E, seed=E + H + 1)
+        kpm = torch.arange(11)[None, :] >= torch.tensor([11, 7, 3])[:, None]
+        with torch.no_grad():
+            want = ref(q.double(), kk.double(), kk.double(), key_padding_mask=kpm)[0]
+            got = mha.cuda()(q.cuda(), kk.cuda(), kk.cuda(), key_padding_mask=kpm.cuda())[0]
+        assert rel_err(got, want) < 5e-6, (E, H)
+
+
+def _ref_attention_general(q, k, v, hd, kpm=None, causal=False, bias=None, amask=None):
+    """q [G,H,nq,hd], k / v [G,H,nk,hd] fp64; kpm [G,nk] bool; bias / amask [nq,nk] or [G*H,nq,nk]."""
+    G, H, nq, _ = q.shape
+    s = (q * hd ** -0.5) @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + (bias.double().view(G, H, nq, -1) if bias.dim() == 3 else bias.double())
+    if amask is not None:
+        s = s.masked_fill(amask.view(G, H, nq, -1) if amask.dim() == 3 else amask, float("-inf"))
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(nq, s.shape[-1], dtype=torch.bool), 1), float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("G,H,hd,nq,nk,form", [
+    (2, 2, 64, 33, 33, "plain"), (3, 4, 32, 17, 70, "kpm"), (2, 1, 128, 9, 130, "kpm"), (2, 8, 16, 40, 40, "causal"),
+    (1, 2, 48, 5, 19, "kpm"), (2, 3, 20, 7, 65, "plain"), (1, 16, 8, 6, 200, "kpm"), (1, 2, 4, 3, 9, "plain"), (1, 1, 256, 4, 31, "kpm"),
+    (2, 2, 64, 12, 20, "bias2d"), (2, 2, 32, 12, 20, "bias3d"), (3, 2, 64, 10, 15, "mask2d"), (2, 4, 32, 10, 15, "mask3d"),
+    (2, 2, 64, 8, 300, "bias2d+mask2d"), (2, 2, 64, 9, 9, "causal+bias2d"), (1, 1, 64, 3, 2000, "kpm"), (1, 3, 7, 5, 11, "mask2d")])
+def test_attention_general_matches_fp64(hip_lib, ops, G, H, hd, nq, nk, form):
+    """ff_attention_general (any head width; additive and boolean attn_mask, one matrix or one per (group, head); key padding,
+    kv_len, causal) against the explicit fp64 softmax, in the position-major layout of the blocks (row = position * G + g)."""
+    E = H * hd
+    q, kv = rnd(nq * G, E, seed=1), rnd(nk * G, 2 * E + 8, seed=2)       # k | v packed in one buffer with a wider ld
+    kpm = kv_len = bias = amask = None
+    if "kpm" in form:
+        keep = torch.tensor([max(1, nk - 3 * g - nk // 4) for g in range(G)])
+        kpm = torch.arange(nk)[None, :] >= keep[:, None]
+        if nk > 4:
+            kpm[:, 1] = True
+        kv_len = keep.to(torch.int32)
+    if "bias2d" in form:
+        bias = rnd(nq, nk, seed=3, scale=2.0)
+        bias[0, min(3, nk - 1)] = float("-inf")       # torch allows -inf inside an additive mask
+    if "bias3d" in form:
+        bias = rnd(G * H, nq, nk, seed=4, scale=2.0)
+    if "mask2d" in form:
+        amask = rnd(nq, nk, seed=5) > 0.5
+        amask[:, 0] = False
+    if "mask3d" in form:
+        amask = rnd(G * H, nq, nk, seed=6) > 0.5
+        amask[..., 0] = False
+    dkv = kv.cuda()
+    out = ops.attention_general(q.cuda(), dkv[:, :E], dkv[:, E:2 * E], G, H, hd, nq, nk, q_group_stride=1, q_inner=1, q_outer_stride=G,
+                                k_group_stride=1, k_stride=G, kv_len=None if kv_len is None else kv_len.cuda(),
+                                key_mask=None if kpm is None else kpm.to(torch.uint8).cuda(), causal="causal" in form,
+                                attn_bias=None if bias is None else bias.cuda(), attn_mask=None if amask is None else amask.cuda())
+    qd = q.double().view(nq, G, H, hd).permute(1, 2, 0, 3)
+    kd = kv[:, :E].double().view(nk, G, H, hd).permute(1, 2, 0, 3)
+    vd = kv[:, E:2 * E].double().view(nk, G, H, hd).permute(1, 2, 0, 3)
+    ref = _ref_attention_general(qd, kd, vd, hd, kpm, "causal" in form, bias, amask).permute(2, 0, 1, 3).reshape(nq * G, E)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 5e-6
+
+
+def test_attention_general_query_without_keys_is_nan_like_torch(hip_lib, ops):
+    """torch's softmax over a row of -inf is NaN and so is that query's output (nn.MultiheadAttention with a boolean mask that
+    removes every key); the general kernel keeps that, other queries of the launch are unaffected."""
+    G, H, hd, nq, nk = 1, 2, 32, 4, 6
+    q, k, v = rnd(nq, H * hd, seed=1), rnd(nk, H * hd, seed=2), rnd(nk, H * hd, seed=3)
+    amask = torch.zeros(nq, nk, dtype=torch.bool)
+    amask[2] = True
+    out = ops.attention_general(q.cuda(), k.cuda(), v.cuda(), G, H, hd, nq, nk, q_group_stride=1, q_inner=1, q_outer_stride=1,
+                                k_group_stride=1, k_stride=1, attn_mask=amask.cuda()).cpu()
+    assert torch.isnan(out[2]).all() and torch.isfinite(out[[0, 1, 3]]).all()
+    with pytest.raises(ValueError):
+        ops.attention_general(q.cuda(), k.cuda(), v.cuda(), G, H, hd, nq, nk, 1, 1, 1, 1, 1, attn_mask=amask[:, :3].cuda())
     from faceformer_amd.hip.lib import HipExtensionError
-    from faceformer_amd.transformer import TransformerEncoderLayer
-    layer = TransformerEncoderLayer(128, 4, 256, 0.1, "relu", True).eval().cuda()     # heads of 32
-    with pytest.raises(HipExtensionError, match="head width 64"):
-        layer(torch.zeros(5, 2, 128, device="cuda"))
-    with pytest.raises(NotImplementedError, match="glu"):
-        TransformerEncoderLayer(128, 2, 256, 0.1, "glu", True).eval().cuda()(torch.zeros(5, 2, 128, device="cuda"))
+    with pytest.raises(HipExtensionError, match="LDS"):      # 4 rows of (head_dim + nk) floats must fit a CU's LDS
+        big = torch.zeros(20000, 64, device="cuda")
+        ops.attention_general(big[:1], big, big, 1, 1, 64, 1, 20000, 1, 1, 1, 1, 1)
 
 
 # ---- LayerNorm -------------------------------------------------------------------------------------
