@@ -61,10 +61,12 @@ def _pos_table(pos, length, batch):
 def _mask_u8(mask, name, shape):
     if mask is None:
         return None
-    if mask.dtype not in (torch.bool, torch.uint8):
-        raise NotImplementedError("%s: only boolean padding masks are supported" % name)
     if tuple(mask.shape) != tuple(shape):
         raise ValueError("%s must have shape %s, got %s" % (name, shape, tuple(mask.shape)))
+    if mask.is_floating_point():    # torch adds a floating-point padding mask to the scores of its keys (attend -> ff_attention_general)
+        return mask.to(torch.float32).contiguous()
+    if mask.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("%s must be a boolean or floating-point tensor, got %s" % (name, mask.dtype))
     return mask.to(torch.uint8).contiguous()
 
 
@@ -147,6 +149,19 @@ class MultiheadAttention(nn.Module):
         padding mask and / or the causal rule run on the MFMA kernels (ff_attention); any other head width and torch's general
         `attn_mask` forms (attn_bias additive, attn_mask boolean: _attn_mask_forms) run on ff_attention_general."""
         kv_len = None
+        if key_padding_mask is not None and key_padding_mask.is_floating_point():
+            # additive padding mask [batch, lk]: one [lq, lk] matrix per (batch, head) like torch's merged mask (mask plumbing only)
+            pad = key_padding_mask[:, None, None, :].expand(batch, self.num_heads, lq, lk)
+            if attn_bias is not None:
+                pad = pad + (attn_bias.view(batch, self.num_heads, lq, lk) if attn_bias.dim() == 3 else attn_bias)
+            if attn_mask is not None and attn_mask.dim() == 2:
+                attn_mask = attn_mask[None].expand(batch * self.num_heads, lq, lk)
+            attn_bias, key_padding_mask = pad.reshape(batch * self.num_heads, lq, lk).contiguous(), None
+        elif attn_bias is not None and attn_mask is not None and attn_bias.dim() != attn_mask.dim():
+            if attn_bias.dim() == 2:
+                attn_bias = attn_bias[None].expand(batch * self.num_heads, lq, lk).contiguous()
+            else:
+                attn_mask = attn_mask[None].expand(batch * self.num_heads, lq, lk).contiguous()
         if key_padding_mask is not None:
             idx = torch.arange(1, lk + 1, device=q.device, dtype=torch.int32)
             kv_len = ((key_padding_mask == 0).to(torch.int32) * idx).amax(dim=1).to(torch.int32)

@@ -66,6 +66,27 @@ def test_head_width_other_than_64_runs_on_the_general_kernel(hip_lib, ops):
         assert rel_err(got, want) < 5e-6, (E, H)
 
 
+def test_float_key_padding_mask_and_mixed_mask_forms_match_torch(hip_lib, ops):
+    """torch adds a floating-point key_padding_mask to the scores of its keys; combined with a boolean [L, S] attn_mask or an
+    additive one per (batch, head) the module merges them like torch's multi_head_attention_forward does."""
+    from faceformer_amd.transformer import MultiheadAttention
+    E, H, L, S, B = 128, 2, 5, 9, 3
+    mha = MultiheadAttention(E, H).eval()
+    ref = torch.nn.MultiheadAttention(E, H).double().eval()
+    ref.load_state_dict({k: v.double() for k, v in mha.state_dict().items()})
+    mha = mha.cuda()
+    q, kk = rnd(L, B, E, seed=1), rnd(S, B, E, seed=2)
+    kpm_f = rnd(B, S, seed=3, scale=1.5)
+    am_b = rnd(L, S, seed=4) > 0.7
+    am_b[:, 0] = False
+    am_f3 = rnd(B * H, L, S, seed=5, scale=1.5)
+    for kpm, am in ((kpm_f, None), (kpm_f, am_f3), (kpm_f, am_b.float().masked_fill(am_b, float("-inf")))):
+        with torch.no_grad():
+            want = ref(q.double(), kk.double(), kk.double(), key_padding_mask=kpm.double(), attn_mask=None if am is None else am.double())[0]
+            got = mha(q.cuda(), kk.cuda(), kk.cuda(), key_padding_mask=kpm.cuda(), attn_mask=None if am is None else am.cuda())[0]
+        assert rel_err(got, want) < 5e-6
+
+
 def _ref_attention_general(q, k, v, hd, kpm=None, causal=False, bias=None, amask=None):
     """q [G,H,nq,hd], k / v [G,H,nk,hd] fp64; kpm [G,nk] bool; bias / amask [nq,nk] or [G*H,nq,nk]."""
     G, H, nq, _ = q.shape
