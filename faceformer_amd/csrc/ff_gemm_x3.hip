@@ -175,6 +175,27 @@ __device__ __forceinline__ float x3_fmul(float a, float b) {
 }
 
 constexpr int X3_BN = 128, X3_BK = 16;
+// Depth of the LDS ring of K slices.  Slice s + RING is requested while slice s computes and must have landed one iteration
+// before its fragments are read, so RING - 1.5 iterations of a block cover the DMA round trip.  Round 6 asked whether the fp16 loop
+// (3 x 2 x 32 = 192 matrix-core cycles per slice and wave against 6 x 64 / 16 x 64 of the bf16 / f32 loops; MFMA-busy 0.18-0.28
+// whatever the size) waits for its DMA: rings of four (plain forms, three blocks per CU) / five / six slots (the two-block
+// LayerNorm consumers) measured the same as three within the run-to-run noise (profiles/r06/x2h_loop_probes.txt), and so did
+// a loop that never waits for vmcnt -- the DMA round trip is covered.  Three slots stay; the depth is a build-time constant
+// for probes (tools/build_variant.sh ... -DX3_RING_H=4).
+#ifndef X3_RING_H
+#define X3_RING_H 3
+#endif
+#ifndef X3_RING_H1
+#define X3_RING_H1 3
+#endif
+#ifndef X3_RING_H3
+#define X3_RING_H3 3
+#endif
+#ifndef X3_RING_F32
+#define X3_RING_F32 3
+#endif
+template <int MODE, int NT>
+constexpr int x3_ring() { return NT == 3 ? 3 : (MODE == 1 ? X3_RING_H1 : (MODE == 3 ? X3_RING_H3 : X3_RING_H)); }
 constexpr int X3_STAT_BYTES = 16384;   // MODE 1: one 4 KB patch per wave (32 rows x 16 segments x (mean, M2))
 
 // BM: 128 (4 x 1 waves) or 64 (2 x 2 waves).  MODE: 0 plain, 1 LayerNorm consumer (rows normalised before the split),
@@ -186,14 +207,20 @@ constexpr int X3_STAT_BYTES = 16384;   // MODE 1: one 4 KB patch per wave (32 ro
 // the fp32 class (profiles/r06/fp16_split_error_table.txt; tests/test_hip_ops.py::test_gemm_x2h_*).  fp16 has 5 exponent
 // bits: |x| must stay below 65504, which the callers guarantee (LayerNorm output is bounded by sqrt(K); the engine checks the
 // norm bounds of the other operands when it binds the planes: faceformer_amd/hip/engine.py).
+#ifndef X3_LN_H_BLOCKS      // blocks per CU of the LayerNorm-consuming fp16 form (MODE 1, NT 2).  Round 6 tried 3 (168 registers, spills on the
+#define X3_LN_H_BLOCKS 2    // tile-change paths only; 52 KB of LDS each): +5 % on the isolated launch, -1.5 % on config B / C128 end to end -- stays at 2 (199 registers)
+#endif
+template <int MODE, int NT>
+constexpr int x3_blocks_per_cu() { return MODE == 3 ? 2 : (MODE == 1 ? (NT == 2 ? X3_LN_H_BLOCKS : 2) : 3); }
 template <int BM, int MODE, int NT>
-__global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3_kernel(X3Args g) {   // (MODE 3 with two terms at three blocks per CU: 368 B of scratch, 10 accesses inside the MFMA runs -- stays at two)
+__global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_kernel(X3Args g) {   // (MODE 3 with two terms at three blocks per CU: 368 B of scratch, 10 accesses inside the MFMA runs -- stays at two)
   constexpr int BN = X3_BN, BK = X3_BK;
   constexpr int WN = 128 / BM;              // waves along N: 1 or 2
   constexpr int NI = BN / WN / 32;          // 32-column accumulators per wave: 4 or 2
   constexpr int NPA = BM / 64;              // A pieces (16 rows x 64 B) per wave and slice
   constexpr int NP = NPA + NT;              // DMA pieces per wave and slice
   constexpr int A_REG = BM * 64, SLOT = A_REG + NT * BN * 32;
+  constexpr int RING = x3_ring<MODE, NT>();
   constexpr int NPROD = NT == 3 ? 6 : 3;    // partial products per fp32 product
   constexpr int NMF = NPROD * NI;           // MFMAs per wave and slice
   constexpr int NRD = 2 + NT * NI;          // fragment reads per wave and slice
@@ -291,6 +318,13 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
   };
   auto issue_piece = [&](int k, int slot) {   // piece k of the slice the loader stands on -> ring slot `slot`
     unsigned char* base = lds + slot * SLOT;
+#if defined(X3_EXP_NODMA)          // probe: the loop without its operand traffic (computes on whatever the LDS holds)
+    if (g.M > 0) return;
+#elif defined(X3_EXP_NODMA_A)      // probe: ... without the activation pieces only
+    if (k < NPA) return;
+#elif defined(X3_EXP_NODMA_W)      // probe: ... without the weight pieces only
+    if (k >= NPA) return;
+#endif
     if (k < NPA) {
       __builtin_amdgcn_global_load_lds(a_base + a_off[k < NPA ? k : 0], X3_LDS_PTR(base + (wave * NPA + k) * 1024), 16, 0, 0);
     } else {
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
   // ---- MODE 1: (mean, rstd) of this lane's row for the tile being computed and the next one ----
   float mean_c = 0.f, rstd_c = 1.f, mean_n = 0.f, rstd_n = 1.f;
   float mean_s = 0.f, rstd_s = 1.f;   // what the split in flight uses
-  const unsigned stat_lds = lds0 + 3 * SLOT + wave * 4096;
+  const unsigned stat_lds = lds0 + RING * SLOT + wave * 4096;
   auto stats_fetch = [&](int p) {     // DMA the segment statistics of segment p's rows (this wave's 32) into the wave's patch
     if (MODE != 1 || p >= nseg) return;
     int tile, j0, n, kind, m0, n0;
@@ -351,7 +385,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
       row = row < g.M ? row : g.M - 1;
       // (16-byte chunk c of patch row r sits at position c ^ ((r >> 1) & 7): the merge's reads are then bank-conflict free)
       __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + ((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 4,
-                                       X3_LDS_PTR(lds + 3 * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
+                                       X3_LDS_PTR(lds + RING * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
     }
   };
   auto stats_merge = [&](float& mean, float& rstd) {   // Chan's update for 16 equal parts (as ff_ln_finish of the f32 family)
@@ -403,20 +437,50 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
           x0 = x3_fmul(x0, 0.015625f);
           x1 = x3_fmul(x1, 0.015625f);
         }
+#if defined(X3_EXP_NOSPLIT)      // probe: no split arithmetic at all (wrong numbers; the upper bound of what cheaper splitting can buy)
+        p1_[q] = __builtin_bit_cast(unsigned, x0);
+        r_[q][0] = x1; r_[q][1] = x0;
+        asm volatile("" : "+v"(p1_[q]), "+v"(r_[q][0]), "+v"(r_[q][1]));
+        return;
+#elif defined(X3_MIXSPLIT)
+        // x1 = fp16(x) (one packed conversion); the scaled inputs t = x 2^11 (exact); the second terms then are ONE mixed-precision
+        // fma each, fp16(fma(x1, -2^11, t)) = fp16((x - x1) 2^11) -- fma's argument is exact in fp32, so the bits are those of the
+        // five-instruction form (convert back, subtract, scale, convert) at five VALU per pair instead of eight
+        const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+        p1_[q] = __builtin_bit_cast(unsigned, h);
+        r_[q][0] = x3_fmul(x0, 2048.0f);
+        r_[q][1] = x3_fmul(x1, 2048.0f);
+        asm volatile("" : "+v"(p1_[q]), "+v"(r_[q][0]), "+v"(r_[q][1]));
+        return;
+#else
         const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
         p1_[q] = __builtin_bit_cast(unsigned, h);
         r_[q][0] = x3_fsub(x0, (float)h[0]);
         r_[q][1] = x3_fsub(x1, (float)h[1]);
         asm volatile("" : "+v"(p1_[q]), "+v"(r_[q][0]), "+v"(r_[q][1]));
         return;
+#endif
       }
       p1_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
       r_[q][0] = x3_fsub(x0, __builtin_bit_cast(float, p1_[q] << 16));
       r_[q][1] = x3_fsub(x1, __builtin_bit_cast(float, p1_[q] & 0xffff0000u));
       asm volatile("" : "+v"(p1_[q]), "+v"(r_[q][0]), "+v"(r_[q][1]));
     } else if (NT == 2) {   // second term, scaled by 2^11 (exact)
+#if defined(X3_EXP_NOSPLIT)
+      p2_[q] = __builtin_bit_cast(unsigned, r_[q][0]);
+      asm volatile("" : "+v"(p2_[q]));
+#elif defined(X3_MIXSPLIT)
+      unsigned d;
+      const float m2048 = -2048.0f;
+      asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+                   "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                   : "=&v"(d) : "v"(p1_[q]), "v"(m2048), "v"(r_[q][0]), "v"(r_[q][1]));
+      p2_[q] = d;
+      asm volatile("" : "+v"(p2_[q]));
+#else
       p2_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x3_fmul(r_[q][0], 2048.0f), x3_fmul(r_[q][1], 2048.0f)}, f16x2));
       asm volatile("" : "+v"(p2_[q]));
+#endif
     } else {
       p2_[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r_[q][0], r_[q][1]}, bf16x2));
       const float s0 = x3_fsub(r_[q][0], __builtin_bit_cast(float, p2_[q] << 16));
@@ -636,9 +700,11 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
     stats_fetch(2);
     mean_s = mean_c; rstd_s = rstd_c;
   }
-  issue(0); issue(1); issue(2);
+#pragma unroll
+  for (int r = 0; r < RING; ++r) issue(r);
   begin_segment(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70 | NP);   // vmcnt(NP): all but the youngest slice
+  static_assert((RING - 2) * NP <= 15, "vmcnt immediate");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | ((RING - 2) * NP));   // vmcnt: slices 0 and 1 have landed, the younger ones may be in flight
   __builtin_amdgcn_s_barrier();
   {
     ar[0] = x3_lds_read16(lds0 + fa_r0);
@@ -659,7 +725,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
   constexpr int SPG = (8 + (NMF - SP0) - 1) / (NMF - SP0);   // split steps per gap (1 with six products, 3 with three)
   constexpr int SPC = SP0 + (8 + SPG - 1) / SPG;  // gap behind which the split is complete
   constexpr int DM0 = NI == 4 ? NRD : NMF - NP;   // first DMA piece
-  int s0 = 0, s1 = 1;   // ring slots of slice s, s + 1  (slice s + 3 goes to slot s0)
+  int s0 = 0, s1 = 1;   // ring slots of slice s, s + 1  (slice s + RING goes to slot s0)
   const int total = 2 * (u1 - u0);
   for (int s = 0; s < total; s += 2) {
 #pragma unroll
@@ -672,13 +738,20 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
       // NMF MFMAs of slice s; in their gaps: the reads of slice s + 1 (one per gap), the split of its rows, the DMA of s + 3
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
+#if defined(X3_EXP_MFMA_ORDER)     // probe: the x1 y1 products between the two small ones (same-accumulator MFMAs four apart, not two)
+        const int t = NT == 2 ? (i / NI == 1 ? 2 : (i / NI == 2 ? 1 : 0)) : i / NI, ni = i % NI;
+#else
         const int t = i / NI, ni = i % NI;
+#endif
         if (NT == 3) {
           if (t < 5) accs[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
                                                                         __builtin_bit_cast(bf16x8, af[u][PA[t]]), accs[ni], 0, 0, 0);
           else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[u][PB[t]][ni]),
                                                                  __builtin_bit_cast(bf16x8, af[u][PA[t]]), acc[ni], 0, 0, 0);
         } else {
+#if defined(X3_EXP_NOMFMA)         // probe: the loop without its matrix-core work
+          if (g.M < 0)
+#endif
           if (t < 2) accs[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[u][PB[t]][ni]),
                                                                        __builtin_bit_cast(f16x8, af[u][PA[t]]), accs[ni], 0, 0, 0);
           else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[u][PB[t]][ni]),
@@ -703,7 +776,11 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
       }
       if (SPC >= NMF) split_collect(af[u ^ 1]);
       // slice s + 2 has landed (own pieces), every fragment of slice s + 1 is in registers
-      __builtin_amdgcn_s_waitcnt(0x0070 | NP);   // vmcnt(NP) lgkmcnt(0)
+#if defined(X3_EXP_NOVMWAIT)      // probe: the loop never waits for its DMA (reads whatever the LDS holds)
+      __builtin_amdgcn_s_waitcnt(0x0F70 & ~0x0F00);   // lgkmcnt(0) only
+#else
+      __builtin_amdgcn_s_waitcnt(0x0070 | ((RING - 2) * NP));   // vmcnt: everything but the youngest RING - 2 slices; lgkmcnt(0)
+#endif
 #pragma unroll
       for (int p = 0; p < NT; ++p)
 #pragma unroll
@@ -737,8 +814,13 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 3) ? 2 : 3) void gemm_x3
           stats_fetch(cp_p + 2);
         }
       }
+#if defined(X3_EXP_NOBARRIER)     // probe: no block barrier in the K loop (races: wrong numbers)
+#elif defined(X3_EXP_HALFBARRIER) // probe: a barrier every second slice only
+      if (u == 1) __builtin_amdgcn_s_barrier();
+#else
       __builtin_amdgcn_s_barrier();
-      { const int tmp = s0; s0 = s1; s1 = 3 - s0 - tmp; }   // (s0, s1, s2) -> (s1, s2, s0)
+#endif
+      s0 = s1; s1 = s1 + 1 == RING ? 0 : s1 + 1;
     }
   }
 }
@@ -760,6 +842,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
   constexpr int NPW = BN / 64;              // W pieces (16 rows x 64 B) per wave and slice
   constexpr int NP = NPA + NPW;             // DMA pieces per wave and slice
   constexpr int A_REG = BM * 64, SLOT = A_REG + BN * 64;
+  constexpr int RING = X3_RING_F32;
   constexpr int NMF = 8 * NI;               // MFMAs per wave and slice
   constexpr int NRD = 2 + 2 * NI;           // fragment reads per wave and slice
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -904,7 +987,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
   // ---- MODE 1: (mean, rstd) of this lane's row for the tile being computed and the next one ----
   float mean_c = 0.f, rstd_c = 1.f, mean_n = 0.f, rstd_n = 1.f;
   float mean_s = 0.f, rstd_s = 1.f;   // what the split in flight uses
-  const unsigned stat_lds = lds0 + 3 * SLOT + wave * 4096;
+  const unsigned stat_lds = lds0 + RING * SLOT + wave * 4096;
   auto stats_fetch = [&](int p) {     // DMA the segment statistics of segment p's rows (this wave's 32) into the wave's patch
     if (MODE != 1 || p >= nseg) return;
     int tile, j0, n, kind, m0, n0;
@@ -916,7 +999,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
       row = row < g.M ? row : g.M - 1;
       // (16-byte chunk c of patch row r sits at position c ^ ((r >> 1) & 7): the merge's reads are then bank-conflict free)
       __builtin_amdgcn_global_load_lds(g.ln_in + (size_t)row * 32 + ((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 4,
-                                       X3_LDS_PTR(lds + 3 * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
+                                       X3_LDS_PTR(lds + RING * SLOT + wave * 4096 + q * 1024), 16, 0, 0);
     }
   };
   auto stats_merge = [&](float& mean, float& rstd) {   // Chan's update for 16 equal parts (as ff_ln_finish of the f32 family)
@@ -1153,9 +1236,11 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
     stats_fetch(2);
     mean_s = mean_c; rstd_s = rstd_c;
   }
-  issue(0); issue(1); issue(2);
+#pragma unroll
+  for (int r = 0; r < RING; ++r) issue(r);
   begin_segment(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70 | NP);   // vmcnt(NP): all but the youngest slice
+  static_assert((RING - 2) * NP <= 15, "vmcnt immediate");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | ((RING - 2) * NP));   // vmcnt: slices 0 and 1 have landed
   __builtin_amdgcn_s_barrier();
   {
     af[0][0] = x3_lds_read16(lds0 + fa_r0);
@@ -1201,7 +1286,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
         __builtin_amdgcn_sched_barrier(0);
       }
       // slice s + 2 has landed (own pieces), every fragment of slice s + 1 is in registers
-      __builtin_amdgcn_s_waitcnt(0x0070 | NP);   // vmcnt(NP) lgkmcnt(0)
+      __builtin_amdgcn_s_waitcnt(0x0070 | ((RING - 2) * NP));   // vmcnt: everything but the youngest RING - 2 slices; lgkmcnt(0)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         asm volatile("" : "+v"(af[u ^ 1][j]));
@@ -1239,7 +1324,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
         }
       }
       __builtin_amdgcn_s_barrier();
-      { const int tmp = s0; s0 = s1; s1 = 3 - s0 - tmp; }   // (s0, s1, s2) -> (s1, s2, s0)
+      s0 = s1; s1 = s1 + 1 == RING ? 0 : s1 + 1;
     }
   }
 }
@@ -1281,7 +1366,10 @@ int g_x3_force_shape = 0;
 template <int BM, int MODE, int NT = 3>
 int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
   static std::atomic<bool> attr_set[16] = {};   // hipFuncSetAttribute is per device; host threads may race here (idempotent)
-  constexpr int bytes = 3 * (BM * 64 + NT * X3_BN * 32) + (MODE == 1 ? X3_STAT_BYTES : 0);
+#ifndef X3_EXP_LDS_PAD     // probe: extra dynamic LDS per block = fewer blocks per CU (occupancy experiments)
+#define X3_EXP_LDS_PAD 0
+#endif
+  constexpr int bytes = x3_ring<MODE, NT>() * (BM * 64 + NT * X3_BN * 32) + (MODE == 1 ? X3_STAT_BYTES : 0) + X3_EXP_LDS_PAD;
   int dev = 0;
   FF_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
@@ -1296,7 +1384,7 @@ int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
 template <int BM, int MODE>
 int dma_f32_launch_mode(const X3Args& g, int grid, hipStream_t st) {
   static std::atomic<bool> attr_set[16] = {};
-  constexpr int bytes = 3 * (BM * 64 + X3_BN * 64) + (MODE == 1 ? X3_STAT_BYTES : 0);
+  constexpr int bytes = X3_RING_F32 * (BM * 64 + X3_BN * 64) + (MODE == 1 ? X3_STAT_BYTES : 0);
   int dev = 0;
   FF_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
@@ -1323,7 +1411,7 @@ int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
   constexpr int BM = 64;
   const int cus = ff_num_cus();   // 256 on an MI355X in SPX mode; a partition (CPX / fewer CUs) gets its own launch shape
   // block slots per CU: registers / the statistics patch of the LayerNorm consumers decide
-  const int spc = f32 ? 3 : ((mode == 1 || mode == 3) ? 2 : 3);
+  const int spc = f32 ? 3 : (mode == 3 ? 2 : (mode == 1 ? (g.nt == 2 ? X3_LN_H_BLOCKS : 2) : 3));
   const int slots = cus * spc;
   g.tiles_n = ff_cdiv(N, X3_BN);
   g.tiles_m = ff_cdiv(M, BM);
