@@ -267,6 +267,9 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
     u1 = u0 + (g.base + mine) * g.gran;
   }
   if (u0 >= u1) return;
+#if defined(X3_EXP_STAGGER)         // probe: blocks start in three phases, X3_EXP_STAGGER x 0.85 us apart (de-phases the tile ends -- and with
+  for (int q = 0; q < (int)(blockIdx.x % 3) * X3_EXP_STAGGER; ++q) __builtin_amdgcn_s_sleep(32);   // them the chip-wide bursts of result stores)
+#endif
   const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
   const int ja = u0 - k0 * upt;
   const int jb = u1 - k1 * upt;
@@ -333,6 +336,9 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
     }
   };
   auto advance = [&]() {
+#if defined(X3_EXP_NOADVANCE)      // probe: the loader stays on its first slice (no pointer / segment bookkeeping per slice)
+    if (g.M > 0) return;
+#endif
     if (++ld_j == ld_end) {
       if (ld_p + 1 < nseg) {
         int tile, j0, n, kind;
@@ -757,9 +763,15 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
           else acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[u][PB[t]][ni]),
                                                                 __builtin_bit_cast(f16x8, af[u][PA[t]]), acc[ni], 0, 0, 0);
         }
+#if defined(X3_EXP_NOLDSREAD)       // probe: no fragment reads in the loop (both register sets keep the prologue's values)
+        if (g.M < 0) {
+#else
+        {
+#endif
         if (i == 0) ar[0] = x3_lds_read16(nb + fa_r0);
         else if (i == 1) ar[1] = x3_lds_read16(nb + fa_r1);
         else if (i < NRD) x3_read_w_i<NI>(wf[u ^ 1], nb + fw, i - 2);
+        }
         if (i == SP0) {
           if (SP0 == 5) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
           else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(ar[1])::"memory");
@@ -820,7 +832,9 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
 #else
       __builtin_amdgcn_s_barrier();
 #endif
+#if !defined(X3_EXP_FIXEDSLOT)      // probe: without the ring rotation (slot offsets become loop constants)
       s0 = s1; s1 = s1 + 1 == RING ? 0 : s1 + 1;
+#endif
     }
   }
 }
@@ -888,6 +902,9 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
     u1 = u0 + (g.base + mine) * g.gran;
   }
   if (u0 >= u1) return;
+#if defined(X3_EXP_STAGGER)         // probe: blocks start in three phases, X3_EXP_STAGGER x 0.85 us apart (de-phases the tile ends -- and with
+  for (int q = 0; q < (int)(blockIdx.x % 3) * X3_EXP_STAGGER; ++q) __builtin_amdgcn_s_sleep(32);   // them the chip-wide bursts of result stores)
+#endif
   const int k0 = u0 / upt, k1 = (u1 - 1) / upt;
   const int ja = u0 - k0 * upt;
   const int jb = u1 - k1 * upt;
