@@ -680,7 +680,14 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
       for (int q = 0; q < NQ; ++q)
         if (nb0 + (q >> 2) * 32 + (q & 3) * 8 + 3 < g.N) {
           const f32x4 v = {acc[q >> 2][4 * (q & 3)], acc[q >> 2][4 * (q & 3) + 1], acc[q >> 2][4 * (q & 3) + 2], acc[q >> 2][4 * (q & 3) + 3]};
+#if defined(X3_EXP_NOSTORE)        // probe: results are not stored (one store per lane and tile keeps the accumulators alive)
+          if (q == 0)
+#endif
+#if defined(X3_EXP_NTSTORE)        // probe: non-temporal result stores
+          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(cp + (q >> 2) * 32 + (q & 3) * 8), "v"(v) : "memory");
+#else
           asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(cp + (q >> 2) * 32 + (q & 3) * 8), "v"(v) : "memory");
+#endif
         }
     }
 #pragma unroll
@@ -956,6 +963,9 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
   };
   auto issue_piece = [&](int k, int slot) {   // piece k of the slice the loader stands on -> ring slot `slot`
     unsigned char* base = lds + slot * SLOT;
+#if defined(X3_EXP_NODMA)          // probe (see gemm_x3_kernel)
+    if (g.M > 0) return;
+#endif
     if (k < NPA) {
       __builtin_amdgcn_global_load_lds(a_base + a_off[k < NPA ? k : 0], X3_LDS_PTR(base + (wave * NPA + k) * 1024), 16, 0, 0);
     } else {
@@ -1227,7 +1237,14 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
       for (int q = 0; q < NQ; ++q)
         if (nb0 + (q >> 2) * 32 + (q & 3) * 8 + 3 < g.N) {
           const f32x4 v = {acc[q >> 2][4 * (q & 3)], acc[q >> 2][4 * (q & 3) + 1], acc[q >> 2][4 * (q & 3) + 2], acc[q >> 2][4 * (q & 3) + 3]};
+#if defined(X3_EXP_NOSTORE)        // probe: results are not stored (one store per lane and tile keeps the accumulators alive)
+          if (q == 0)
+#endif
+#if defined(X3_EXP_NTSTORE)        // probe: non-temporal result stores
+          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(cp + (q >> 2) * 32 + (q & 3) * 8), "v"(v) : "memory");
+#else
           asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(cp + (q >> 2) * 32 + (q & 3) * 8), "v"(v) : "memory");
+#endif
         }
     }
 #pragma unroll
@@ -1289,6 +1306,9 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
 #pragma unroll
       for (int i = 0; i < NMF; ++i) {
         const int e = i / NI, ni = i % NI;
+#if defined(X3_EXP_NOMFMA)
+        if (g.M < 0)
+#endif
         acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, wf[u][e >> 2][ni])[e & 3],
                                                        __builtin_bit_cast(f32x4, af[u][e >> 2])[e & 3], acc[ni], 0, 0, 0);
         if (i == 0) af[u ^ 1][0] = x3_lds_read16(nb + fa_r0);
