@@ -143,6 +143,58 @@ def test_attention_general_matches_fp64(hip_lib, ops, G, H, hd, nq, nk, form):
     assert rel_err(out, ref) < 5e-6
 
 
+def test_attention_general_random_shapes_and_mask_mixes(hip_lib, ops):
+    """40 seeded random problems (head widths 1..160 incl. odd ones, 1..6 heads, 1..3 groups, up to 90 queries x 400 keys, random mixes
+    of kv_len / key mask / causal / additive / boolean masks, group-major AND position-major row addressing, padded leading
+    dimensions) against the explicit fp64 softmax."""
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        G, H = int(rng.integers(1, 4)), int(rng.integers(1, 7))
+        hd = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 24, 32, 40, 64, 72, 96, 128, 160]))
+        nq, nk = int(rng.integers(1, 91)), int(rng.integers(1, 401))
+        E, pad = H * hd, 4 * int(rng.integers(0, 3))
+        group_major = bool(rng.integers(0, 2))
+        q = rnd(nq * G, E + pad, seed=100 + case)
+        k, v = rnd(nk * G, E + pad, seed=200 + case), rnd(nk * G, E + pad, seed=300 + case)
+        use = rng.integers(0, 2, size=5).astype(bool)   # kv_len, key mask, causal, bias, bool mask
+        kv_len = kpm = bias = amask = None
+        causal = bool(use[2]) and nq == nk
+        if use[0]:
+            kv_len = torch.from_numpy(rng.integers(max(1, nk // 2), nk + 1, size=G).astype(np.int32))
+        if use[1]:
+            kpm = torch.from_numpy(rng.random((G, nk)) > 0.7)
+            kpm[:, 0] = False
+        if use[3]:
+            shape = (G * H, nq, nk) if rng.integers(0, 2) else (nq, nk)
+            bias = torch.from_numpy(rng.normal(size=shape).astype(np.float32) * 2)
+        if use[4]:
+            shape = tuple(bias.shape) if bias is not None else ((G * H, nq, nk) if rng.integers(0, 2) else (nq, nk))
+            amask = torch.from_numpy(rng.random(shape) > 0.6)
+            amask[..., 0] = False
+        if group_major:      # row = g * n + i
+            addr = dict(q_group_stride=nq, q_inner=nq, q_outer_stride=0, k_group_stride=nk, k_stride=1)
+            qd = q[:, :E].double().view(G, nq, H, hd).permute(0, 2, 1, 3)
+            kd = k[:, :E].double().view(G, nk, H, hd).permute(0, 2, 1, 3)
+            vd = v[:, :E].double().view(G, nk, H, hd).permute(0, 2, 1, 3)
+        else:                # row = i * G + g
+            addr = dict(q_group_stride=1, q_inner=1, q_outer_stride=G, k_group_stride=1, k_stride=G)
+            qd = q[:, :E].double().view(nq, G, H, hd).permute(1, 2, 0, 3)
+            kd = k[:, :E].double().view(nk, G, H, hd).permute(1, 2, 0, 3)
+            vd = v[:, :E].double().view(nk, G, H, hd).permute(1, 2, 0, 3)
+        dq, dk, dv = q.cuda(), k.cuda(), v.cuda()
+        out = ops.attention_general(dq[:, :E], dk[:, :E], dv[:, :E], G, H, hd, nq, nk, kv_len=None if kv_len is None else kv_len.cuda(),
+                                    key_mask=None if kpm is None else kpm.to(torch.uint8).cuda(), causal=causal,
+                                    attn_bias=None if bias is None else bias.cuda(), attn_mask=None if amask is None else amask.cuda(), **addr)
+        full = kpm.clone() if kpm is not None else torch.zeros(G, nk, dtype=torch.bool)
+        if kv_len is not None:
+            full |= torch.arange(nk)[None, :] >= kv_len[:, None].long()
+        ref = _ref_attention_general(qd, kd, vd, hd, full, causal, bias, amask)
+        ref = ref.permute(0, 2, 1, 3).reshape(G * nq, E) if group_major else ref.permute(2, 0, 1, 3).reshape(nq * G, E)
+        ok = ~torch.isnan(ref).any(dim=1)          # (a random mix may remove every key of a query: NaN on both sides)
+        assert torch.isnan(out.cpu()[~ok]).any(dim=1).all(), case
+        assert ok.sum() > 0 and rel_err(out[ok.cuda()], ref[ok]) < 1e-5, (case, G, H, hd, nq, nk, use.tolist())
+
+
 def test_attention_general_query_without_keys_is_nan_like_torch(hip_lib, ops):
     """torch's softmax over a row of -inf is NaN and so is that query's output (nn.MultiheadAttention with a boolean mask that
     removes every key); the general kernel keeps that, other queries of the launch are unaffected."""
