@@ -6,6 +6,8 @@ reference; `forward_eval` runs on the native engine (ff_encode + ff_decode, vari
 start token SOS, at most label_seq_length-1 steps, stop when the cumulative EOS count equals the
 batch size (reference model.py:191,207-210), zero padding afterwards.
 """
+import torch
+
 from ..hip import lib as _L
 from .common import SurfaceFormerBase
 
@@ -39,6 +41,12 @@ class SurfaceFormer(SurfaceFormerBase):
         Adds predict N x T (int64), embedding N x S x E, pointer N x t_last x E."""
         label = inputs["label"]
         T = self.num_labels
+        if inputs["input"].size(0) == 0:     # an empty batch: the reference's loop stops after its first step (0 EOS == batch size 0, model.py:207)
+            dev, S = inputs["input"].device, inputs["input"].size(1) + self.num_token
+            inputs["embedding"] = torch.zeros((0, S, self.num_model), device=dev)
+            inputs["pointer"] = torch.zeros((0, 1, self.num_model), device=dev)
+            inputs["predict"] = torch.zeros((0, T), dtype=torch.long, device=dev)
+            return inputs
         if not self.engine_supported():      # post-norm / gelu constructor arguments: the sub-module loop (models/common.py)
             return self._forward_eval_modules(inputs, parallel=False)
         if label.size(1) < T - 1:

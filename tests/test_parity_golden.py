@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import batch_to, build_model, case_weights_and_batch, golden_names, load_golden
+from conftest import batch_to, build_model, case_weights_and_batch, golden_names, load_golden, token_ns
 
 pytestmark = pytest.mark.gpu
 
@@ -841,6 +841,45 @@ def test_c_callback_keeps_its_cadence_on_the_drain_path(hip_lib):
                        capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here),
                        env=dict(os.environ, FF_PINNED_COUNTERS="8"))
     assert p.returncode == 0 and " passed" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+
+
+def test_degenerate_inputs_behave_like_the_reference(hip_lib):
+    """Empty and zero-edge inputs (checked against the imported reference in the build container, tools/edge_probe.py): a wireframe
+    WITHOUT edges inside a batch decodes like the oracle (its anchors are all padding anchors, model_para.py:204-205); an empty
+    batch of the single-sequence model returns empty tensors (the reference's loop stops after its first step: 0 EOS == batch
+    size 0, model.py:207); an empty batch / a batch whose widest wireframe has no edges raises in the parallel model, as the
+    reference does (`max()` of an empty list, model_para.py:200; a reshape to [-1, 0, T], model_para.py:238)."""
+    from faceformer_amd.models import SurfaceFormer, SurfaceFormer_Parallel
+    from oracle import refpath
+    torch.manual_seed(0)
+    kw = dict(num_model=128, num_head=2, num_feedforward=256, num_encoder_layers=1, num_decoder_layers=1, num_lines=8, token=token_ns())
+    m = SurfaceFormer_Parallel(max_face_length=5, **kw).eval()
+    s = SurfaceFormer(label_seq_length=6, **kw).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m, s = m.cuda(), s.cuda()
+
+    def batch(num_input, L=8, T=5):
+        N = len(num_input)
+        g = torch.Generator().manual_seed(N + 17)
+        mask = torch.arange(L)[None, :] >= torch.tensor(num_input, dtype=torch.long)[:, None] if N else torch.zeros(0, L, dtype=torch.bool)
+        return dict(input=torch.randn(N, L, 50, 2, generator=g), input_mask=mask, label=torch.zeros(N, L, T, dtype=torch.long),
+                    num_input=list(num_input))
+
+    for ni in ([3, 0], [0, 5, 0], [8, 1]):
+        b = batch(ni)
+        with torch.no_grad():
+            got = m(batch_to(b, "cuda"))["predict"].cpu().numpy()
+        ref = refpath.parallel_forward_eval(sd, {k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in b.items()}, num_head=2)
+        assert np.array_equal(got, ref["predict"].numpy()), ni
+    with torch.no_grad():
+        out = s(dict(input=torch.randn(0, 8, 50, 2).cuda(), input_mask=torch.zeros(0, 8, dtype=torch.bool).cuda(),
+                     label=torch.zeros(0, 6, dtype=torch.long).cuda()))
+    assert tuple(out["embedding"].shape) == (0, 12, 128) and tuple(out["pointer"].shape) == (0, 1, 128)
+    assert tuple(out["predict"].shape) == (0, 6) and out["predict"].dtype == torch.int64
+    with pytest.raises(ValueError):
+        m(batch_to(batch([]), "cuda"))
+    with pytest.raises(Exception):
+        m(batch_to(batch([0]), "cuda"))
 
 
 @pytest.mark.parametrize("name", ["par_small_ragged", "par_small_earlybreak", "par_small_break1", "seq_small_gain4"])
