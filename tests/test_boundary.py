@@ -109,6 +109,38 @@ def test_import_surface_of_reference_modules():
         tr._get_activation_fn("swish")
 
 
+def test_attn_mask_forms_are_validated_on_the_host():
+    """torch's `attn_mask` forms (2-D [L, S] / 3-D [N*H, L, S], boolean or floating point) are sorted into (causal, additive bias,
+    boolean mask) before any HIP call; the 'subsequent' triangle (reference model.py:71-73) is recognised as the causal rule of the
+    MFMA kernels; wrong shapes / ranks / dtypes are ValueError / TypeError like torch's own checks."""
+    from faceformer_amd import transformer as tr
+    L, S, BH = 5, 7, 6
+    assert tr._attn_mask_forms(None, "m", L, S, BH) == (False, None, None)
+    tri = torch.triu(torch.ones(L, L, dtype=torch.bool), diagonal=1)
+    assert tr._attn_mask_forms(tri, "m", L, L, BH) == (True, None, None)
+    assert tr._attn_mask_forms(tri.to(torch.uint8), "m", L, L, BH)[0] is True
+    causal, bias, mask = tr._attn_mask_forms(~tri, "m", L, L, BH)
+    assert causal is False and bias is None and mask.dtype == torch.uint8 and tuple(mask.shape) == (L, L)
+    causal, bias, mask = tr._attn_mask_forms(torch.zeros(BH, L, S, dtype=torch.float64), "m", L, S, BH)
+    assert causal is False and mask is None and bias.dtype == torch.float32 and tuple(bias.shape) == (BH, L, S)
+    with pytest.raises(ValueError):
+        tr._attn_mask_forms(torch.zeros(L, S + 1), "m", L, S, BH)
+    with pytest.raises(ValueError):
+        tr._attn_mask_forms(torch.zeros(BH + 1, L, S), "m", L, S, BH)
+    with pytest.raises(ValueError):
+        tr._attn_mask_forms(torch.zeros(1, BH, L, S), "m", L, S, BH)
+    with pytest.raises(TypeError):
+        tr._attn_mask_forms(torch.zeros(L, S, dtype=torch.int32), "m", L, S, BH)
+    with pytest.raises(TypeError):
+        tr._mask_u8(torch.zeros(2, S, dtype=torch.int64), "key_padding_mask", (2, S))
+    assert tr._mask_u8(torch.zeros(2, S), "key_padding_mask", (2, S)).dtype == torch.float32     # additive padding mask
+    mha = tr.MultiheadAttention(96, 2)                                                           # 48-wide heads: constructible, CPU run refused
+    assert mha.head_dim == 48
+    from faceformer_amd.hip.lib import HipExtensionError
+    with pytest.raises(HipExtensionError):
+        mha.eval()(torch.zeros(3, 1, 96), torch.zeros(4, 1, 96), torch.zeros(4, 1, 96))
+
+
 def test_alias_package_exposes_reference_names():
     import faceformer
     from faceformer.models import SurfaceFormer, SurfaceFormer_Parallel  # noqa: F401
