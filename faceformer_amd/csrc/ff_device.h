@@ -65,7 +65,7 @@ struct GemmArgs {
 
 // the LDS-DMA f32 projection kernel (ff_gemm_x3.hip): eligibility of a launch and the launch itself
 bool ff_gemm_dma_f32_ok(const GemmArgs& a, int batch);
-int ff_gemm_dma_f32(const GemmArgs& a, hipStream_t st);
+int ff_gemm_dma_f32(const GemmArgs& a, hipStream_t st, int bn = 128);   // bn: tile columns, 128 or 64
 
 __device__ __forceinline__ float ff_sum8(float v) {  // sum over the aligned group of 8 lanes, result on all of them
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

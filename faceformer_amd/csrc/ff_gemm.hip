@@ -1559,6 +1559,10 @@ int gemm_dispatch(GemmArgs g, int batch, int tile, hipStream_t st) {
     FF_CHECK_ARG(dma_ok, "ff_gemm_f32: tile 11 needs K %% 32 == 0, K >= 64, N %% 4 == 0, leading dimensions %% 4, 16-byte aligned operands, batch 1");
     return ff_gemm_dma_f32(g, st);
   }
+  if (tile == 12) {   // the same kernel with 64 x 64 tiles (round 6)
+    FF_CHECK_ARG(dma_ok && (!g.A2 || (g.n_split % 64) == 0), "ff_gemm_f32: tile 12 needs what tile 11 needs");
+    return ff_gemm_dma_f32(g, st, 64);
+  }
   const long dmr = dma_min_rows(), dmr512 = dma_min_rows_n512(), dmrw = dma_min_rows_wide();
   const long dma_from = N <= 512 ? (dmr512 > dmr ? dmr512 : dmr) : (N >= 1536 && dmrw < dmr ? dmrw : dmr);
   if (tile == 7 && dma_ok && (long)M >= dma_from) return ff_gemm_dma_f32(g, st);
@@ -1609,7 +1613,7 @@ extern "C" int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int
                "ff_gemm_f32: A/A2/W must be 16-byte aligned");
   FF_CHECK_ARG(!residual || ldr >= N, "ff_gemm_f32: bad ldr");
   FF_CHECK_ARG(act == 0 || act == 1, "ff_gemm_f32: act must be 0 or 1");
-  FF_CHECK_ARG(tile >= 0 && tile <= 11, "ff_gemm_f32: tile must be 0..11");
+  FF_CHECK_ARG(tile >= 0 && tile <= 12, "ff_gemm_f32: tile must be 0..12");
   FF_CHECK_ARG(batch > 0 && batch <= 65535 && (stride_a & 3) == 0 && (stride_w & 3) == 0,
                "ff_gemm_f32: bad batch arguments");
   FF_CHECK_ARG(batch == 1 || !residual, "ff_gemm_f32: residual is not supported with batch > 1");
@@ -1630,7 +1634,7 @@ extern "C" int ff_gemm_f32_ln(const ff_gemm_ln_desc* d, ff_stream_t stream) {
   FF_CHECK_ARG(ff_aligned16(d->A) && ff_aligned16(d->W), "ff_gemm_f32_ln: A/W must be 16-byte aligned");
   FF_CHECK_ARG(!d->residual || d->ldr >= N, "ff_gemm_f32_ln: bad ldr");
   FF_CHECK_ARG(d->act == 0 || d->act == 1, "ff_gemm_f32_ln: act must be 0 or 1");
-  FF_CHECK_ARG(d->tile == 0 || d->tile == 3 || d->tile == 6 || d->tile == 7 || d->tile == 8 || d->tile == 11,
+  FF_CHECK_ARG(d->tile == 0 || d->tile == 3 || d->tile == 6 || d->tile == 7 || d->tile == 8 || d->tile == 11 || d->tile == 12,
                "ff_gemm_f32_ln: tile must be 0, 3, 6, 7, 8 or 11 (the kernels that carry the LayerNorm fusion)");
   FF_CHECK_ARG(!(d->ln_stats_in && d->ln_stats_out), "ff_gemm_f32_ln: statistics in AND out in one launch are not supported");
   FF_CHECK_ARG(!d->ln_stats_in || (d->ln_nseg > 0 && d->ln_nseg * 32 == K && d->ln_eps >= 0.f),

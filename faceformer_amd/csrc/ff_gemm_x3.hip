@@ -854,9 +854,11 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
 // of LDS; three blocks per CU (at the 128 registers of four, the epilogue's operands push loop addresses into scratch).  W is the nn.Linear weight itself ([N, K] fp32 rows, ld = ldw): no planes.
 // Operand k order inside a slice: MFMA e of 8 takes k = e from the lanes 0..31 and k = 8 + e from the lanes 32..63 of BOTH
 // operands (a lane holds floats 8 half .. 8 half + 7 of its row).
-template <int BM, int MODE>
+// BN: 128 (2 x 2 waves of 32 x 64), or -- round 6 -- 64 (2 x 2 waves of 32 x 32: twice the tiles for the 512-column projections of
+// the middle steps; 8 MFMAs, 4 fragment reads and 2 DMA pieces per wave and slice, 24 KB of LDS).
+template <int BM, int MODE, int BN = X3_BN>
 __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
-  constexpr int BN = X3_BN, BK = X3_BK;
+  constexpr int BK = X3_BK;
   constexpr int WN = 128 / BM;              // waves along N: 1 or 2
   constexpr int NI = BN / WN / 32;          // 32-column accumulators per wave: 4 or 2
   constexpr int NPA = BM / 64;              // A pieces (16 rows x 64 B) per wave and slice
@@ -1118,7 +1120,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
           __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         const f32x4* rp = reinterpret_cast<const f32x4*>(g.ws + (size_t)c * (BM * BN)) + tid;
-        constexpr int TQ = 8;   // 8 x 16 bytes in flight per lane and round trip (all 16 of a 128-row tile would spill)
+        constexpr int TQ = NQ < 8 ? NQ : 8;   // 8 x 16 bytes in flight per lane and round trip (all 16 of a 128-row tile would spill)
 #pragma unroll
         for (int h = 0; h < NQ / TQ; ++h) {
           f32x4 t[TQ];
@@ -1172,7 +1174,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
     }
     // a few 32-column groups at a time: with all of a 128-column row's operands in flight at once the register allocator
     // spills loop-invariant addresses INTO the K loop
-    constexpr int GQ = (NI == 4 || MODE == 3) ? 4 : 8;
+    constexpr int GQ = (NI == 4 || MODE == 3) ? 4 : (NQ < 8 ? NQ : 8);
 #pragma unroll
     for (int h = 0; h < NQ / GQ; ++h) {
       f32x4 xv[GQ], bv[GQ], cv[GQ];
@@ -1418,18 +1420,18 @@ int x3_launch_mode(const X3Args& g, int grid, hipStream_t st) {
   FF_CHECK_LAUNCH();
   return FF_OK;
 }
-template <int BM, int MODE>
+template <int BM, int MODE, int BN = X3_BN>
 int dma_f32_launch_mode(const X3Args& g, int grid, hipStream_t st) {
   static std::atomic<bool> attr_set[16] = {};
-  constexpr int bytes = X3_RING_F32 * (BM * 64 + X3_BN * 64) + (MODE == 1 ? X3_STAT_BYTES : 0);
+  constexpr int bytes = X3_RING_F32 * (BM * 64 + BN * 64) + (MODE == 1 ? X3_STAT_BYTES : 0);
   int dev = 0;
   FF_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_f32_kernel<BM, MODE>),
+    FF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_f32_kernel<BM, MODE, BN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((gemm_dma_f32_kernel<BM, MODE>), dim3(grid), dim3(256), bytes, st, g);
+  hipLaunchKernelGGL((gemm_dma_f32_kernel<BM, MODE, BN>), dim3(grid), dim3(256), bytes, st, g);
   FF_CHECK_LAUNCH();
   return FF_OK;
 }
@@ -1443,14 +1445,15 @@ int dma_f32_launch_mode(const X3Args& g, int grid, hipStream_t st) {
 // and the register allocator then spills INTO the K loop (a spill of a fragment register that an asynchronous ds_read has
 // not filled yet stores garbage, and every reload costs a full vmcnt drain); where it compiled cleanly it was within +-7 %
 // of the 64-row tile.
-int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
+int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false, int bn = X3_BN) {
   const int M = g.M, N = g.N, K = g.K;
   constexpr int BM = 64;
   const int cus = ff_num_cus();   // 256 on an MI355X in SPX mode; a partition (CPX / fewer CUs) gets its own launch shape
   // block slots per CU: registers / the statistics patch of the LayerNorm consumers decide
-  const int spc = f32 ? 3 : (mode == 3 ? 2 : (mode == 1 ? (g.nt == 2 ? X3_LN_H_BLOCKS : 2) : 3));
+  // (the 64-column f32 tile needs 109-111 registers without the LayerNorm consumer's state: four blocks fit a CU)
+  const int spc = f32 ? ((bn == 64 && mode != 1) ? 4 : 3) : (mode == 3 ? 2 : (mode == 1 ? (g.nt == 2 ? X3_LN_H_BLOCKS : 2) : 3));
   const int slots = cus * spc;
-  g.tiles_n = ff_cdiv(N, X3_BN);
+  g.tiles_n = ff_cdiv(N, bn);
   g.tiles_m = ff_cdiv(M, BM);
   g.upt = K / 32;
   const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -1485,6 +1488,11 @@ int x3_launch(X3Args g, int mode, hipStream_t st, bool f32 = false) {
     g.rem = (int)(units % grid);
   }
   FF_RETURN_IF(x3_acquire(st, &g));
+  if (f32 && bn == 64) {
+    if (mode == 1) return dma_f32_launch_mode<BM, 1, 64>(g, (int)grid, st);
+    if (mode == 2) return dma_f32_launch_mode<BM, 2, 64>(g, (int)grid, st);
+    return dma_f32_launch_mode<BM, 0, 64>(g, (int)grid, st);
+  }
   if (f32) {   // (the caller opened the f32 family's profiling scope)
     if (mode == 1) return dma_f32_launch_mode<BM, 1>(g, (int)grid, st);
     if (mode == 2) return dma_f32_launch_mode<BM, 2>(g, (int)grid, st);
@@ -1534,7 +1542,7 @@ bool ff_gemm_dma_f32_ok(const GemmArgs& a, int batch) {
   if (a.ln_out && (a.N & 31)) return false;
   return true;
 }
-int ff_gemm_dma_f32(const GemmArgs& a, hipStream_t st) {
+int ff_gemm_dma_f32(const GemmArgs& a, hipStream_t st, int bn) {
   X3Args g;
   memset(&g, 0, sizeof(g));
   g.A = a.A; g.A2 = a.A2; g.lda = a.lda;
@@ -1545,7 +1553,7 @@ int ff_gemm_dma_f32(const GemmArgs& a, hipStream_t st) {
   g.ln_in = a.ln_in; g.ln_eps = a.ln_eps;
   g.rowtab = a.rowtab; g.ld_rowtab = a.ld_rowtab; g.rowtab_div = a.rowtab_div > 0 ? a.rowtab_div : 1; g.rowtab_cols = a.rowtab_cols;
   g.ln_out = a.ln_out;
-  return x3_launch(g, a.ln_in ? 1 : (a.ln_out ? 2 : 0), st, true);
+  return x3_launch(g, a.ln_in ? 1 : (a.ln_out ? 2 : 0), st, true, bn == 64 ? 64 : X3_BN);
 }
 
 extern "C" size_t ff_split_weight_bytes(int N, int K) { return (size_t)3 * N * K * sizeof(unsigned short); }

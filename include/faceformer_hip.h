@@ -106,7 +106,8 @@ int ff_gelu(float* x, int ldx, int rows, int E, ff_stream_t stream);
  * least 4096 rows whose tile count fills the resident block slots evenly), 10 = pipelined 128x128 with
  * 16-wide slices (measurement only), 11 = the LDS-DMA kernel (both operands by global_load_lds, transposed accumulators,
  * 64 x 128 tiles at three blocks per CU, whole tiles + remaining tiles cut into K pieces; K % 32 == 0, K >= 64, N % 4 == 0,
- * leading dimensions % 4, 16-byte aligned operands; 7 hands it the launches of at least FF_DMA_MIN_ROWS rows).
+ * leading dimensions % 4, 16-byte aligned operands; 7 hands it the launches of at least FF_DMA_MIN_ROWS rows), 12 = the same
+ * kernel with 64 x 64 tiles (round 6; up to four blocks per CU).
  * Kernels 6/7 keep an internal 8 MB workspace per (device, stream), allocated at the first launch on
  * that stream.
  * ------------------------------------------------------------------------------------------- */
@@ -139,7 +140,7 @@ int ff_gemm_f32_batched(const float* A, int lda, const float* A2, int n_split,
  *   row_table    : optional [*, ld_row_table] table added to columns < row_cols, row m taking line m / row_div:
  *                  (LN(x) + pos_j) W^T = LN(x) W^T + (pos W^T)_j for the position-major rows of the decoder
  *                  (j = m / sequences).  Needs ln_stats_in and no residual.
- * tile: 0 (automatic), 3, 6, 7 or 8; K % 64 == 0 and K >= 128 for the fused forms, K <= 512 with ln_stats_in. */
+ * tile: 0 (automatic), 3, 6, 7, 8, 11 or 12; K % 64 == 0 and K >= 128 for the fused forms, K <= 512 with ln_stats_in. */
 typedef struct ff_gemm_ln_desc {
   const float* A; int lda;
   const float* W; int ldw;

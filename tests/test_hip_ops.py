@@ -261,37 +261,39 @@ def test_gemm_bias_act_residual(ops, M, N, K, tile):
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1, 512, 512), (77, 1536, 512), (333, 512, 1024), (4100, 1024, 512),
                                    (64, 260, 512), (130, 96, 64), (7680, 512, 512), (8448, 1536, 512), (9216, 512, 1024),
                                    (6400, 512, 512), (6400, 1536, 512), (6656, 512, 1024)])   # K-pieces beyond one per CU
-def test_gemm_dma_kernel(ops, M, N, K):
-    """Tile 11: the LDS-DMA kernel of the f32 family (both operands by DMA, transposed accumulators, whole tiles + the hybrid
-    remainder split): bias, ReLU, aliased residual, ragged edges in M and N, an output wider than N, determinism."""
+@pytest.mark.parametrize("dma_tile", [11, 12])
+def test_gemm_dma_kernel(ops, M, N, K, dma_tile):
+    """Tile 11 / 12: the LDS-DMA kernel of the f32 family with 64 x 128 / 64 x 64 tiles (both operands by DMA, transposed accumulators,
+    whole tiles + the hybrid remainder split): bias, ReLU, aliased residual, ragged edges in M and N, an output wider than N, determinism."""
     a, w, bias, res = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.1), rnd(N, seed=23), rnd(M, N, seed=24)
     ref0 = a.double() @ w.double().t() + bias.double()
-    out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), tile=11)
+    out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), tile=dma_tile)
     e11 = rel_err(out, ref0)
     assert e11 < 3e-6 and e11 < 2.0 * rel_err(ops.linear(a.cuda(), w.cuda(), bias.cuda(), tile=3), ref0) + 1e-7
     x = res.cuda()
-    ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=x, out=x, tile=11)
+    ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=x, out=x, tile=dma_tile)
     assert rel_err(x, torch.relu(ref0) + res.double()) < 3e-6
     y = res.cuda()
-    ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=y, out=y, tile=11)
+    ops.linear(a.cuda(), w.cuda(), bias.cuda(), act=1, residual=y, out=y, tile=dma_tile)
     assert torch.equal(x, y)
     wide = torch.full((M, N + 8), 7.0, device="cuda")
-    ops.linear(a.cuda(), w.cuda(), None, out=wide[:, :N], tile=11)
+    ops.linear(a.cuda(), w.cuda(), None, out=wide[:, :N], tile=dma_tile)
     assert torch.equal(wide[:, N:], torch.full((M, 8), 7.0, device="cuda"))
     assert rel_err(wide[:, :N], a.double() @ w.double().t()) < 3e-6
 
 
-def test_gemm_dma_kernel_split_a_and_identity(ops):
+@pytest.mark.parametrize("dma_tile", [11, 12])
+def test_gemm_dma_kernel_split_a_and_identity(ops, dma_tile):
     E, M = 512, 5120
     yq, y, w, b = rnd(M, E, seed=1), rnd(M, E, seed=2), rnd(3 * E, E, seed=3, scale=0.05), rnd(3 * E, seed=4)
-    out = ops.linear(yq.cuda(), w.cuda(), b.cuda(), x2=y.cuda(), n_split=2 * E, tile=11)
+    out = ops.linear(yq.cuda(), w.cuda(), b.cuda(), x2=y.cuda(), n_split=2 * E, tile=dma_tile)
     ref = torch.cat([yq.double() @ w[: 2 * E].double().t(), y.double() @ w[2 * E:].double().t()], 1) + b.double()
     assert rel_err(out, ref) < 3e-6
     eye, wi = torch.eye(64), rnd(96, 64, seed=9)
-    assert torch.equal(ops.linear(eye.cuda(), wi.cuda(), None, tile=11).cpu(), wi.t().contiguous())
+    assert torch.equal(ops.linear(eye.cuda(), wi.cuda(), None, tile=dma_tile).cpu(), wi.t().contiguous())
     from faceformer_amd.hip import lib as L
     with pytest.raises(L.HipExtensionError):      # K = 100 is not a multiple of 32: not this kernel's
-        ops.linear(rnd(64, 100).cuda(), rnd(32, 100).cuda(), None, tile=11)
+        ops.linear(rnd(64, 100).cuda(), rnd(32, 100).cuda(), None, tile=dma_tile)
 
 
 def test_gemm_identity_layout(ops):
@@ -783,7 +785,7 @@ def _seg_stats(x64):
     return torch.stack([mean, m2], dim=2)
 
 
-@pytest.mark.parametrize("tile", [0, 3, 6, 8, 11])
+@pytest.mark.parametrize("tile", [0, 3, 6, 8, 11, 12])
 @pytest.mark.parametrize("M,N,K", [(37, 512, 512), (300, 512, 1024), (1300, 512, 512), (5000, 512, 512), (640, 128, 256),
                                    (2304, 512, 512), (4864, 512, 1024), (6400, 512, 512)])   # (hybrid launches, round 5)
 def test_gemm_emits_layernorm_segment_statistics(hip_lib, ops, M, N, K, tile):
@@ -804,7 +806,7 @@ def test_gemm_emits_layernorm_segment_statistics(hip_lib, ops, M, N, K, tile):
     assert ((stats[..., 1].double() - want[..., 1]).abs() / want[..., 1].clamp_min(1e-6)).max() < 1e-5
 
 
-@pytest.mark.parametrize("tile", [0, 3, 6, 8, 11])
+@pytest.mark.parametrize("tile", [0, 3, 6, 8, 11, 12])
 @pytest.mark.parametrize("M,N,K,div", [(37, 1536, 512, 5), (300, 512, 512, 7), (1300, 1536, 512, 64), (5000, 1024, 512, 256),
                                        (256, 512, 128, 16), (9216, 1536, 512, 256),
                                        # round 5, the hybrid launch of the 64x64 family with this consumer form: unit ranges of
@@ -817,7 +819,7 @@ def test_gemm_consumes_layernorm_statistics_with_folded_weights(hip_lib, ops, M,
     weight / bias and the pos W^T table -- against the unfused arithmetic in float64."""
     if tile == 8 and M > 1024:
         pytest.skip("small-M kernel")
-    if tile == 11 and K != 512:
+    if tile in (11, 12) and K != 512:
         pytest.skip("the LDS-DMA kernel's normalising form is built for K = 512")
     g = torch.Generator().manual_seed(M * 3 + N + K)
     x = (1.5 + 2.0 * torch.randn(M, K, generator=g)) * (1.0 + torch.rand(M, 1, generator=g))   # row-dependent scale / mean

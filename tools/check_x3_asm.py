@@ -19,7 +19,7 @@ def main():
                         os.path.join(ROOT, "faceformer_amd", "csrc", "ff_gemm_x3.hip")], check=True, stderr=subprocess.DEVNULL)
         s = open(out).read()
     bad = 0
-    for n in re.findall(r"^(_ZN12_GLOBAL__N_1\d+gemm_(?:x3|dma_f32)_kernelILi\d+ELi\d(?:ELi\d)?EEEvNS_6X3ArgsE):", s, re.M):
+    for n in re.findall(r"^(_ZN12_GLOBAL__N_1\d+gemm_(?:x3|dma_f32)_kernelILi\d+ELi\d(?:ELi\d+)?EEEvNS_6X3ArgsE):", s, re.M):
         a = s.index("\n" + n + ":")
         b = s.index("s_endpgm", a)
         body = s[a:b].split("\n")
@@ -36,9 +36,9 @@ def main():
         desc = s[s.index(".amdhsa_kernel " + n):]
         regs = re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1)
         scratch = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1)
-        tag = re.search(r"ILi(\d+)ELi(\d)E(?:Li(\d)E)?", n)
+        tag = re.search(r"ILi(\d+)ELi(\d)E(?:Li(\d+)E)?", n)
         name = ("gemm_dma_f32_kernel" if "dma_f32" in n else "gemm_x3_kernel") + "<%s, %s%s>" % (
-            tag.group(1), tag.group(2), ", %s terms" % tag.group(3) if tag.group(3) else "")
+            tag.group(1), tag.group(2), (", %s terms" if "dma_f32" not in n else ", BN %s") % tag.group(3) if tag.group(3) else "")
         print("%s: %s VGPRs, %s B scratch (tile-end paths), MFMA runs %s, scratch ops inside %d, vmcnt(0) inside %d"
               % (name, regs, scratch, [y - x for x, y in runs], sc, vm))
         bad += sc + vm
