@@ -44,6 +44,16 @@
 #include "ff_common.h"
 #include "ff_device.h"
 
+// Timing experiment (tools/x3_phase_probe.py, -DX3_EXP_STAMP): wave 0 of workgroup 0 of gemm_x3_kernel sums, over its K-loop iterations,
+// the shader-clock time of (0) the MFMA block with everything placed in its gaps, (1) the wait for the DMA / fragment reads behind
+// it, (2) the segment-end branch + block barrier, (3) the rest of the iteration; [4] = iterations, [5] = whole kernel.
+#ifdef X3_EXP_STAMP
+__device__ unsigned long long ff_exp_x3_stamps[8];
+extern "C" int ff_exp_read_x3_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_exp_x3_stamps), sizeof(ff_exp_x3_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -740,9 +750,18 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
   constexpr int DM0 = NI == 4 ? NRD : NMF - NP;   // first DMA piece
   int s0 = 0, s1 = 1;   // ring slots of slice s, s + 1  (slice s + RING goes to slot s0)
   const int total = 2 * (u1 - u0);
+#ifdef X3_EXP_STAMP
+  const bool stamping = blockIdx.x == 0 && wave == 0;
+  unsigned long long st_d[4] = {0, 0, 0, 0}, st_n = 0, st_t3 = 0;
+  const unsigned long long st_begin = __builtin_readcyclecounter();
+#endif
   for (int s = 0; s < total; s += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+#ifdef X3_EXP_STAMP
+      unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0;
+      if (stamping) { st_t0 = __builtin_readcyclecounter(); if (st_n) st_d[3] += st_t0 - st_t3; }
+#endif
       const unsigned nb = lds0 + s1 * SLOT;   // slot of slice s + 1
       if (MODE == 1) {   // the rows split in this iteration belong to the next segment's tile when this is the segment's last slice
         const bool nx = cp_cnt + 1 == cp_n;
@@ -794,6 +813,9 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
         __builtin_amdgcn_sched_barrier(0);
       }
       if (SPC >= NMF) split_collect(af[u ^ 1]);
+#ifdef X3_EXP_STAMP
+      if (stamping) st_t1 = __builtin_readcyclecounter();
+#endif
       // slice s + 2 has landed (own pieces), every fragment of slice s + 1 is in registers
 #if defined(X3_EXP_NOVMWAIT)      // probe: the loop never waits for its DMA (reads whatever the LDS holds)
       __builtin_amdgcn_s_waitcnt(0x0F70 & ~0x0F00);   // lgkmcnt(0) only
@@ -804,6 +826,9 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
       for (int p = 0; p < NT; ++p)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[u ^ 1][p][ni]));
+#ifdef X3_EXP_STAMP
+      if (stamping) st_t2 = __builtin_readcyclecounter();
+#endif
       if (++cp_cnt == cp_n) {  // block-uniform: the last slice of the segment was just issued
         end_segment();
         if (++cp_p < nseg) begin_segment(cp_p);
@@ -842,8 +867,17 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
 #if !defined(X3_EXP_FIXEDSLOT)      // probe: without the ring rotation (slot offsets become loop constants)
       s0 = s1; s1 = s1 + 1 == RING ? 0 : s1 + 1;
 #endif
+#ifdef X3_EXP_STAMP
+      if (stamping) { st_t3 = __builtin_readcyclecounter(); st_d[0] += st_t1 - st_t0; st_d[1] += st_t2 - st_t1; st_d[2] += st_t3 - st_t2; ++st_n; }
+#endif
     }
   }
+#ifdef X3_EXP_STAMP
+  if (stamping && lane == 0) {
+    for (int q = 0; q < 4; ++q) ff_exp_x3_stamps[q] = st_d[q];
+    ff_exp_x3_stamps[4] = st_n; ff_exp_x3_stamps[5] = __builtin_readcyclecounter() - st_begin;
+  }
+#endif
 }
 
 // ---- the same launch structure on the f32 matrix cores ------------------------------------------------------------------------
