@@ -624,8 +624,10 @@ __global__ __launch_bounds__(256, (x3_blocks_per_cu<MODE, NT>())) void gemm_x3_k
         xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         cv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !defined(X3_EXP_NOEPILOAD)      // probe: the epilogue without its bias / residual / table loads (wrong numbers)
         if (xrow && n + 3 < xlim) xv[j] = gload16(xrow + n);
         if (g.bias && n + 3 < g.N) bv[j] = gload16(g.bias + n);
+#endif
         if (MODE == 3 && n + 3 < g.N) cv[j] = gload16(g.colsum + g.w_row0 + n);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1219,8 +1221,10 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_f32_kernel(X3Args g) {
         xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         cv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !defined(X3_EXP_NOEPILOAD)      // probe: the epilogue without its bias / residual / table loads (wrong numbers)
         if (xrow && n + 3 < xlim) xv[j] = gload16(xrow + n);
         if (g.bias && n + 3 < g.N) bv[j] = gload16(g.bias + n);
+#endif
         if (MODE == 3 && n + 3 < g.N) cv[j] = gload16(g.colsum + g.w_row0 + n);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
